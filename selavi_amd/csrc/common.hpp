@@ -1,0 +1,73 @@
+// Shared helpers for the selavi_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace slv {
+
+// ---- error plumbing: C-ABI entry points return 0 / negative code, message is thread local
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, const char* a = "") {
+  snprintf(g_err, sizeof(g_err), fmt, a);
+  return code;
+}
+
+#define SLV_CHECK_ARG(cond, msg)                                              \
+  do {                                                                        \
+    if (!(cond)) return ::slv::fail(-2, "%s: bad argument: " msg, __func__);  \
+  } while (0)
+
+inline int launch_check(const char* fn) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  snprintf(g_err, sizeof(g_err), "%s: kernel launch failed: %s", fn, hipGetErrorString(e));
+  return -3;
+}
+#define SLV_LAUNCH_CHECK()                          \
+  do {                                              \
+    int rc__ = ::slv::launch_check(__func__);       \
+    if (rc__) return rc__;                          \
+  } while (0)
+
+#define SLV_HIP(call)                                                                     \
+  do {                                                                                    \
+    hipError_t e__ = (call);                                                              \
+    if (e__ != hipSuccess) {                                                              \
+      snprintf(::slv::g_err, sizeof(::slv::g_err), "%s: %s -> %s", __func__, #call,       \
+               hipGetErrorString(e__));                                                   \
+      return -4;                                                                          \
+    }                                                                                     \
+  } while (0)
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---- wave-level butterflies (all 64 lanes end up with the result; fixed order => deterministic)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace slv

@@ -1,0 +1,574 @@
+// Sinkhorn-Knopp pseudo-label solver kernels for gfx950 (MI355X).
+//
+// Replaces the torch fp64 ops of /root/reference/src/sk_utils.py:359-422 (optimize_L_sk_gpu) and
+// the per-head softmax64 product of :309-315.  The matrix P (N x K fp64, row-major) is the only
+// large object; every kernel here is HBM-bound and is written as a coalesced streaming pass:
+// one 64-lane wavefront owns a row at a time (lane l holds columns l, l+64, ...), row sums are
+// wave butterflies, column sums are kept per lane in registers and reduced block -> grid in a
+// FIXED order (no atomics) so results are bit-reproducible run to run.
+//
+// The reference reads P twice per iteration (matmul(beta.t(), PS) then matmul(PS, alpha)); here the
+// row pass of iteration t also accumulates the column sums iteration t+1 needs, so P is read once
+// per iteration: algorithmic traffic = N*K*8 bytes/iteration.
+#include "common.hpp"
+#include "../../include/selavi_hip.h"
+
+namespace slv {
+thread_local char g_err[512] = {0};
+
+struct SkCtrl {       // lives at the head of the workspace (64 bytes)
+  int counter;        // iterations executed so far (the reference's _counter)
+  int done;           // 1 -> loop has terminated, later launches are no-ops
+  double err;         // last tested err (init 1e6, sk_utils.py:396)
+  double pad[6];
+};
+
+struct SkWs {
+  SkCtrl* ctrl;
+  double* alpha;    // Kp
+  double* s;        // Kp + 64 ; s[K] carries the err partial so one all-reduce moves both
+  double* partial;  // grid * Kp
+  double* errp;     // grid
+  int Kp;
+};
+
+static inline int kpad(int K) { return ((K + 63) / 64) * 64; }
+
+static inline SkWs carve(void* ws, int K, int grid) {
+  SkWs w;
+  char* p = (char*)ws;
+  w.Kp = kpad(K);
+  w.ctrl = (SkCtrl*)p;
+  p += sizeof(SkCtrl);
+  w.alpha = (double*)p;
+  p += sizeof(double) * w.Kp;
+  w.s = (double*)p;
+  p += sizeof(double) * (w.Kp + 64);
+  w.partial = (double*)p;
+  p += sizeof(double) * (size_t)grid * w.Kp;
+  w.errp = (double*)p;
+  return w;
+}
+
+constexpr int SK_THREADS = 512;           // 8 waves per workgroup
+constexpr int SK_WAVES = SK_THREADS / 64;
+
+// torch.argmax semantics: NaN counts as the maximum, first index wins ties.
+__device__ __forceinline__ bool beats(double a, int ia, double b, int ib) {
+  const bool an = a != a, bn = b != b;
+  if (an != bn) return an;
+  if (!an && a != b) return a > b;
+  return ia < ib;
+}
+
+// ------------------------------------------------------------------------------------------
+// softmax64(lv) * softmax64(la) [^power]   (sk_utils.py:309-315 + :391), one wave per row
+// ------------------------------------------------------------------------------------------
+template <int KJ, bool TWO>
+__global__ __launch_bounds__(SK_THREADS) void sk_prepare_kernel(const float* __restrict__ lv,
+                                                               const float* __restrict__ la,
+                                                               double* __restrict__ P, int64_t N,
+                                                               int K, double power, int do_pow) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * SK_WAVES + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * SK_WAVES;
+  for (int64_t i = wave0; i < N; i += nwaves) {
+    double xv[KJ], xa[KJ];
+    double mv = -INFINITY, ma = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      const int k = lane + 64 * j;
+      xv[j] = (k < K) ? (double)lv[i * K + k] : -INFINITY;
+      mv = fmax(mv, xv[j]);
+      if (TWO) {
+        xa[j] = (k < K) ? (double)la[i * K + k] : -INFINITY;
+        ma = fmax(ma, xa[j]);
+      }
+    }
+    mv = wave_max(mv);
+    if (TWO) ma = wave_max(ma);
+    double sv = 0.0, sa = 0.0;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      const int k = lane + 64 * j;
+      xv[j] = (k < K) ? exp(xv[j] - mv) : 0.0;
+      sv += xv[j];
+      if (TWO) {
+        xa[j] = (k < K) ? exp(xa[j] - ma) : 0.0;
+        sa += xa[j];
+      }
+    }
+    sv = wave_sum(sv);
+    if (TWO) sa = wave_sum(sa);
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      const int k = lane + 64 * j;
+      if (k < K) {
+        double p = xv[j] / sv;
+        if (TWO) p = p * (xa[j] / sa);
+        if (do_pow) p = pow(p, power);
+        P[i * K + k] = p;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sk_pow_kernel(double* __restrict__ P, int64_t n, double power) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) P[i] = pow(P[i], power);
+}
+
+// ------------------------------------------------------------------------------------------
+// block-level fixed-order reduction of the per-lane column accumulators -> partial[block][k]
+// ------------------------------------------------------------------------------------------
+template <int KJ>
+__device__ __forceinline__ void block_reduce_cols(const double (&acc)[KJ], double e, SkWs w,
+                                                  double* sh /* SK_WAVES*KJ*64 + SK_WAVES */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) sh[(wave * KJ + j) * 64 + lane] = acc[j];
+  double* she = sh + SK_WAVES * KJ * 64;
+  if (lane == 0) she[wave] = e;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < KJ * 64; idx += SK_THREADS) {
+    double v = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < SK_WAVES; ++wv) v += sh[wv * KJ * 64 + idx];
+    // idx = j*64 + lane  <->  column k = lane + 64*j
+    w.partial[(size_t)blockIdx.x * w.Kp + idx] = v;
+  }
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < SK_WAVES; ++wv) v += she[wv];
+    w.errp[blockIdx.x] = v;
+  }
+}
+
+// weighted column sums: partial[b][k] = sum_{rows of block b} weight_i * P[i][k]
+template <int KJ>
+__global__ __launch_bounds__(SK_THREADS) void sk_colsum_kernel(const double* __restrict__ P,
+                                                              const double* __restrict__ wgt,
+                                                              double wconst, int64_t N, int K,
+                                                              SkWs w, int64_t rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc[KJ];
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) acc[j] = 0.0;
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t row1 = (row0 + rows_per_block < N) ? row0 + rows_per_block : N;
+  for (int64_t i = row0 + wave; i < row1; i += SK_WAVES) {
+    const double b = wgt ? wgt[i] : wconst;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      const int k = lane + 64 * j;
+      if (k < K) acc[j] += b * P[i * K + k];
+    }
+  }
+  block_reduce_cols<KJ>(acc, 0.0, w, sh);
+}
+
+// ------------------------------------------------------------------------------------------
+// The fused iteration pass  (sk_utils.py:401-405, one read of P)
+//   t_i = sum_k P_ik alpha_k ; beta'_i = c / t_i ; err += |beta_i / beta'_i - 1| (tested iters)
+//   s'_k += beta'_i P_ik  (column sums the NEXT iteration's alpha needs)
+// ------------------------------------------------------------------------------------------
+template <int KJ, int ROWS>
+__global__ __launch_bounds__(SK_THREADS) void sk_pass_kernel(const double* __restrict__ P,
+                                                            int64_t N, int K, double c,
+                                                            double* __restrict__ beta, SkWs w,
+                                                            int64_t rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  if (w.ctrl->done) return;
+  const bool check = (w.ctrl->counter % 10) == 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double al[KJ], acc[KJ];
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) {
+    const int k = lane + 64 * j;
+    al[j] = (k < K) ? w.alpha[k] : 0.0;
+    acc[j] = 0.0;
+  }
+  double e = 0.0;
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t row1 = (row0 + rows_per_block < N) ? row0 + rows_per_block : N;
+  for (int64_t i = row0 + (int64_t)wave * ROWS; i < row1; i += (int64_t)SK_WAVES * ROWS) {
+    double p[ROWS][KJ];
+    double t[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int64_t ii = i + r;
+      const bool rv = ii < row1;
+      t[r] = 0.0;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        const int k = lane + 64 * j;
+        p[r][j] = (rv && k < K) ? P[ii * K + k] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) t[r] += p[r][j] * al[j];
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) t[r] = wave_sum(t[r]);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int64_t ii = i + r;
+      if (ii < row1) {
+        const double bn = c / t[r];
+        if (check) e += fabs(beta[ii] / bn - 1.0);
+        if (lane == 0) beta[ii] = bn;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) acc[j] += bn * p[r][j];
+      }
+    }
+  }
+  block_reduce_cols<KJ>(acc, e, w, sh);
+}
+
+// grid-level fixed-order reduce: s[k] = sum_b partial[b][k];  s[K] = sum_b errp[b]
+__global__ __launch_bounds__(512) void sk_local_reduce_kernel(SkWs w, int K, int grid, int respect_done) {
+  if (respect_done && w.ctrl->done) return;
+  __shared__ double sh[8][64];
+  const int kx = threadIdx.x & 63, by = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kx;
+  double v = 0.0;
+  for (int b = by; b < grid; b += 8) v += w.partial[(size_t)b * w.Kp + k];
+  sh[by][kx] = v;
+  __syncthreads();
+  if (by == 0 && k < K) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sh[q][kx];
+    w.s[k] = t;
+  }
+  if (blockIdx.x == 0) {
+    __syncthreads();
+    double ev = 0.0;
+    for (int b = threadIdx.x; b < grid; b += 512) ev += w.errp[b];
+    // fixed-order tree over the 512 threads
+    __shared__ double she[512];
+    she[threadIdx.x] = ev;
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) she[threadIdx.x] += she[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) w.s[K] = she[0];
+  }
+}
+
+// alpha = r / s and loop control  (sk_utils.py:400-401,403-406)
+__global__ __launch_bounds__(1024) void sk_update_kernel(const double* __restrict__ r, SkWs w, int K,
+                                                        double tol, int max_iter, int first) {
+  const int cnt = w.ctrl->counter;
+  const int was_done = w.ctrl->done;
+  double err = w.ctrl->err;
+  int done = was_done, newc = cnt;
+  if (!was_done && !first) {
+    const bool tested = (cnt % 10) == 0;
+    if (tested) err = w.s[K];
+    newc = cnt + 1;
+    done = (!(err > tol)) || (newc >= max_iter);
+  }
+  __syncthreads();  // everybody has read ctrl before thread 0 rewrites it
+  if (!was_done && !done) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) w.alpha[k] = r[k] / w.s[k];
+  }
+  if (threadIdx.x == 0 && !was_done) {
+    w.ctrl->counter = newc;
+    w.ctrl->done = done;
+    w.ctrl->err = err;
+  }
+}
+
+__global__ void sk_begin_kernel(SkWs w, double* __restrict__ beta, int64_t N_local, double b0) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    w.ctrl->counter = 0;
+    w.ctrl->done = 0;
+    w.ctrl->err = 1e6;
+  }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < N_local; i += stride) beta[i] = b0;
+}
+
+__global__ void sk_status_kernel(SkWs w, double* __restrict__ out) {
+  out[0] = (double)w.ctrl->counter;
+  out[1] = (double)w.ctrl->done;
+  out[2] = w.ctrl->err;
+  out[3] = 0.0;
+}
+
+// labels + cost  (sk_utils.py:411-419): argmax_k (P_ik beta_i) alpha_k ; log of the undone value
+template <int KJ>
+__global__ __launch_bounds__(SK_THREADS) void sk_labels_kernel(const double* __restrict__ P, int64_t N,
+                                                              int K, const double* __restrict__ beta,
+                                                              SkWs w, int64_t* __restrict__ labels,
+                                                              int64_t rows_per_block) {
+  __shared__ double she[SK_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double al[KJ];
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) {
+    const int k = lane + 64 * j;
+    al[j] = (k < K) ? w.alpha[k] : 0.0;
+  }
+  double lsum = 0.0;
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t row1 = (row0 + rows_per_block < N) ? row0 + rows_per_block : N;
+  for (int64_t i = row0 + wave; i < row1; i += SK_WAVES) {
+    const double b = beta[i];
+    double best = 0.0, bestx = 0.0;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      const int k = lane + 64 * j;
+      if (k < K) {
+        const double v = (P[i * K + k] * b) * al[j];                    // :411-412
+        if (bi == 0x7fffffff || beats(v, k, best, bi)) {
+          best = v;
+          bi = k;
+          bestx = (v * (1.0 / al[j])) * (1.0 / b);                      // :416-417
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(best, o, 64);
+      const double ox = __shfl_xor(bestx, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      const bool take = (bi == 0x7fffffff) ? (oi != 0x7fffffff)
+                                           : (oi != 0x7fffffff && beats(ov, oi, best, bi));
+      if (take) {
+        best = ov;
+        bestx = ox;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      labels[i] = bi;
+      const double lg = log(bestx);                                      // :418
+      if (lg == lg) lsum += lg;                                          // nansum
+    }
+  }
+  if (lane == 0) she[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < SK_WAVES; ++q) v += she[q];
+    w.errp[blockIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(512) void sk_sum_errp_kernel(SkWs w, int grid, double* __restrict__ out) {
+  __shared__ double she[512];
+  double ev = 0.0;
+  for (int b = threadIdx.x; b < grid; b += 512) ev += w.errp[b];
+  she[threadIdx.x] = ev;
+  __syncthreads();
+  for (int o = 256; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) she[threadIdx.x] += she[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = she[0];
+}
+
+// ---- KJ dispatch -----------------------------------------------------------------------------
+#define SK_DISPATCH_KJ(K, ...)                                             \
+  do {                                                                     \
+    const int kj__ = ((K) + 63) / 64;                                      \
+    if (kj__ <= 1) { constexpr int KJ = 1; __VA_ARGS__; }                         \
+    else if (kj__ <= 2) { constexpr int KJ = 2; __VA_ARGS__; }                    \
+    else if (kj__ <= 4) { constexpr int KJ = 4; __VA_ARGS__; }                    \
+    else if (kj__ <= 5) { constexpr int KJ = 5; __VA_ARGS__; }                    \
+    else if (kj__ <= 7) { constexpr int KJ = 7; __VA_ARGS__; }                    \
+    else if (kj__ <= 8) { constexpr int KJ = 8; __VA_ARGS__; }                    \
+    else return ::slv::fail(-2, "%s: K > 512 is not supported", __func__);  \
+  } while (0)
+
+static inline size_t sh_bytes(int KJ) { return sizeof(double) * (SK_WAVES * KJ * 64 + SK_WAVES); }
+
+}  // namespace slv
+
+using namespace slv;
+
+extern "C" {
+
+int slv_version(void) { return 1; }
+const char* slv_last_error(void) { return slv::g_err; }
+
+int slv_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len) {
+  int dev = 0;
+  SLV_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  SLV_HIP(hipGetDeviceProperties(&p, dev));
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (wave_size) *wave_size = p.warpSize;
+  if (arch_name && arch_name_len > 0) {
+    strncpy(arch_name, p.gcnArchName, arch_name_len - 1);
+    arch_name[arch_name_len - 1] = 0;
+  }
+  return 0;
+}
+
+size_t slv_sk_workspace_bytes(int K, int grid) {
+  const int Kp = kpad(K);
+  return sizeof(SkCtrl) + sizeof(double) * ((size_t)Kp + (Kp + 64) + (size_t)grid * Kp + grid);
+}
+
+int slv_sk_default_grid(int64_t N, int K) {
+  // 2 workgroups of 8 waves per CU on a 256-CU part; never more blocks than 8-row chunks
+  int64_t g = 512;
+  const int64_t maxg = (N + 7) / 8;
+  if (g > maxg) g = maxg;
+  if (g < 1) g = 1;
+  (void)K;
+  return (int)g;
+}
+
+double* slv_sk_s_ptr(void* ws, int K, int grid) { return carve(ws, K, grid).s; }
+double* slv_sk_alpha_ptr(void* ws, int K, int grid) { return carve(ws, K, grid).alpha; }
+
+int slv_sk_prepare(const float* lv, const float* la, double* P, int64_t N, int K, double power,
+                   slv_stream_t stream) {
+  SLV_CHECK_ARG(lv && la && P && N >= 0 && K > 0, "null pointer or empty shape");
+  if (N == 0) return 0;
+  const int grid = (int)((N + SK_WAVES - 1) / SK_WAVES < 4096 ? (N + SK_WAVES - 1) / SK_WAVES : 4096);
+  SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_prepare_kernel<KJ, true>), dim3(grid), dim3(SK_THREADS), 0,
+                                        (hipStream_t)stream, lv, la, P, N, K, power, power != 1.0));
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_sk_softmax64(const float* logits, double* P, int64_t N, int K, slv_stream_t stream) {
+  SLV_CHECK_ARG(logits && P && N >= 0 && K > 0, "null pointer or empty shape");
+  if (N == 0) return 0;
+  const int grid = (int)((N + SK_WAVES - 1) / SK_WAVES < 4096 ? (N + SK_WAVES - 1) / SK_WAVES : 4096);
+  SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_prepare_kernel<KJ, false>), dim3(grid), dim3(SK_THREADS), 0,
+                                        (hipStream_t)stream, logits, (const float*)nullptr, P, N, K, 1.0,
+                                        0));
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_sk_pow(double* P, int64_t count, double power, slv_stream_t stream) {
+  SLV_CHECK_ARG(P && count >= 0, "null pointer");
+  if (count == 0) return 0;
+  int64_t blocks = (count + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(sk_pow_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, P, count, power);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+static int launch_colsum(const double* P, const double* wgt, double wconst, int64_t N, int K, SkWs w,
+                         int grid, hipStream_t st) {
+  const int64_t rpb = (N + grid - 1) / grid;
+  SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_colsum_kernel<KJ>), dim3(grid), dim3(SK_THREADS), sh_bytes(KJ),
+                                        st, P, wgt, wconst, N, K, w, rpb));
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_sk_colsum(const double* P, const double* row_weight, int64_t N, int K, double* out, void* ws,
+                  int grid, slv_stream_t stream) {
+  SLV_CHECK_ARG(P && out && ws && N > 0 && K > 0 && grid > 0, "null pointer or empty shape");
+  SkWs w = carve(ws, K, grid);
+  int rc = launch_colsum(P, row_weight, 1.0, N, K, w, grid, (hipStream_t)stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sk_local_reduce_kernel, dim3(w.Kp / 64), dim3(512), 0, (hipStream_t)stream, w, K, grid,
+                     0);
+  SLV_LAUNCH_CHECK();
+  SLV_HIP(hipMemcpyAsync(out, w.s, sizeof(double) * K, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int slv_sk_begin(const double* P, int64_t N_local, int64_t N_global, int K, double* beta, void* ws,
+                 int grid, slv_stream_t stream) {
+  SLV_CHECK_ARG(P && beta && ws && N_local > 0 && N_global >= N_local && K > 0 && grid > 0,
+                "null pointer or empty shape");
+  SkWs w = carve(ws, K, grid);
+  const double b0 = 1.0 / (double)N_global;  // sk_utils.py:390
+  hipLaunchKernelGGL(sk_begin_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w, beta, N_local, b0);
+  SLV_LAUNCH_CHECK();
+  // s_0 = beta_0^T P   (the first matmul(beta.t(), PS) of sk_utils.py:401)
+  return launch_colsum(P, nullptr, b0, N_local, K, w, grid, (hipStream_t)stream);
+}
+
+int slv_sk_pass(const double* P, int64_t N_local, int64_t N_global, int K, double* beta, void* ws,
+                int grid, slv_stream_t stream) {
+  SLV_CHECK_ARG(P && beta && ws && N_local > 0 && K > 0 && grid > 0, "null pointer or empty shape");
+  SkWs w = carve(ws, K, grid);
+  const int64_t rpb = (N_local + grid - 1) / grid;
+  const double c = 1.0 / (double)N_global;  // sk_utils.py:395
+  SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_pass_kernel<KJ, 4>), dim3(grid), dim3(SK_THREADS), sh_bytes(KJ),
+                                        (hipStream_t)stream, P, N_local, K, c, beta, w, rpb));
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_sk_iterate(const double* P, int64_t N, int K, double* beta, const double* r, double tol,
+                   int max_iter, int n_iters, void* ws, int grid, slv_stream_t stream) {
+  // single-GPU fast path: n_iters x (pass, local_reduce, update) enqueued from C, no host sync
+  for (int it = 0; it < n_iters; ++it) {
+    int rc = slv_sk_pass(P, N, N, K, beta, ws, grid, stream);
+    if (rc) return rc;
+    rc = slv_sk_local_reduce(K, ws, grid, stream);
+    if (rc) return rc;
+    rc = slv_sk_update(r, K, tol, max_iter, 0, ws, grid, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int slv_sk_local_reduce(int K, void* ws, int grid, slv_stream_t stream) {
+  SLV_CHECK_ARG(ws && K > 0 && grid > 0, "null pointer or empty shape");
+  SkWs w = carve(ws, K, grid);
+  hipLaunchKernelGGL(sk_local_reduce_kernel, dim3(w.Kp / 64), dim3(512), 0, (hipStream_t)stream, w, K, grid,
+                     1);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_sk_update(const double* r, int K, double tol, int max_iter, int first, void* ws, int grid,
+                  slv_stream_t stream) {
+  SLV_CHECK_ARG(r && ws && K > 0 && grid > 0, "null pointer or empty shape");
+  SkWs w = carve(ws, K, grid);
+  hipLaunchKernelGGL(sk_update_kernel, dim3(1), dim3(K < 1024 ? ((K + 63) / 64) * 64 : 1024), 0,
+                     (hipStream_t)stream, r, w, K, tol, max_iter, first);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_sk_status(void* ws, int K, int grid, double* host_out, slv_stream_t stream) {
+  SLV_CHECK_ARG(ws && host_out, "null pointer");
+  SkWs w = carve(ws, K, grid);
+  // the status words are staged through s[K+1..K+4] so the copy is one small D2H
+  double* stage = w.s + K + 8;
+  hipLaunchKernelGGL(sk_status_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, w, stage);
+  SLV_LAUNCH_CHECK();
+  SLV_HIP(hipMemcpyAsync(host_out, stage, 4 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+
+int slv_sk_labels(const double* P, int64_t N_local, int K, const double* beta, void* ws, int grid,
+                  int64_t* labels, double* logsum_out, slv_stream_t stream) {
+  SLV_CHECK_ARG(P && beta && ws && labels && logsum_out && N_local > 0 && K > 0 && grid > 0,
+                "null pointer or empty shape");
+  SkWs w = carve(ws, K, grid);
+  const int64_t rpb = (N_local + grid - 1) / grid;
+  SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_labels_kernel<KJ>), dim3(grid), dim3(SK_THREADS), 0,
+                                        (hipStream_t)stream, P, N_local, K, beta, w, labels, rpb));
+  SLV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sk_sum_errp_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, w, grid, logsum_out);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+"""SK iterations/s at a given size, timed with HIP events around a fixed number of passes."""
+import argparse
+import json
+
+import torch
+
+from selavi_amd import sk_utils
+from selavi_amd._lib import C, ptr, stream
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--N", type=int, default=170752)
+ap.add_argument("--K", type=int, default=309)
+ap.add_argument("--iters", type=int, default=100)
+ap.add_argument("--grid", type=int, default=0)
+a = ap.parse_args()
+N, K = a.N, a.K
+g = torch.Generator(device="cuda").manual_seed(0)
+lv = torch.randn(N, K, device="cuda", generator=g)
+la = torch.randn(N, K, device="cuda", generator=g)
+P = sk_utils.head_probabilities(lv, la, power=10.0)
+be = sk_utils._HIP
+for grid in ([a.grid] if a.grid else [256, 512, 1024, 2048]):
+    ws = be.workspace(K, grid, P.device)
+    beta = torch.empty(N, dtype=torch.float64, device="cuda")
+    r = torch.full((K,), 1.0 / K, dtype=torch.float64, device="cuda")
+    be.begin(P, N, beta, ws, grid); be.local_reduce(K, ws, grid); be.update(r, K, 0.0, 10**9, True, ws, grid)
+    be.iterate(P, beta, r, 0.0, 10**9, 10, ws, grid)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    be.iterate(P, beta, r, 0.0, 10**9, a.iters, ws, grid)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    print(json.dumps(dict(N=N, K=K, grid=grid, us_per_iter=ms * 1e3, iters_per_s=1e3 / ms,
+                          GBps=N * K * 8 / ms / 1e6, frac_of_8TBs=N * K * 8 / ms / 1e6 / 8000)))
