@@ -12,7 +12,9 @@
  *     caller unless marked "host".  The library never allocates outputs and owns no streams.
  *   - every call enqueues work on `stream` (a hipStream_t passed as void*; NULL = default
  *     stream) of the CURRENT device and returns without synchronising unless stated.
- *   - return value: 0 on success, negative on error; slv_last_error() gives a thread-local text.
+ *   - functions returning `int` return a STATUS: 0 on success, negative on error, and
+ *     slv_last_error() gives a thread-local text.  Functions that return a VALUE are declared
+ *     with int32_t / size_t / pointer return types (the ctypes binding keys on this).
  *   - one process per GPU; calls are re-entrant and thread-safe (no global mutable state).
  *   - tensors are dense row-major ("contiguous" in torch terms); activations are N,C,T,H,W
  *     (2-D audio tensors are the T==1 case).
@@ -27,7 +29,7 @@ extern "C" {
 typedef void* slv_stream_t; /* hipStream_t */
 
 /* ---------------------------------------------------------------- library ------------------ */
-int slv_version(void);                 /* ABI version, bumps on any signature change          */
+int32_t slv_version(void);                /* ABI version, bumps on any signature change          */
 const char* slv_last_error(void);      /* thread-local, valid until the next failing call      */
 int slv_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len);
 
@@ -52,7 +54,7 @@ int slv_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_nam
  * After done: ws holds the alpha used by the last executed pass and `beta` the last beta'.
  */
 size_t slv_sk_workspace_bytes(int K, int grid);
-int slv_sk_default_grid(int64_t N, int K);
+int32_t slv_sk_default_grid(int64_t N, int K);
 double* slv_sk_s_ptr(void* ws, int K, int grid);      /* K+1 doubles: column sums + err     */
 double* slv_sk_alpha_ptr(void* ws, int K, int grid);  /* K doubles                          */
 

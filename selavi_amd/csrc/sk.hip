@@ -400,7 +400,7 @@ using namespace slv;
 
 extern "C" {
 
-int slv_version(void) { return 1; }
+int32_t slv_version(void) { return 1; }
 const char* slv_last_error(void) { return slv::g_err; }
 
 int slv_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len) {
@@ -422,7 +422,7 @@ size_t slv_sk_workspace_bytes(int K, int grid) {
   return sizeof(SkCtrl) + sizeof(double) * ((size_t)Kp + (Kp + 64) + (size_t)grid * Kp + grid);
 }
 
-int slv_sk_default_grid(int64_t N, int K) {
+int32_t slv_sk_default_grid(int64_t N, int K) {
   // 2 workgroups of 8 waves per CU on a 256-CU part; never more blocks than 8-row chunks
   int64_t g = 512;
   const int64_t maxg = (N + 7) / 8;

@@ -1,6 +1,10 @@
 """SK iterations/s at a given size, timed with HIP events around a fixed number of passes."""
 import argparse
 import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
