@@ -82,6 +82,123 @@ int slv_sk_labels(const double* P, int64_t N_local, int K, const double* beta, v
                   int64_t* labels /* N_local */, double* logsum_out /* 1 double, device */,
                   slv_stream_t stream);
 
+/* ---------------------------------------------------------------- convolutions ---------------
+ * Replace cuDNN Conv3d/Conv2d forward / backward-data / backward-weight of the torchvision nets
+ * built by model.py:95 (r2plus1d_18) and model.py:114 (ResNet-9) and driven by main.py:284,301.
+ * fp32 in, fp32 accumulate on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
+ *
+ * geom: HOST pointer to 18 int32 = {Bn, Cin, Ti, Hi, Wi, Cout, To, Ho, Wo, kt, kh, kw, st, sh, sw,
+ * pt, ph, pw}; strides 1 or 2; 2-D convs are Ti = kt = 1.  Activations N,C,T,H,W; weights
+ * [Cout][Cin][kt][kh][kw]; all convs bias-free.  `tab` is a DEVICE copy of slv_conv_table().
+ *
+ * Fused BatchNorm (every conv of the model is followed by one):
+ *   in_scale_shift [2][Cin]  : the input is read as relu?(x*scale[c] + shift[c]) (zero padding applied
+ *                              AFTER the affine), i.e. the producer's BN+ReLU is applied on load;
+ *   stat_sum/stat_sq [Cout][slv_conv_fwd_nblk()] : per-channel partial sum / sum of squares of y;
+ *   bwd5 [5][Cout] = {s, h, A1, A2, A3} : the gradient w.r.t. the raw conv output is formed on load
+ *                              as A1*mask*g + A2 + A3*x with mask = relu ? (s*x + h > 0) : 1
+ *                              (BN backward folded into per-channel coefficients, slv_bn_bwd_finalize).
+ */
+int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out /* host, [C*taps][2] */);
+int32_t slv_conv_fwd_nblk(const int32_t* geom);
+int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const int32_t* tab,
+                 const float* in_scale_shift /* nullable */, int in_relu, float* y,
+                 float* stat_sum /* nullable */, float* stat_sq, slv_stream_t stream);
+/* wt[ci][co][tap] = w[co][ci][tap]  (the dgrad kernel reads its weight matrix K-contiguous) */
+int slv_conv_wt_transform(const float* w, float* wt, int Cout, int Cin, int taps, slv_stream_t stream);
+/* dx = conv_transpose(dXout) (+ addend);  dXout = bwd5 ? fused(dy, x_out) : dy.  tab = dgrad table */
+int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* x_out /* nullable */,
+                   const float* wt, const int32_t* tab, const float* bwd5 /* nullable */, int relu,
+                   float* dx, const float* addend /* nullable, may alias dx */, slv_stream_t stream);
+size_t slv_conv_wgrad_ws_bytes(const int32_t* geom);
+/* dw = sum_p dXout[co,p] * act(x_in)[ci, p*stride+tap-pad]; deterministic split-K via `ws`.  tab = fwd table */
+int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_out /* nullable */,
+                   const float* bwd5 /* nullable */, int a_relu, const float* x_in,
+                   const float* in_scale_shift /* nullable */, int in_relu, const int32_t* tab,
+                   float* dw, void* ws, size_t ws_bytes, slv_stream_t stream);
+/* C[m][n] = sum_k A[m][k] * B[n][k] (+ bias[n]);  A [M][K], B [N][K] row-major (nn.Linear layout) */
+int slv_gemm_nt(const float* A, const float* B, const float* bias /* nullable */, float* C, int M,
+                int N, int K, int ldc, slv_stream_t stream);
+
+/* ---------------------------------------------------------------- BatchNorm / pools / SGD -----
+ * torch BatchNorm3d/2d train+eval, ReLU, residual add, AdaptiveAvgPool(1), MaxPool2d(3,2,1) of the
+ * same nets; torch.optim.SGD(momentum, weight_decay) of main.py:132-137.  Tensors [Bn][C][P].
+ * SyncBN (main.py:117-118): all-reduce(sum) the double `sums` buffers between the two calls.     */
+int slv_bn_partials_to_sums(const float* psum, const float* psq, int nblk, int C,
+                            double* sums /* [2][C] */, slv_stream_t stream);
+int slv_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                    float* running_mean /* nullable: no update */, float* running_var, float momentum,
+                    float eps, float* mean_invstd /* [2][C] */, float* scale_shift /* [2][C] */, int C,
+                    slv_stream_t stream);
+int slv_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* mean_invstd /* nullable */,
+                       float* scale_shift, int C, slv_stream_t stream);
+/* out = relu?(x*s+h + (res ? (res_ss ? res*rs+rh : res) : 0)) : block tail / activation materialise */
+int slv_bn_act(const float* x, const float* scale_shift, const float* res /* nullable */,
+               const float* res_scale_shift /* nullable */, int relu, float* out, int Bn, int C,
+               int64_t P, slv_stream_t stream);
+int32_t slv_bn_bwd_nsplit(int Bn, int C, int64_t P);
+/* partial[c][nsplit][2] = {sum g', sum g' xhat}; g' = g masked by (scale_shift_mask: own BN output > 0)
+ * or (v_mask > 0, masked gradient also written to g_out) or unmasked; optional second BN (x2) sharing g' */
+int slv_bn_bwd_reduce(const float* g, const float* x, const float* mean_invstd,
+                      const float* scale_shift_mask /* nullable */, const float* v_mask /* nullable */,
+                      const float* x2 /* nullable */, const float* mean_invstd2, float* g_out,
+                      float* partial, float* partial2, int Bn, int C, int64_t P, int nsplit,
+                      slv_stream_t stream);
+int slv_bn_bwd_sums(const float* partial, int nsplit, int C, double* sums /* [2][C] */,
+                    slv_stream_t stream);
+int slv_bn_bwd_finalize(const double* sums, double count, const float* gamma, const float* mean_invstd,
+                        const float* scale_shift /* nullable: no relu mask */, float* bwd5 /* [5][C] */,
+                        float* dgamma /* nullable */, float* dbeta, int accumulate, int C,
+                        slv_stream_t stream);
+int slv_avgpool_fwd(const float* v, float* out, int rows, int P, slv_stream_t stream);
+int slv_avgpool_bwd(const float* dout, float* dv, int rows, int P, slv_stream_t stream);
+int slv_bnrelu_maxpool_fwd(const float* x, const float* scale_shift, float* out, uint8_t* idx, int Bn,
+                           int C, int H, int W, slv_stream_t stream);
+int slv_maxpool_bwd(const float* dout, const uint8_t* idx, float* dy, int Bn, int C, int H, int W,
+                    slv_stream_t stream);
+/* params/grads/bufs/sizes: HOST arrays of n_tensors device pointers / element counts */
+int slv_sgd_step(const void* const* params, const void* const* grads, const void* const* bufs,
+                 const int64_t* sizes, int n_tensors, float lr, float momentum, float weight_decay,
+                 int first_step, slv_stream_t stream);
+int slv_fill_f32(float* p, float value, int64_t n, slv_stream_t stream);
+
+/* ---------------------------------------------------------------- grouped heads + loss ---------
+ * All G = 2*headcount heads per launch (model.py:62-90,233-252; utils.py:377-387; main.py:291-293).
+ * Activations are stacked [G][B][dim]; parameter pointers come as HOST arrays of G device pointers
+ * (each head keeps its own nn.Parameter so state_dict keys match the reference).
+ * x: shared_x ? [2][B][IN] (group g reads modality g / hc) : [G][B][IN].                          */
+int slv_heads_linear_fwd(const float* x, int shared_x, int hc, const float* mask /* nullable [G][B][IN] */,
+                         float mask_scale, const void* const* W, const void* const* bias /* nullable */,
+                         float* out, int G, int B, int IN, int OUT, slv_stream_t stream);
+int slv_heads_bn_stats(const float* h, double* sums /* [G][2][C] */, int G, int B, int C,
+                       slv_stream_t stream);
+int slv_heads_bn_apply(const float* h, const double* sums, double count, const void* const* gamma,
+                       const void* const* beta, const void* const* running_mean,
+                       const void* const* running_var, const float* mask2 /* nullable */,
+                       float mask_scale, float momentum, float eps, int training, float* a,
+                       float* mean_invstd /* [G][2][C] */, int G, int B, int C, slv_stream_t stream);
+int slv_heads_ce(const float* logits, const int64_t* labels /* [B][label_stride], column g % hc */,
+                 int label_stride, int hc, float* loss_rows /* [G*B] */, float* dlogits /* nullable */,
+                 float grad_scale, int G, int B, int K, slv_stream_t stream);
+int slv_heads_linear_bwd_w(const float* dout, const float* x, int shared_x, int hc, const float* mask,
+                           float mask_scale, float* dW /* [G][OUT][IN] */, float* dbias /* nullable */,
+                           int G, int B, int IN, int OUT, slv_stream_t stream);
+int slv_heads_linear_bwd_x(const float* dout, const void* const* W, const float* mask, float mask_scale,
+                           float* dx /* [G][B][IN] */, int G, int B, int IN, int OUT, slv_stream_t stream);
+int slv_heads_bn_bwd_stats(const float* da, const float* h, const float* mean_invstd,
+                           const void* const* gamma, const void* const* beta, const float* mask2,
+                           float mask_scale, double* sums /* [G][2][C] */, int G, int B, int C,
+                           slv_stream_t stream);
+int slv_heads_bn_bwd_apply(const float* da, const float* h, const float* mean_invstd,
+                           const void* const* gamma, const void* const* beta, const float* mask2,
+                           float mask_scale, const double* sums, double count, float* dh, float* dgamma,
+                           float* dbeta, int G, int B, int C, slv_stream_t stream);
+int slv_heads_sum_groups(const float* src /* [2*hc][n] */, float* out /* [2][n] */, int hc, int64_t n,
+                         slv_stream_t stream);
+int slv_rowwise_affine(const float* x, const float* scale_shift, int relu, float* y, int64_t rows, int C,
+                       slv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

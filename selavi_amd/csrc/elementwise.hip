@@ -1,0 +1,490 @@
+// HBM-bound kernels around the convolutions: BatchNorm statistics/finalize, the block-tail
+// "BN + residual + ReLU" materialisation, BN backward reductions, pools and the fused SGD step.
+// Reference semantics: torch BatchNorm3d/2d (train + eval), ReLU, residual add, AdaptiveAvgPool,
+// MaxPool2d(3,2,1) as used by the torchvision nets of /root/reference/model.py:95,114; SGD of
+// main.py:132-137.
+#include "common.hpp"
+#include "../../include/selavi_hip.h"
+
+namespace slv {
+
+// ------------------------------------------------------------------ BN statistics
+// partial[c][nblk] (float, written by the conv epilogue) -> sums[2C] (double): sum, sum of squares
+__global__ __launch_bounds__(256) void bn_partials_to_sums_kernel(const float* __restrict__ ps,
+                                                                 const float* __restrict__ pq, int nblk,
+                                                                 int C, double* __restrict__ sums) {
+  __shared__ double sh[2][256];
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) {
+    s += (double)ps[(size_t)c * nblk + i];
+    q += (double)pq[(size_t)c * nblk + i];
+  }
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sums[c] = sh[0][0];
+    sums[C + c] = sh[1][0];
+  }
+}
+
+// sums -> mean/invstd (saved for backward), scale/shift (consumer prologue), running stats update
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, float momentum, float eps,
+                                   float* __restrict__ mean_invstd, float* __restrict__ scale_shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sums[c] / count;
+  double var = sums[C + c] / count - mean * mean;  // biased
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  mean_invstd[c] = meanf;
+  mean_invstd[C + c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = beta[c] - meanf * sc;
+  if (rmean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * meanf;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                      float* __restrict__ mean_invstd, float* __restrict__ scale_shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rvar[c] + eps);
+  const float sc = gamma[c] * invstd;
+  if (mean_invstd) {
+    mean_invstd[c] = rmean[c];
+    mean_invstd[C + c] = invstd;
+  }
+  scale_shift[c] = sc;
+  scale_shift[C + c] = beta[c] - rmean[c] * sc;
+}
+
+// ------------------------------------------------------------------ block tail (forward)
+// out = relu?( x*s + h  +  (res ? (rss ? res*rs + rh : res) : 0) ),  tensors [Bn][C][P]
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ ss,
+                                                    const float* __restrict__ res, const float* __restrict__ rss,
+                                                    int relu, float* __restrict__ out, int C, int P,
+                                                    size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / P) % C);
+    float v = x[i] * ss[c] + ss[C + c];
+    if (res) v += rss ? (res[i] * rss[c] + rss[C + c]) : res[i];
+    out[i] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+// ------------------------------------------------------------------ BN backward reductions
+// For channel c (blockIdx.x) and slice blockIdx.y of the (b,p) space:
+//   g' = mask * g ;  partial = { sum g', sum g' * xhat(x) [, sum g' * xhat2(x2)] }
+// MASK 0: none; 1: own BN output > 0 (s*x+h); 2: external tensor v > 0 (and g' is written to gout)
+template <int MASK, bool TWO>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ gin,
+                                                           const float* __restrict__ x,
+                                                           const float* __restrict__ mi,  // mean,invstd [2C]
+                                                           const float* __restrict__ ss,  // MASK 1
+                                                           const float* __restrict__ v,   // MASK 2
+                                                           const float* __restrict__ x2, const float* __restrict__ mi2,
+                                                           float* __restrict__ gout, float* __restrict__ part,
+                                                           float* __restrict__ part2, int Bn, int C, int P,
+                                                           int nsplit) {
+  __shared__ float sh[3][256];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const long long tot = (long long)Bn * P;
+  const long long per = (tot + nsplit - 1) / nsplit;
+  const long long e0 = sp * per, e1 = (e0 + per < tot) ? e0 + per : tot;
+  const float mean = mi[c], invstd = mi[C + c];
+  float mean2 = 0.f, invstd2 = 0.f, s_ = 0.f, h_ = 0.f;
+  if (TWO) { mean2 = mi2[c]; invstd2 = mi2[C + c]; }
+  if (MASK == 1) { s_ = ss[c]; h_ = ss[C + c]; }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
+    const long long b = e / P;
+    const size_t ad = ((size_t)b * C + c) * P + (size_t)(e - b * P);
+    float g = gin[ad];
+    const float xv = x[ad];
+    if (MASK == 1) g = (xv * s_ + h_ > 0.f) ? g : 0.f;
+    if (MASK == 2) {
+      g = (v[ad] > 0.f) ? g : 0.f;
+      gout[ad] = g;
+    }
+    a0 += g;
+    a1 += g * ((xv - mean) * invstd);
+    if (TWO) a2 += g * ((x2[ad] - mean2) * invstd2);
+  }
+  sh[0][threadIdx.x] = a0;
+  sh[1][threadIdx.x] = a1;
+  sh[2][threadIdx.x] = a2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+      sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[((size_t)c * nsplit + sp) * 2 + 0] = sh[0][0];
+    part[((size_t)c * nsplit + sp) * 2 + 1] = sh[1][0];
+    if (TWO) {
+      part2[((size_t)c * nsplit + sp) * 2 + 0] = sh[0][0];
+      part2[((size_t)c * nsplit + sp) * 2 + 1] = sh[2][0];
+    }
+  }
+}
+
+__global__ void bn_bwd_sums_kernel(const float* __restrict__ part, int nsplit, int C, double* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    a += (double)part[((size_t)c * nsplit + s) * 2];
+    b += (double)part[((size_t)c * nsplit + s) * 2 + 1];
+  }
+  sums[c] = a;
+  sums[C + c] = b;
+}
+
+// dx = A1*g' + A2 + A3*x  with  A1 = gamma*invstd, A3 = -A1*c2*invstd, A2 = -A1*c1 - A3*mean,
+// c1 = sum g'/n, c2 = sum g' xhat / n.   bwd5 = {s, h, A1, A2, A3} (s,h = forward scale/shift for the mask)
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mi,
+                                       const float* __restrict__ ss, float* __restrict__ bwd5,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                       int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sg = sums[c], sgx = sums[C + c];
+  const float invstd = mi[C + c], mean = mi[c];
+  const float A1 = gamma[c] * invstd;
+  const float c1 = (float)(sg / count), c2 = (float)(sgx / count);
+  const float A3 = -A1 * c2 * invstd;
+  const float A2 = -A1 * c1 - A3 * mean;
+  bwd5[c] = ss ? ss[c] : 0.f;
+  bwd5[C + c] = ss ? ss[C + c] : 0.f;
+  bwd5[2 * C + c] = A1;
+  bwd5[3 * C + c] = A2;
+  bwd5[4 * C + c] = A3;
+  if (dgamma) {
+    if (accumulate) {
+      dgamma[c] += (float)sgx;
+      dbeta[c] += (float)sg;
+    } else {
+      dgamma[c] = (float)sgx;
+      dbeta[c] = (float)sg;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ pools
+// adaptive average pool to 1: out[row] = mean_p v[row][p], one wave per row
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ v, float* __restrict__ out,
+                                                         int rows, int P) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int p = threadIdx.x & 63; p < P; p += 64) s += v[(size_t)row * P + p];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) out[row] = s / (float)P;
+}
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dv,
+                                                         int P, size_t total) {
+  const float inv = 1.f / (float)P;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    dv[i] = dout[i / P] * inv;
+}
+
+// relu(bn(x)) -> MaxPool2d(3, stride 2, pad 1); idx = winning tap 0..8 (first max wins, like torch)
+__global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ ss,
+                                                                float* __restrict__ out,
+                                                                unsigned char* __restrict__ idx, int C, int H,
+                                                                int W, int Ho, int Wo, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int wo = (int)(i % Wo);
+    size_t r = i / Wo;
+    const int ho = (int)(r % Ho);
+    r /= Ho;  // r = b*C + c
+    const int c = (int)(r % C);
+    const float s = ss[c], h = ss[C + c];
+    float best = -INFINITY;
+    int bi = 0;
+    bool any = false;
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hh = ho * 2 - 1 + dh;
+      if (hh < 0 || hh >= H) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int ww = wo * 2 - 1 + dw;
+        if (ww < 0 || ww >= W) continue;
+        const float v = fmaxf(x[(r * H + hh) * W + ww] * s + h, 0.f);
+        if (!any || v > best || v != v) {
+          best = v;
+          bi = dh * 3 + dw;
+          any = true;
+        }
+      }
+    }
+    out[i] = best;
+    idx[i] = (unsigned char)bi;
+  }
+}
+// gather form (deterministic): dy[b,c,h,w] = sum over the <=4 windows that contain (h,w) and chose it
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout,
+                                                         const unsigned char* __restrict__ idx,
+                                                         float* __restrict__ dy, int H, int W, int Ho, int Wo,
+                                                         size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    size_t r = i / W;
+    const int h = (int)(r % H);
+    r /= H;
+    float g = 0.f;
+    for (int ho = (h + 1) / 2 - 1; ho <= (h + 1) / 2; ++ho) {
+      if (ho < 0 || ho >= Ho) continue;
+      const int dh = h - (ho * 2 - 1);
+      if (dh < 0 || dh > 2) continue;
+      for (int wo = (w + 1) / 2 - 1; wo <= (w + 1) / 2; ++wo) {
+        if (wo < 0 || wo >= Wo) continue;
+        const int dw = w - (wo * 2 - 1);
+        if (dw < 0 || dw > 2) continue;
+        const size_t o = (r * Ho + ho) * Wo + wo;
+        if (idx[o] == dh * 3 + dw) g += dout[o];
+      }
+    }
+    dy[i] = g;
+  }
+}
+
+// ------------------------------------------------------------------ fused multi-tensor SGD
+// torch.optim.SGD (momentum, weight decay, no nesterov/dampening): d = g + wd*p ; buf = mu*buf + d
+// (buf = d on the first step) ; p -= lr*buf.     Up to SGD_CHUNK tensors per launch.
+constexpr int SGD_CHUNK = 48;
+struct SgdTable {
+  float* p[SGD_CHUNK];
+  const float* g[SGD_CHUNK];
+  float* m[SGD_CHUNK];
+  long long n[SGD_CHUNK];
+  int blk0[SGD_CHUNK + 1];  // first block of each tensor
+  int count;
+};
+__global__ __launch_bounds__(256) void sgd_kernel(const SgdTable t, float lr, float mu, float wd, int first) {
+  // find the tensor this block works on (count <= 48: linear scan by one lane is fine)
+  int ti = 0;
+  while (ti + 1 < t.count && (int)blockIdx.x >= t.blk0[ti + 1]) ++ti;
+  const long long base = (long long)(blockIdx.x - t.blk0[ti]) * 4096;
+  float* __restrict__ p = t.p[ti];
+  const float* __restrict__ g = t.g[ti];
+  float* __restrict__ m = t.m[ti];
+  const long long n = t.n[ti];
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const long long i = base + j * 256 + threadIdx.x;
+    if (i < n) {
+      const float pv = p[i];
+      const float d = g[i] + wd * pv;
+      const float b = first ? d : mu * m[i] + d;
+      m[i] = b;
+      p[i] = pv - lr * b;
+    }
+  }
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+static inline unsigned grid_for(size_t n, int cap = 4096) {
+  size_t b = (n + 255) / 256;
+  if (b > (size_t)cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace slv
+
+using namespace slv;
+
+extern "C" {
+
+int slv_bn_partials_to_sums(const float* psum, const float* psq, int nblk, int C, double* sums,
+                            slv_stream_t stream) {
+  SLV_CHECK_ARG(psum && psq && sums && nblk > 0 && C > 0, "null pointer or empty shape");
+  hipLaunchKernelGGL(bn_partials_to_sums_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, psum, psq, nblk, C,
+                     sums);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, float* mean_invstd, float* scale_shift, int C,
+                    slv_stream_t stream) {
+  SLV_CHECK_ARG(sums && gamma && beta && mean_invstd && scale_shift && C > 0 && count > 0, "bad argument");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, mean_invstd, scale_shift, C);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, float* mean_invstd, float* scale_shift, int C, slv_stream_t stream) {
+  SLV_CHECK_ARG(gamma && beta && running_mean && running_var && scale_shift && C > 0, "bad argument");
+  hipLaunchKernelGGL(bn_eval_params_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, mean_invstd, scale_shift, C);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_bn_act(const float* x, const float* scale_shift, const float* res, const float* res_scale_shift, int relu,
+               float* out, int Bn, int C, int64_t P, slv_stream_t stream) {
+  SLV_CHECK_ARG(x && scale_shift && out && Bn > 0 && C > 0 && P > 0, "bad argument");
+  const size_t total = (size_t)Bn * C * P;
+  hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, scale_shift,
+                     res, res_scale_shift, relu, out, C, (int)P, total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int32_t slv_bn_bwd_nsplit(int Bn, int C, int64_t P) {
+  const long long tot = (long long)Bn * P;
+  long long s = (2048 + C - 1) / C;          // ~2048 workgroups in total
+  const long long maxs = (tot + 1023) / 1024;  // >= 1024 elements per slice
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  return (int32_t)s;
+}
+
+int slv_bn_bwd_reduce(const float* g, const float* x, const float* mean_invstd, const float* scale_shift_mask,
+                      const float* v_mask, const float* x2, const float* mean_invstd2, float* g_out, float* partial,
+                      float* partial2, int Bn, int C, int64_t P, int nsplit, slv_stream_t stream) {
+  SLV_CHECK_ARG(g && x && mean_invstd && partial && Bn > 0 && C > 0 && P > 0 && nsplit > 0, "bad argument");
+  SLV_CHECK_ARG(!(scale_shift_mask && v_mask), "choose one mask source");
+  SLV_CHECK_ARG(!v_mask || g_out, "masked gradient output required with v_mask");
+  SLV_CHECK_ARG(!x2 || (mean_invstd2 && partial2), "second BN needs its stats and partial buffer");
+  dim3 grid(C, nsplit);
+  hipStream_t st = (hipStream_t)stream;
+#define SLV_RED(MASK, TWO)                                                                                   \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<MASK, TWO>), grid, dim3(256), 0, st, g, x, mean_invstd,            \
+                     scale_shift_mask, v_mask, x2, mean_invstd2, g_out, partial, partial2, Bn, C, (int)P, nsplit)
+  if (v_mask) {
+    if (x2) SLV_RED(2, true); else SLV_RED(2, false);
+  } else if (scale_shift_mask) {
+    if (x2) SLV_RED(1, true); else SLV_RED(1, false);
+  } else {
+    if (x2) SLV_RED(0, true); else SLV_RED(0, false);
+  }
+#undef SLV_RED
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_bn_bwd_sums(const float* partial, int nsplit, int C, double* sums, slv_stream_t stream) {
+  SLV_CHECK_ARG(partial && sums && nsplit > 0 && C > 0, "bad argument");
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nsplit,
+                     C, sums);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_bn_bwd_finalize(const double* sums, double count, const float* gamma, const float* mean_invstd,
+                        const float* scale_shift, float* bwd5, float* dgamma, float* dbeta, int accumulate, int C,
+                        slv_stream_t stream) {
+  SLV_CHECK_ARG(sums && gamma && mean_invstd && bwd5 && C > 0 && count > 0, "bad argument");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, count,
+                     gamma, mean_invstd, scale_shift, bwd5, dgamma, dbeta, accumulate, C);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_avgpool_fwd(const float* v, float* out, int rows, int P, slv_stream_t stream) {
+  SLV_CHECK_ARG(v && out && rows > 0 && P > 0, "bad argument");
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, v, out, rows, P);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_avgpool_bwd(const float* dout, float* dv, int rows, int P, slv_stream_t stream) {
+  SLV_CHECK_ARG(dout && dv && rows > 0 && P > 0, "bad argument");
+  const size_t total = (size_t)rows * P;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, dv, P,
+                     total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_bnrelu_maxpool_fwd(const float* x, const float* scale_shift, float* out, uint8_t* idx, int Bn, int C,
+                           int H, int W, slv_stream_t stream) {
+  SLV_CHECK_ARG(x && scale_shift && out && idx && Bn > 0 && C > 0 && H > 0 && W > 0, "bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)Bn * C * Ho * Wo;
+  hipLaunchKernelGGL(bnrelu_maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x,
+                     scale_shift, out, idx, C, H, W, Ho, Wo, total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_maxpool_bwd(const float* dout, const uint8_t* idx, float* dy, int Bn, int C, int H, int W,
+                    slv_stream_t stream) {
+  SLV_CHECK_ARG(dout && idx && dy && Bn > 0 && C > 0 && H > 0 && W > 0, "bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)Bn * C * H * W;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, idx, dy, H,
+                     W, Ho, Wo, total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_sgd_step(const void* const* params, const void* const* grads, const void* const* bufs,
+                 const int64_t* sizes, int n_tensors, float lr, float momentum, float weight_decay, int first_step,
+                 slv_stream_t stream) {
+  SLV_CHECK_ARG(params && grads && bufs && sizes && n_tensors >= 0, "null pointer (host arrays expected)");
+  int i = 0;
+  while (i < n_tensors) {
+    SgdTable t;
+    t.count = 0;
+    int blocks = 0;
+    while (i < n_tensors && t.count < SGD_CHUNK) {
+      if (sizes[i] > 0) {
+        const int k = t.count++;
+        t.p[k] = (float*)params[i];
+        t.g[k] = (const float*)grads[i];
+        t.m[k] = (float*)bufs[i];
+        t.n[k] = sizes[i];
+        t.blk0[k] = blocks;
+        blocks += (int)((sizes[i] + 4095) / 4096);
+      }
+      ++i;
+    }
+    t.blk0[t.count] = blocks;
+    if (t.count == 0) break;
+    hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, lr, momentum, weight_decay,
+                       first_step);
+    SLV_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int slv_fill_f32(float* p, float value, int64_t n, slv_stream_t stream) {
+  SLV_CHECK_ARG(p && n >= 0, "bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, p, value, (size_t)n);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

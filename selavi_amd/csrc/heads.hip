@@ -1,0 +1,406 @@
+// Grouped MLP heads + softmax cross-entropy: all 2*headcount heads of the model in ONE launch per
+// stage (the reference loops over heads in Python, model.py:244-251, ~160 tiny kernels).
+// Head g (g < hc: video, g >= hc: audio) is MLPv2 (model.py:62-90):
+//   Dropout -> Linear(512,512,no bias) -> BatchNorm1d -> ReLU -> Dropout -> Linear(512,K)+bias
+// or a plain Linear(512,K) when use_mlp is off.  Loss: utils.get_loss (utils.py:377-387) and the
+// 0.5/0.5 mix of main.py:291-293 folded into the logits gradient scale.
+// These layers are < 0.1 % of the step's FLOPs and are weight-bandwidth bound: one wave per output
+// column (lanes stride the 512-long reduction), wave butterflies, no LDS tiling needed.
+#include "common.hpp"
+#include "../../include/selavi_hip.h"
+
+namespace slv {
+
+constexpr int MAXG = 40;
+struct PtrTab {
+  const float* p[MAXG];
+};
+struct PtrTabW {
+  float* p[MAXG];
+};
+
+// out[g][b][n] = sum_k X(g)[b][k] * (mask ? mask[g][b][k]*msc : 1) * W[g][n][k] (+ bias[g][n])
+// X(g) = xin + (shared_x ? (g / hc) : g) * B*IN
+template <bool MASK>
+__global__ __launch_bounds__(256) void heads_linear_fwd_kernel(const float* __restrict__ xin, int shared_x, int hc,
+                                                              const float* __restrict__ mask, float msc,
+                                                              const PtrTab W, const PtrTab bias, int has_bias,
+                                                              float* __restrict__ out, int B, int IN, int OUT) {
+  const int g = blockIdx.y;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= OUT) return;
+  const int lane = threadIdx.x & 63;
+  const float* __restrict__ w = W.p[g] + (size_t)n * IN;
+  const float* __restrict__ x = xin + (size_t)(shared_x ? g / hc : g) * B * IN;
+  const float* __restrict__ mk = MASK ? mask + (size_t)g * B * IN : nullptr;
+  const float bv = has_bias ? bias.p[g][n] : 0.f;
+  for (int b = 0; b < B; ++b) {
+    float s = 0.f;
+    for (int k = lane; k < IN; k += 64) {
+      float xv = x[(size_t)b * IN + k];
+      if (MASK) xv *= mk[(size_t)b * IN + k] * msc;
+      s += xv * w[k];
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[((size_t)g * B + b) * OUT + n] = s + bv;
+  }
+}
+
+// sums[g][0][c] = sum_b h ; sums[g][1][c] = sum_b h^2     (double, for the SyncBN all-reduce)
+__global__ void heads_bn_stats_kernel(const float* __restrict__ h, double* __restrict__ sums, int G, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  const int g = i / C, c = i - g * C;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const double v = (double)h[((size_t)g * B + b) * C + c];
+    s += v;
+    q += v * v;
+  }
+  sums[((size_t)g * 2) * C + c] = s;
+  sums[((size_t)g * 2 + 1) * C + c] = q;
+}
+
+// a = relu(bn(h)) * mask2 * msc ; training: batch stats from sums + running update ; eval: running stats
+__global__ void heads_bn_apply_kernel(const float* __restrict__ h, const double* __restrict__ sums, double count,
+                                      const PtrTab gamma, const PtrTab beta, const PtrTabW rmean, const PtrTabW rvar,
+                                      const float* __restrict__ mask2, float msc, float momentum, float eps,
+                                      int training, float* __restrict__ a, float* __restrict__ mean_invstd, int G,
+                                      int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  const int g = i / C, c = i - g * C;
+  float mean, invstd;
+  if (training) {
+    const double m = sums[((size_t)g * 2) * C + c] / count;
+    double var = sums[((size_t)g * 2 + 1) * C + c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean.p[g][c] = (1.f - momentum) * rmean.p[g][c] + momentum * mean;
+    rvar.p[g][c] = (1.f - momentum) * rvar.p[g][c] + momentum * (float)unb;
+  } else {
+    mean = rmean.p[g][c];
+    invstd = 1.f / sqrtf(rvar.p[g][c] + eps);
+  }
+  mean_invstd[((size_t)g * 2) * C + c] = mean;
+  mean_invstd[((size_t)g * 2 + 1) * C + c] = invstd;
+  const float sc = gamma.p[g][c] * invstd, sh = beta.p[g][c] - mean * sc;
+  for (int b = 0; b < B; ++b) {
+    const size_t ad = ((size_t)g * B + b) * C + c;
+    float v = fmaxf(h[ad] * sc + sh, 0.f);
+    if (mask2) v *= mask2[ad] * msc;
+    a[ad] = v;
+  }
+}
+
+// softmax cross-entropy per (g, b) row, one wave per row.
+// loss_rows[g*B+b] = lse - logit[label] ; dlogits = (softmax - onehot) * gscale
+__global__ __launch_bounds__(256) void heads_ce_kernel(const float* __restrict__ logits,
+                                                      const int64_t* __restrict__ labels, int label_stride, int hc,
+                                                      float* __restrict__ loss_rows, float* __restrict__ dlogits,
+                                                      float gscale, int G, int B, int K) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= G * B) return;
+  const int lane = threadIdx.x & 63;
+  const int g = row / B, b = row - g * B;
+  const int64_t lab = labels[(size_t)b * label_stride + (g % hc)];
+  const float* __restrict__ z = logits + (size_t)row * K;
+  float mx = -INFINITY;
+  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, z[k]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int k = lane; k < K; k += 64) se += expf(z[k] - mx);
+  se = wave_sum(se);
+  const float lse = mx + logf(se);
+  if (lane == 0) loss_rows[row] = lse - z[lab];
+  if (dlogits) {
+    const float inv = 1.f / se;
+    for (int k = lane; k < K; k += 64) {
+      const float p = expf(z[k] - mx) * inv;
+      dlogits[(size_t)row * K + k] = (p - (k == lab ? 1.f : 0.f)) * gscale;
+    }
+  }
+}
+
+// dW[g][n][k] = sum_b dout[g][b][n] * Xm(g)[b][k] ; dbias[g][n] = sum_b dout[g][b][n]
+template <bool MASK>
+__global__ __launch_bounds__(256) void heads_linear_bwd_w_kernel(const float* __restrict__ dout,
+                                                                const float* __restrict__ xin, int shared_x, int hc,
+                                                                const float* __restrict__ mask, float msc,
+                                                                float* __restrict__ dW, float* __restrict__ dbias,
+                                                                int B, int IN, int OUT) {
+  const int g = blockIdx.y;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= OUT) return;
+  const int lane = threadIdx.x & 63;
+  const float* __restrict__ x = xin + (size_t)(shared_x ? g / hc : g) * B * IN;
+  const float* __restrict__ mk = MASK ? mask + (size_t)g * B * IN : nullptr;
+  float db = 0.f;
+  for (int k = lane; k < IN; k += 64) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float d = dout[((size_t)g * B + b) * OUT + n];
+      float xv = x[(size_t)b * IN + k];
+      if (MASK) xv *= mk[(size_t)b * IN + k] * msc;
+      s += d * xv;
+    }
+    dW[((size_t)g * OUT + n) * IN + k] = s;
+  }
+  if (dbias && lane == 0) {
+    for (int b = 0; b < B; ++b) db += dout[((size_t)g * B + b) * OUT + n];
+    dbias[(size_t)g * OUT + n] = db;
+  }
+}
+
+// dx[g][b][k] = (mask ? mask*msc : 1) * sum_n dout[g][b][n] * W[g][n][k]     (thread per k, BB rows at a time)
+template <bool MASK, int BB>
+__global__ __launch_bounds__(256) void heads_linear_bwd_x_kernel(const float* __restrict__ dout, const PtrTab W,
+                                                                const float* __restrict__ mask, float msc,
+                                                                float* __restrict__ dx, int B, int IN, int OUT) {
+  const int g = blockIdx.y, b0 = blockIdx.z * BB;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= IN) return;
+  const float* __restrict__ w = W.p[g];
+  float acc[BB];
+#pragma unroll
+  for (int i = 0; i < BB; ++i) acc[i] = 0.f;
+  for (int n = 0; n < OUT; ++n) {
+    const float wv = w[(size_t)n * IN + k];
+#pragma unroll
+    for (int i = 0; i < BB; ++i) {
+      if (b0 + i < B) acc[i] += dout[((size_t)g * B + b0 + i) * OUT + n] * wv;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BB; ++i) {
+    if (b0 + i < B) {
+      const size_t ad = ((size_t)g * B + b0 + i) * IN + k;
+      dx[ad] = MASK ? acc[i] * mask[ad] * msc : acc[i];
+    }
+  }
+}
+
+// BN1d backward, stage 1: g' = da * mask2*msc * (bnout > 0);  sums[g][0][c] = sum g', [1] = sum g' xhat
+__global__ void heads_bn_bwd_stats_kernel(const float* __restrict__ da, const float* __restrict__ h,
+                                          const float* __restrict__ mean_invstd, const PtrTab gamma,
+                                          const PtrTab beta, const float* __restrict__ mask2, float msc,
+                                          double* __restrict__ sums, int G, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  const int g = i / C, c = i - g * C;
+  const float mean = mean_invstd[((size_t)g * 2) * C + c], invstd = mean_invstd[((size_t)g * 2 + 1) * C + c];
+  const float ga = gamma.p[g][c], be = beta.p[g][c];
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const size_t ad = ((size_t)g * B + b) * C + c;
+    const float xh = (h[ad] - mean) * invstd;
+    float gv = da[ad];
+    if (mask2) gv *= mask2[ad] * msc;
+    if (!(xh * ga + be > 0.f)) gv = 0.f;
+    s += (double)gv;
+    q += (double)gv * (double)xh;
+  }
+  sums[((size_t)g * 2) * C + c] = s;
+  sums[((size_t)g * 2 + 1) * C + c] = q;
+}
+// stage 2: dh = gamma*invstd*(g' - c1 - xhat*c2) ; dgamma = sum g' xhat ; dbeta = sum g'
+__global__ void heads_bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ h,
+                                          const float* __restrict__ mean_invstd, const PtrTab gamma,
+                                          const PtrTab beta, const float* __restrict__ mask2, float msc,
+                                          const double* __restrict__ sums, double count, float* __restrict__ dh,
+                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int B,
+                                          int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  const int g = i / C, c = i - g * C;
+  const float mean = mean_invstd[((size_t)g * 2) * C + c], invstd = mean_invstd[((size_t)g * 2 + 1) * C + c];
+  const float ga = gamma.p[g][c], be = beta.p[g][c];
+  const double sg = sums[((size_t)g * 2) * C + c], sgx = sums[((size_t)g * 2 + 1) * C + c];
+  const float c1 = (float)(sg / count), c2 = (float)(sgx / count);
+  const float A1 = ga * invstd;
+  for (int b = 0; b < B; ++b) {
+    const size_t ad = ((size_t)g * B + b) * C + c;
+    const float xh = (h[ad] - mean) * invstd;
+    float gv = da[ad];
+    if (mask2) gv *= mask2[ad] * msc;
+    if (!(xh * ga + be > 0.f)) gv = 0.f;
+    dh[ad] = A1 * (gv - c1 - xh * c2);
+  }
+  dgamma[(size_t)g * C + c] = (float)sgx;
+  dbeta[(size_t)g * C + c] = (float)sg;
+}
+
+// out[m][i] = sum_{g in modality m} src[g][i]   (fixed order)
+__global__ void heads_sum_groups_kernel(const float* __restrict__ src, float* __restrict__ out, int hc, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int m = blockIdx.y;
+  float s = 0.f;
+  for (int g = 0; g < hc; ++g) s += src[((size_t)(m * hc + g)) * n + i];
+  out[(size_t)m * n + i] = s;
+}
+
+// y[r][c] = relu?(x[r][c]*s[c] + h[c])    rows x C row-major (eval-mode BN1d of the SK feature bank)
+__global__ void rowwise_affine_kernel(const float* __restrict__ x, const float* __restrict__ ss, int relu,
+                                      float* __restrict__ y, int C, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float v = x[i] * ss[c] + ss[C + c];
+    y[i] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+static int fill_tab(PtrTab& t, const void* const* host, int G) {
+  if (G > MAXG) return -1;
+  for (int g = 0; g < G; ++g) t.p[g] = host ? (const float*)host[g] : nullptr;
+  return 0;
+}
+static int fill_tabw(PtrTabW& t, const void* const* host, int G) {
+  if (G > MAXG) return -1;
+  for (int g = 0; g < G; ++g) t.p[g] = host ? (float*)host[g] : nullptr;
+  return 0;
+}
+
+}  // namespace slv
+
+using namespace slv;
+
+extern "C" {
+
+int slv_heads_linear_fwd(const float* x, int shared_x, int hc, const float* mask, float mask_scale,
+                         const void* const* W, const void* const* bias, float* out, int G, int B, int IN, int OUT,
+                         slv_stream_t stream) {
+  SLV_CHECK_ARG(x && W && out && G > 0 && G <= MAXG && B > 0 && IN > 0 && OUT > 0 && hc > 0, "bad argument");
+  PtrTab tw, tb;
+  fill_tab(tw, W, G);
+  fill_tab(tb, bias, G);
+  dim3 grid((OUT + 3) / 4, G);
+  if (mask)
+    hipLaunchKernelGGL((heads_linear_fwd_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x, shared_x, hc,
+                       mask, mask_scale, tw, tb, bias != nullptr, out, B, IN, OUT);
+  else
+    hipLaunchKernelGGL((heads_linear_fwd_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x, shared_x, hc,
+                       mask, mask_scale, tw, tb, bias != nullptr, out, B, IN, OUT);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_heads_bn_stats(const float* h, double* sums, int G, int B, int C, slv_stream_t stream) {
+  SLV_CHECK_ARG(h && sums && G > 0 && B > 0 && C > 0, "bad argument");
+  hipLaunchKernelGGL(heads_bn_stats_kernel, dim3((G * C + 127) / 128), dim3(128), 0, (hipStream_t)stream, h, sums, G,
+                     B, C);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_heads_bn_apply(const float* h, const double* sums, double count, const void* const* gamma,
+                       const void* const* beta, const void* const* running_mean, const void* const* running_var,
+                       const float* mask2, float mask_scale, float momentum, float eps, int training, float* a,
+                       float* mean_invstd, int G, int B, int C, slv_stream_t stream) {
+  SLV_CHECK_ARG(h && gamma && beta && running_mean && running_var && a && mean_invstd && G > 0 && G <= MAXG,
+                "bad argument");
+  SLV_CHECK_ARG(!training || (sums && count > 0), "training mode needs batch sums");
+  PtrTab tg, tb;
+  PtrTabW tm, tv;
+  fill_tab(tg, gamma, G);
+  fill_tab(tb, beta, G);
+  fill_tabw(tm, running_mean, G);
+  fill_tabw(tv, running_var, G);
+  hipLaunchKernelGGL(heads_bn_apply_kernel, dim3((G * C + 127) / 128), dim3(128), 0, (hipStream_t)stream, h, sums,
+                     count, tg, tb, tm, tv, mask2, mask_scale, momentum, eps, training, a, mean_invstd, G, B, C);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_heads_ce(const float* logits, const int64_t* labels, int label_stride, int hc, float* loss_rows,
+                 float* dlogits, float grad_scale, int G, int B, int K, slv_stream_t stream) {
+  SLV_CHECK_ARG(logits && labels && loss_rows && G > 0 && B > 0 && K > 0 && hc > 0, "bad argument");
+  hipLaunchKernelGGL(heads_ce_kernel, dim3((G * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                     label_stride, hc, loss_rows, dlogits, grad_scale, G, B, K);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_heads_linear_bwd_w(const float* dout, const float* x, int shared_x, int hc, const float* mask,
+                           float mask_scale, float* dW, float* dbias, int G, int B, int IN, int OUT,
+                           slv_stream_t stream) {
+  SLV_CHECK_ARG(dout && x && dW && G > 0 && B > 0 && IN > 0 && OUT > 0 && hc > 0, "bad argument");
+  dim3 grid((OUT + 3) / 4, G);
+  if (mask)
+    hipLaunchKernelGGL((heads_linear_bwd_w_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, dout, x,
+                       shared_x, hc, mask, mask_scale, dW, dbias, B, IN, OUT);
+  else
+    hipLaunchKernelGGL((heads_linear_bwd_w_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, dout, x,
+                       shared_x, hc, mask, mask_scale, dW, dbias, B, IN, OUT);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_heads_linear_bwd_x(const float* dout, const void* const* W, const float* mask, float mask_scale, float* dx,
+                           int G, int B, int IN, int OUT, slv_stream_t stream) {
+  SLV_CHECK_ARG(dout && W && dx && G > 0 && G <= MAXG && B > 0 && IN > 0 && OUT > 0, "bad argument");
+  PtrTab tw;
+  fill_tab(tw, W, G);
+  constexpr int BB = 16;
+  dim3 grid((IN + 255) / 256, G, (B + BB - 1) / BB);
+  if (mask)
+    hipLaunchKernelGGL((heads_linear_bwd_x_kernel<true, BB>), grid, dim3(256), 0, (hipStream_t)stream, dout, tw,
+                       mask, mask_scale, dx, B, IN, OUT);
+  else
+    hipLaunchKernelGGL((heads_linear_bwd_x_kernel<false, BB>), grid, dim3(256), 0, (hipStream_t)stream, dout, tw,
+                       mask, mask_scale, dx, B, IN, OUT);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_heads_bn_bwd_stats(const float* da, const float* h, const float* mean_invstd, const void* const* gamma,
+                           const void* const* beta, const float* mask2, float mask_scale, double* sums, int G, int B,
+                           int C, slv_stream_t stream) {
+  SLV_CHECK_ARG(da && h && mean_invstd && gamma && beta && sums && G > 0 && G <= MAXG, "bad argument");
+  PtrTab tg, tb;
+  fill_tab(tg, gamma, G);
+  fill_tab(tb, beta, G);
+  hipLaunchKernelGGL(heads_bn_bwd_stats_kernel, dim3((G * C + 127) / 128), dim3(128), 0, (hipStream_t)stream, da, h,
+                     mean_invstd, tg, tb, mask2, mask_scale, sums, G, B, C);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_heads_bn_bwd_apply(const float* da, const float* h, const float* mean_invstd, const void* const* gamma,
+                           const void* const* beta, const float* mask2, float mask_scale, const double* sums,
+                           double count, float* dh, float* dgamma, float* dbeta, int G, int B, int C,
+                           slv_stream_t stream) {
+  SLV_CHECK_ARG(da && h && mean_invstd && gamma && beta && sums && dh && dgamma && dbeta && G > 0 && G <= MAXG,
+                "bad argument");
+  PtrTab tg, tb;
+  fill_tab(tg, gamma, G);
+  fill_tab(tb, beta, G);
+  hipLaunchKernelGGL(heads_bn_bwd_apply_kernel, dim3((G * C + 127) / 128), dim3(128), 0, (hipStream_t)stream, da, h,
+                     mean_invstd, tg, tb, mask2, mask_scale, sums, count, dh, dgamma, dbeta, G, B, C);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_heads_sum_groups(const float* src, float* out, int hc, int64_t n, slv_stream_t stream) {
+  SLV_CHECK_ARG(src && out && hc > 0 && n > 0, "bad argument");
+  hipLaunchKernelGGL(heads_sum_groups_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0,
+                     (hipStream_t)stream, src, out, hc, (size_t)n);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_rowwise_affine(const float* x, const float* scale_shift, int relu, float* y, int64_t rows, int C,
+                       slv_stream_t stream) {
+  SLV_CHECK_ARG(x && scale_shift && y && rows > 0 && C > 0, "bad argument");
+  const size_t total = (size_t)rows * C;
+  size_t b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(rowwise_affine_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, x, scale_shift,
+                     relu, y, C, total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -65,7 +65,7 @@ __device__ __forceinline__ float apply_bwd(float g, float x, float s, float h, f
 }
 
 template <int MODE, int MT, int NT>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs g) {
+__global__ __launch_bounds__(256, (MT >= 15 ? 2 : 3)) void igemm_kernel(const IgemmArgs g) {
   constexpr int BM = MT * 16, BN = NT * 64;
   constexpr int AS = 18;
   constexpr bool BKF = (MODE == MODE_WGRAD || MODE == MODE_GEMM);  // B tile K-contiguous?

@@ -1,0 +1,237 @@
+"""Thin Python wrappers over the C ABI (include/selavi_hip.h).  torch is used only to own device
+memory and streams; every numeric op below is a hand-written HIP kernel in libselavi_hip.so."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import C, ptr, stream
+
+
+def _f32(*shape, device):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+class ConvPlan:
+    """Geometry + device tables of one convolution layer for a given input shape.
+
+    Mirrors ``nn.Conv3d(Cin, Cout, k, stride, padding, bias=False)`` (2-D convs: T = kt = 1)."""
+
+    _cache = {}
+
+    def __init__(self, Bn, Cin, Ti, Hi, Wi, Cout, k, stride, pad, device):
+        kt, kh, kw = k
+        st, sh, sw = stride
+        pt, ph, pw = pad
+        To = (Ti + 2 * pt - kt) // st + 1
+        Ho = (Hi + 2 * ph - kh) // sh + 1
+        Wo = (Wi + 2 * pw - kw) // sw + 1
+        self.in_shape = (Bn, Cin, Ti, Hi, Wi)
+        self.out_shape = (Bn, Cout, To, Ho, Wo)
+        self.Cin, self.Cout, self.taps = Cin, Cout, kt * kh * kw
+        self.geom = np.array([Bn, Cin, Ti, Hi, Wi, Cout, To, Ho, Wo, kt, kh, kw, st, sh, sw, pt, ph, pw],
+                             dtype=np.int32)
+        self.gp = self.geom.ctypes.data
+        self.device = device
+        tf = np.empty((Cin * self.taps, 2), dtype=np.int32)
+        C.slv_conv_table(self.gp, 0, tf.ctypes.data)
+        td = np.empty((Cout * self.taps, 2), dtype=np.int32)
+        C.slv_conv_table(self.gp, 1, td.ctypes.data)
+        self.tab_fwd = torch.from_numpy(tf).to(device)
+        self.tab_dgrad = torch.from_numpy(td).to(device)
+        self.nblk = C.slv_conv_fwd_nblk(self.gp)
+        self.ws_bytes = C.slv_conv_wgrad_ws_bytes(self.gp)
+        self.count = float(Bn * To * Ho * Wo)          # elements per channel of the output
+        self.P_out = To * Ho * Wo
+        self.P_in = Ti * Hi * Wi
+
+    @classmethod
+    def get(cls, in_shape, Cout, k, stride, pad, device):
+        key = (tuple(in_shape), Cout, tuple(k), tuple(stride), tuple(pad), str(device))
+        p = cls._cache.get(key)
+        if p is None:
+            p = cls._cache[key] = cls(*in_shape, Cout, k, stride, pad, device)
+        return p
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer shared by all wgrad calls on a device (stream ordered)."""
+    key = str(device)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        t = _ws_cache[key] = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
+    return t
+
+
+def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True):
+    """y = conv(relu?(x*s+h)); returns (y, stat_sum, stat_sq) with stats [Cout][nblk] partials."""
+    y = _f32(*plan.out_shape, device=x.device)
+    ssum = ssq = None
+    if want_stats:
+        ssum = _f32(plan.Cout, plan.nblk, device=x.device)
+        ssq = _f32(plan.Cout, plan.nblk, device=x.device)
+    C.slv_conv_fwd(plan.gp, ptr(x), ptr(w), ptr(plan.tab_fwd), ptr(in_ss), int(in_relu), ptr(y), ptr(ssum),
+                   ptr(ssq), stream())
+    return y, ssum, ssq
+
+
+def conv_wt_transform(plan, w, out=None):
+    wt = out if out is not None else torch.empty_like(w)
+    C.slv_conv_wt_transform(ptr(w), ptr(wt), plan.Cout, plan.Cin, plan.taps, stream())
+    return wt
+
+
+def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out=None):
+    dx = out if out is not None else _f32(*plan.in_shape, device=dy.device)
+    C.slv_conv_dgrad(plan.gp, ptr(dy), ptr(x_out), ptr(wt), ptr(plan.tab_dgrad), ptr(bwd5), int(relu), ptr(dx),
+                     ptr(addend), stream())
+    return dx
+
+
+def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, in_relu=False, out=None):
+    dw = out if out is not None else _f32(plan.Cout, plan.Cin * plan.taps, device=dy.device)
+    ws = workspace(plan.ws_bytes, dy.device) if plan.ws_bytes else None
+    C.slv_conv_wgrad(plan.gp, ptr(dy), ptr(x_out), ptr(bwd5), int(a_relu), ptr(x_in), ptr(in_ss), int(in_relu),
+                     ptr(plan.tab_fwd), ptr(dw), ptr(ws), plan.ws_bytes, stream())
+    return dw
+
+
+def gemm_nt(A, B, bias=None, out=None):
+    M, K = A.shape
+    N = B.shape[0]
+    Cm = out if out is not None else _f32(M, N, device=A.device)
+    C.slv_gemm_nt(ptr(A), ptr(B), ptr(bias), ptr(Cm), M, N, K, N, stream())
+    return Cm
+
+
+# ---------------------------------------------------------------------------------- BatchNorm
+def _allreduce(t, group):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def bn_train_finalize(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps, sync=None):
+    """conv-epilogue partials -> (mean_invstd [2][C], scale_shift [2][C]); updates running stats.
+    ``sync`` = (group, world_count): SyncBN -- sums are all-reduced, count is the global count."""
+    Cc = gamma.numel()
+    dev = gamma.device
+    sums = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+    C.slv_bn_partials_to_sums(ptr(ssum), ptr(ssq), ssum.shape[1], Cc, ptr(sums), stream())
+    if sync is not None:
+        _allreduce(sums, sync[0])
+        count = count * sync[1]
+    mi = _f32(2, Cc, device=dev)
+    ss = _f32(2, Cc, device=dev)
+    C.slv_bn_finalize(ptr(sums), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(momentum),
+                      float(eps), ptr(mi), ptr(ss), Cc, stream())
+    return mi, ss
+
+
+def bn_eval_params(gamma, beta, rmean, rvar, eps):
+    Cc = gamma.numel()
+    mi = _f32(2, Cc, device=gamma.device)
+    ss = _f32(2, Cc, device=gamma.device)
+    C.slv_bn_eval_params(ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(eps), ptr(mi), ptr(ss), Cc, stream())
+    return mi, ss
+
+
+def bn_act(x, ss, res=None, res_ss=None, relu=True):
+    Bn, Cc = x.shape[0], x.shape[1]
+    P = x.numel() // (Bn * Cc)
+    out = torch.empty_like(x)
+    C.slv_bn_act(ptr(x), ptr(ss), ptr(res), ptr(res_ss), int(relu), ptr(out), Bn, Cc, P, stream())
+    return out
+
+
+def bn_bwd(g, x, mi, gamma, ss_mask=None, v_mask=None, x2=None, mi2=None, gamma2=None, ss2=None, sync=None,
+           dgamma=None, dbeta=None, dgamma2=None, dbeta2=None):
+    """BN backward reductions for the BN whose input is ``x`` and upstream gradient ``g``.
+
+    mask: ``ss_mask`` (the BN's own scale/shift -> ReLU mask on its output) or ``v_mask`` (block
+    output tensor; the masked gradient is materialised and returned) or none.  Optional second BN
+    (downsample branch) sharing the same masked gradient.  Returns (bwd5, bwd5_2, g_masked)."""
+    Bn, Cc = x.shape[0], x.shape[1]
+    P = x.numel() // (Bn * Cc)
+    dev = x.device
+    ns = C.slv_bn_bwd_nsplit(Bn, Cc, P)
+    part = _f32(Cc, ns, 2, device=dev)
+    part2 = _f32(Cc, ns, 2, device=dev) if x2 is not None else None
+    gout = torch.empty_like(g) if v_mask is not None else None
+    C.slv_bn_bwd_reduce(ptr(g), ptr(x), ptr(mi), ptr(ss_mask), ptr(v_mask), ptr(x2), ptr(mi2), ptr(gout), ptr(part),
+                        ptr(part2), Bn, Cc, P, ns, stream())
+    count = float(Bn * P)
+    if sync is not None:
+        count *= sync[1]
+    outs = []
+    for (pt_, mi_, ga_, ss_, dg_, db_) in ((part, mi, gamma, ss_mask, dgamma, dbeta),
+                                          (part2, mi2, gamma2, None, dgamma2, dbeta2)):
+        if pt_ is None:
+            outs.append(None)
+            continue
+        sums = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+        C.slv_bn_bwd_sums(ptr(pt_), ns, Cc, ptr(sums), stream())
+        if sync is not None:
+            _allreduce(sums, sync[0])
+        b5 = _f32(5, Cc, device=dev)
+        C.slv_bn_bwd_finalize(ptr(sums), count, ptr(ga_), ptr(mi_), ptr(ss_), ptr(b5), ptr(dg_), ptr(db_), 0, Cc,
+                              stream())
+        outs.append(b5)
+    return outs[0], outs[1], gout
+
+
+def avgpool_fwd(v):
+    Bn, Cc = v.shape[0], v.shape[1]
+    P = v.numel() // (Bn * Cc)
+    out = _f32(Bn, Cc, device=v.device)
+    C.slv_avgpool_fwd(ptr(v), ptr(out), Bn * Cc, P, stream())
+    return out
+
+
+def avgpool_bwd(dout, like):
+    Bn, Cc = like.shape[0], like.shape[1]
+    P = like.numel() // (Bn * Cc)
+    dv = torch.empty_like(like)
+    C.slv_avgpool_bwd(ptr(dout), ptr(dv), Bn * Cc, P, stream())
+    return dv
+
+
+def bnrelu_maxpool_fwd(x, ss):
+    Bn, Cc, T, H, W = x.shape
+    assert T == 1
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = _f32(Bn, Cc, 1, Ho, Wo, device=x.device)
+    idx = torch.empty(Bn, Cc, 1, Ho, Wo, dtype=torch.uint8, device=x.device)
+    C.slv_bnrelu_maxpool_fwd(ptr(x), ptr(ss), ptr(out), ptr(idx), Bn, Cc, H, W, stream())
+    return out, idx
+
+
+def maxpool_bwd(dout, idx, in_shape):
+    Bn, Cc, T, H, W = in_shape
+    dy = _f32(*in_shape, device=dout.device)
+    C.slv_maxpool_bwd(ptr(dout), ptr(idx), ptr(dy), Bn, Cc, H, W, stream())
+    return dy
+
+
+# ---------------------------------------------------------------------------------- pointer tables
+class PtrArray:
+    """Host array of device pointers (``const void* const*`` in the C ABI)."""
+
+    def __init__(self, tensors):
+        self.n = len(tensors)
+        self.arr = (ctypes.c_void_p * max(self.n, 1))(*[t.data_ptr() for t in tensors])
+        self.keep = list(tensors)
+
+    @property
+    def p(self):
+        return ctypes.addressof(self.arr)
+
+
+def sgd_step(params, grads, bufs, lr, momentum, wd, first):
+    n = len(params)
+    pa, ga, ba = PtrArray(params), PtrArray(grads), PtrArray(bufs)
+    sizes = (ctypes.c_int64 * n)(*[p.numel() for p in params])
+    C.slv_sgd_step(pa.p, ga.p, ba.p, ctypes.addressof(sizes), n, float(lr), float(momentum), float(wd), int(first),
+                   stream())

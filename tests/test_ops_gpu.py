@@ -1,0 +1,213 @@
+"""GPU parity tests of the individual HIP ops (through the C ABI) against torch's CPU fp32 ops.
+Tolerance: fp32 with a different summation order -> rtol 2e-4 of the output scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (Bn, Cin, T, H, W, Cout, k, stride, pad)  -- every conv family of R(2+1)D-18 / ResNet-9, odd channels,
+# stride 2, odd T (T=15 -> 8), tails in M, N and K
+GEOMS = [
+    (2, 3, 4, 20, 20, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)),      # stem.0
+    (2, 45, 5, 10, 10, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),     # stem.3
+    (2, 64, 3, 12, 12, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # layer1 spatial
+    (2, 144, 4, 6, 6, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),      # layer1 temporal
+    (2, 64, 3, 12, 12, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1)),    # layer2 spatial stride 2
+    (2, 230, 15, 6, 6, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0)),    # temporal stride 2, odd T
+    (3, 64, 5, 9, 9, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),      # downsample 1x1x1 stride 2
+    (1, 256, 2, 7, 7, 921, (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # layer4 spatial (921)
+    (1, 921, 4, 4, 4, 512, (3, 1, 1), (2, 1, 1), (1, 0, 0)),     # layer4 temporal
+    (2, 512, 2, 3, 3, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # layer4.1 spatial
+    (3, 1, 1, 40, 36, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),      # audio conv1 (2-D)
+    (3, 64, 1, 10, 9, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # audio 3x3 stride 2
+    (3, 128, 1, 5, 5, 256, (1, 1, 1), (1, 2, 2), (0, 0, 0)),     # audio downsample
+    (1, 5, 1, 3, 1, 7, (1, 3, 3), (1, 1, 1), (0, 1, 1)),         # degenerate W = 1
+]
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _close(got, want, rtol=2e-4):
+    got = got.detach().cpu().double()
+    want = want.detach().double()
+    scale = want.abs().max().item() + 1e-12
+    err = (got - want).abs().max().item()
+    assert err <= rtol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("geo", GEOMS)
+def test_conv_forward_dgrad_wgrad(geo):
+    from selavi_amd import ops
+    Bn, Cin, T, H, W, Cout, k, st, pd = geo
+    dev = torch.device("cuda")
+    x = _mk((Bn, Cin, T, H, W), 1)
+    w = _mk((Cout, Cin) + k, 2, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5)
+    plan = ops.ConvPlan.get((Bn, Cin, T, H, W), Cout, k, st, pd, dev)
+    xg, wg = x.to(dev), w.to(dev)
+
+    # ---- plain forward + statistics partials
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, stride=st, padding=pd)
+    y, ssum, ssq = ops.conv_fwd(plan, xg, wg)
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    _close(y, y_ref)
+    _close(ssum.sum(1), y_ref.sum((0, 2, 3, 4)), rtol=1e-3)
+    _close(ssq.sum(1), (y_ref ** 2).sum((0, 2, 3, 4)), rtol=1e-3)
+
+    # ---- plain dgrad / wgrad
+    dy = _mk(tuple(y_ref.shape), 3)
+    y_ref.backward(dy)
+    dyg = dy.to(dev)
+    wt = ops.conv_wt_transform(plan, wg)
+    dx = ops.conv_dgrad(plan, dyg, wt)
+    _close(dx, xr.grad)
+    dw = ops.conv_wgrad(plan, dyg, xg)
+    _close(dw.view_as(w), wr.grad)
+
+    # ---- dgrad with addend (residual / in-place accumulate)
+    add = _mk(tuple(x.shape), 4)
+    dx2 = ops.conv_dgrad(plan, dyg, wt, addend=add.to(dev))
+    _close(dx2, xr.grad + add)
+    acc = add.to(dev).clone()
+    ops.conv_dgrad(plan, dyg, wt, addend=acc, out=acc)
+    _close(acc, xr.grad + add)
+
+
+@pytest.mark.parametrize("geo", [GEOMS[2], GEOMS[4], GEOMS[5], GEOMS[8], GEOMS[11]])
+def test_conv_fused_bn_prologues(geo):
+    """Consumer-side BN+ReLU on load (forward / wgrad B operand) and BN-backward on load
+    (dgrad B operand / wgrad A operand) against the unfused torch composition."""
+    from selavi_amd import ops
+    Bn, Cin, T, H, W, Cout, k, st, pd = geo
+    dev = torch.device("cuda")
+    x = _mk((Bn, Cin, T, H, W), 1)
+    w = _mk((Cout, Cin) + k, 2, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5)
+    s_in = _mk((Cin,), 5).abs() + 0.5
+    h_in = _mk((Cin,), 6) * 0.3
+    plan = ops.ConvPlan.get((Bn, Cin, T, H, W), Cout, k, st, pd, dev)
+    xa = torch.relu(x * s_in.view(1, -1, 1, 1, 1) + h_in.view(1, -1, 1, 1, 1)).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv3d(xa, wr, stride=st, padding=pd)
+    ss_in = torch.stack([s_in, h_in]).to(dev).contiguous()
+    y, _, _ = ops.conv_fwd(plan, x.to(dev), w.to(dev), in_ss=ss_in, in_relu=True)
+    _close(y, y_ref)
+
+    # gradient wrt raw conv output formed on load: dXout = A1*mask*g + A2 + A3*xo
+    g = _mk(tuple(y_ref.shape), 7)
+    xo = y_ref.detach()
+    p5 = torch.stack([_mk((Cout,), 8).abs() + 0.2, _mk((Cout,), 9) * 0.2, _mk((Cout,), 10), _mk((Cout,), 11) * 0.1,
+                      _mk((Cout,), 12) * 0.1])
+    v = lambda i: p5[i].view(1, -1, 1, 1, 1)
+    for relu in (True, False):
+        mask = ((xo * v(0) + v(1)) > 0).float() if relu else 1.0
+        dxo = v(2) * mask * g + v(3) + v(4) * xo
+        gx, gw = torch.autograd.grad(y_ref, (xa, wr), dxo, retain_graph=True)
+        wt = ops.conv_wt_transform(plan, w.to(dev))
+        dx = ops.conv_dgrad(plan, g.to(dev), wt, x_out=xo.to(dev), bwd5=p5.to(dev).contiguous(), relu=relu)
+        _close(dx, gx)
+        dw = ops.conv_wgrad(plan, g.to(dev), x.to(dev), x_out=xo.to(dev), bwd5=p5.to(dev).contiguous(), a_relu=relu,
+                            in_ss=ss_in, in_relu=True)
+        _close(dw.view_as(w), gw)
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 309, 512), (1000, 512, 512), (777, 28, 512), (130, 400, 96)])
+def test_gemm_nt(M, N, K):
+    from selavi_amd import ops
+    A, B, bias = _mk((M, K), 1), _mk((N, K), 2, K ** -0.5), _mk((N,), 3)
+    out = ops.gemm_nt(A.cuda(), B.cuda(), bias.cuda())
+    _close(out, A @ B.t() + bias)
+    out = ops.gemm_nt(A.cuda(), B.cuda())
+    _close(out, A @ B.t())
+
+
+def test_bn_train_chain_matches_torch():
+    """conv -> BN(train) -> ReLU -> conv -> BN(train) + residual -> ReLU, forward and backward,
+    with every BN fused as the engine does it."""
+    from selavi_amd import ops
+    dev = torch.device("cuda")
+    Bn, Cc, T, H, W = 3, 24, 3, 6, 5
+    x = _mk((Bn, Cc, T, H, W), 1)
+    w1 = _mk((40, Cc, 1, 3, 3), 2, 0.1)
+    w2 = _mk((Cc, 40, 3, 1, 1), 3, 0.1)
+    g1, b1 = _mk((40,), 4).abs() + 0.5, _mk((40,), 5) * 0.2
+    g2, b2 = _mk((Cc,), 6).abs() + 0.5, _mk((Cc,), 7) * 0.2
+    # torch reference
+    P = [t.clone().requires_grad_(True) for t in (x, w1, w2, g1, b1, g2, b2)]
+    xr, w1r, w2r, g1r, b1r, g2r, b2r = P
+    rm1, rv1, rm2, rv2 = torch.zeros(40), torch.ones(40), torch.zeros(Cc), torch.ones(Cc)
+    y1 = F.conv3d(xr, w1r, padding=(0, 1, 1))
+    a1 = F.relu(F.batch_norm(y1, rm1, rv1, g1r, b1r, True, 0.1, 1e-5))
+    y2 = F.conv3d(a1, w2r, padding=(1, 0, 0))
+    out = F.relu(F.batch_norm(y2, rm2, rv2, g2r, b2r, True, 0.1, 1e-5) + xr)
+    dout = _mk(tuple(out.shape), 8)
+    out.backward(dout)
+    # HIP
+    p1 = ops.ConvPlan.get((Bn, Cc, T, H, W), 40, (1, 3, 3), (1, 1, 1), (0, 1, 1), dev)
+    p2 = ops.ConvPlan.get((Bn, 40, T, H, W), Cc, (3, 1, 1), (1, 1, 1), (1, 0, 0), dev)
+    xg = x.to(dev)
+    G = [t.to(dev) for t in (w1, w2, g1, b1, g2, b2)]
+    w1g, w2g, g1g, b1g, g2g, b2g = G
+    R = [torch.zeros(40, device=dev), torch.ones(40, device=dev), torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)]
+    Y1, s1, q1 = ops.conv_fwd(p1, xg, w1g)
+    mi1, ss1 = ops.bn_train_finalize(s1, q1, p1.count, g1g, b1g, R[0], R[1], 0.1, 1e-5)
+    Y2, s2, q2 = ops.conv_fwd(p2, Y1, w2g, in_ss=ss1, in_relu=True)
+    mi2, ss2 = ops.bn_train_finalize(s2, q2, p2.count, g2g, b2g, R[2], R[3], 0.1, 1e-5)
+    V = ops.bn_act(Y2, ss2, res=xg, relu=True)
+    _close(V, out)
+    _close(R[0], rm1, 1e-3), _close(R[1], rv1, 1e-3), _close(R[3], rv2, 1e-3)
+    # backward
+    dg2, db2 = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    b5_2, _, dz = ops.bn_bwd(dout.to(dev), Y2, mi2, g2g, v_mask=V, dgamma=dg2, dbeta=db2)
+    _close(dg2, g2r.grad, 1e-3), _close(db2, b2r.grad, 1e-3)
+    dw2 = ops.conv_wgrad(p2, dz, Y1, x_out=Y2, bwd5=b5_2, a_relu=False, in_ss=ss1, in_relu=True)
+    _close(dw2.view_as(w2), w2r.grad, 1e-3)
+    da1 = ops.conv_dgrad(p2, dz, ops.conv_wt_transform(p2, w2g), x_out=Y2, bwd5=b5_2, relu=False)
+    dg1, db1 = torch.empty(40, device=dev), torch.empty(40, device=dev)
+    b5_1, _, _ = ops.bn_bwd(da1, Y1, mi1, g1g, ss_mask=ss1, dgamma=dg1, dbeta=db1)
+    _close(dg1, g1r.grad, 1e-3), _close(db1, b1r.grad, 1e-3)
+    dw1 = ops.conv_wgrad(p1, da1, xg, x_out=Y1, bwd5=b5_1, a_relu=True)
+    _close(dw1.view_as(w1), w1r.grad, 1e-3)
+    dx = ops.conv_dgrad(p1, da1, ops.conv_wt_transform(p1, w1g), x_out=Y1, bwd5=b5_1, relu=True, addend=dz)
+    _close(dx, xr.grad, 1e-3)
+
+
+def test_pools_and_sgd():
+    from selavi_amd import ops
+    dev = torch.device("cuda")
+    v = _mk((3, 10, 2, 7, 7), 1)
+    _close(ops.avgpool_fwd(v.to(dev)), v.mean((2, 3, 4)))
+    d = _mk((3, 10), 2)
+    _close(ops.avgpool_bwd(d.to(dev), v.to(dev)), (d / 98).view(3, 10, 1, 1, 1).expand_as(v))
+    # relu(bn(x)) -> maxpool(3,2,1)
+    x = _mk((2, 6, 1, 11, 9), 3).requires_grad_(True)
+    s, h = _mk((6,), 4).abs() + 0.5, _mk((6,), 5) * 0.3
+    a = F.relu(x * s.view(1, -1, 1, 1, 1) + h.view(1, -1, 1, 1, 1))
+    pooled = F.max_pool2d(a[:, :, 0], 3, 2, 1)
+    out, idx = ops.bnrelu_maxpool_fwd(x.detach().to(dev), torch.stack([s, h]).to(dev))
+    _close(out[:, :, 0], pooled)
+    dp = _mk(tuple(pooled.shape), 6)
+    ga, = torch.autograd.grad(pooled, a, dp)
+    dy = ops.maxpool_bwd(dp.unsqueeze(2).contiguous().to(dev), idx, tuple(x.shape))
+    # positions where relu output is 0 may tie; their gradient is masked by the ReLU backward anyway
+    m = (a > 0).float()
+    _close(dy.cpu() * m, ga * m)
+    # SGD
+    ps = [_mk((5000,), 7), _mk((33, 7), 8), _mk((1,), 9)]
+    gs = [_mk(tuple(p.shape), 10 + i) for i, p in enumerate(ps)]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.SGD(ref, lr=0.01, momentum=0.9, weight_decay=1e-5)
+    pg = [p.to(dev) for p in ps]
+    bufs = [torch.zeros_like(p) for p in pg]
+    for step in range(3):
+        for r, g in zip(ref, gs):
+            r.grad = g * (step + 1)
+        opt.step()
+        ops.sgd_step(pg, [(g * (step + 1)).to(dev) for g in gs], bufs, 0.01, 0.9, 1e-5, step == 0)
+    for p, r in zip(pg, ref):
+        _close(p, r.detach(), 1e-6)
