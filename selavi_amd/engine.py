@@ -1,0 +1,199 @@
+"""Forward/backward engine of the two trunks: an explicit schedule of HIP kernels (no autograd
+inside, no per-layer torch modules executed).
+
+Every conv of R(2+1)D-18 / ResNet-9 is followed by a BatchNorm (torchvision nets built by
+/root/reference/model.py:95,114).  The engine keeps only the RAW conv outputs in HBM; BN(+ReLU) is
+applied when the consumer loads the tensor (PRO_ACT), batch statistics come out of the producing
+conv's epilogue, and in the backward pass BN-backward is folded into per-channel coefficients
+(bwd5) applied when dgrad/wgrad load the gradient (PRO_BWD).  Only block outputs (two consumers)
+are materialised.  See csrc/igemm.hpp.
+"""
+import torch
+
+from . import ops
+
+
+class Raw:
+    """A raw conv output with its (pending) BatchNorm."""
+    __slots__ = ("y", "ss", "mi", "plan", "conv", "bn", "src")
+
+    def __init__(self, y, ss, mi, plan, conv, bn, src):
+        self.y, self.ss, self.mi, self.plan, self.conv, self.bn, self.src = y, ss, mi, plan, conv, bn, src
+
+
+class Ctx:
+    """Execution context of one trunk pass."""
+
+    def __init__(self, training, sync=None):
+        self.training = training
+        self.sync = sync            # (process_group, world_size) for SyncBN or None
+        self.grads = {}             # id(param) -> grad tensor
+
+
+def _as5d(t):
+    return t if t.dim() == 5 else t.unsqueeze(2)
+
+
+def conv_bn(ctx, x, conv, bn):
+    """x: materialised tensor or Raw (then relu(bn(x)) is applied on load).  -> Raw"""
+    if isinstance(x, Raw):
+        xin, in_ss = x.y, x.ss
+    else:
+        xin, in_ss = x, None
+    plan = ops.ConvPlan.get(tuple(xin.shape), conv.out_channels, conv.kernel3, conv.stride3, conv.padding3, xin.device)
+    y, ssum, ssq = ops.conv_fwd(plan, xin, conv.weight, in_ss=in_ss, in_relu=in_ss is not None,
+                                want_stats=ctx.training)
+    if ctx.training:
+        mi, ss = ops.bn_train_finalize(ssum, ssq, plan.count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       bn.momentum, bn.eps, sync=ctx.sync)
+        bn.note_batch()
+    else:
+        mi, ss = ops.bn_eval_params(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    return Raw(y, ss, mi, plan, conv, bn, x)
+
+
+def tail(ctx, r, res=None, res_raw=None, relu=True):
+    """Materialise relu(bn(r) + residual)."""
+    if res_raw is not None:
+        return ops.bn_act(r.y, r.ss, res=res_raw.y, res_ss=res_raw.ss, relu=relu)
+    return ops.bn_act(r.y, r.ss, res=res, relu=relu)
+
+
+def _wt(r):
+    return ops.conv_wt_transform(r.plan, r.conv.weight)
+
+
+def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None):
+    """Backward through conv `r.conv` given the gradient `g` w.r.t. the ACTIVATED output of r's BN
+    (or the masked tail gradient when a_relu is False) and its folded BN-backward coefficients.
+    Writes the weight gradient; returns the gradient w.r.t. the conv input (activated, if the
+    source is itself Raw) or None."""
+    src = r.src
+    if isinstance(src, Raw):
+        xin, in_ss = src.y, src.ss
+    else:
+        xin, in_ss = src, None
+    dw = ops.conv_wgrad(r.plan, g, xin, x_out=r.y, bwd5=b5, a_relu=a_relu, in_ss=in_ss, in_relu=in_ss is not None)
+    ctx.grads[id(r.conv.weight)] = dw.view_as(r.conv.weight)
+    if not need_dx:
+        return None
+    return ops.conv_dgrad(r.plan, g, _wt(r), x_out=r.y, bwd5=b5, relu=a_relu, addend=addend, out=out)
+
+
+def bn_bwd_own(ctx, r, g):
+    """BN backward coefficients for Raw r consumed through relu(bn(.)) with upstream gradient g."""
+    dg, db = torch.empty_like(r.bn.weight), torch.empty_like(r.bn.bias)
+    b5, _, _ = ops.bn_bwd(g, r.y, r.mi, r.bn.weight, ss_mask=r.ss, sync=ctx.sync, dgamma=dg, dbeta=db)
+    ctx.grads[id(r.bn.weight)] = dg
+    ctx.grads[id(r.bn.bias)] = db
+    return b5
+
+
+class BlockRec:
+    __slots__ = ("u_in", "chain", "ds", "v")
+
+
+def block_fwd(ctx, u, chain_mods, ds_mods):
+    """Residual block: chain of conv+BN (ReLU between them), optional downsample conv+BN,
+    output relu(bn(last) + shortcut).  chain_mods: [(conv, bn), ...]"""
+    rec = BlockRec()
+    rec.u_in = u
+    x = u
+    rec.chain = []
+    for conv, bn in chain_mods:
+        x = conv_bn(ctx, x, conv, bn)
+        rec.chain.append(x)
+    rec.ds = conv_bn(ctx, u, ds_mods[0], ds_mods[1]) if ds_mods is not None else None
+    rec.v = tail(ctx, rec.chain[-1], res=None if rec.ds is not None else u, res_raw=rec.ds)
+    return rec
+
+
+def block_bwd(ctx, rec, dv, need_du=True):
+    """dv: gradient w.r.t. the block output.  Returns gradient w.r.t. the block input."""
+    last = rec.chain[-1]
+    ds = rec.ds
+    dg, db = torch.empty_like(last.bn.weight), torch.empty_like(last.bn.bias)
+    if ds is not None:
+        dg2, db2 = torch.empty_like(ds.bn.weight), torch.empty_like(ds.bn.bias)
+        b5, b5ds, dz = ops.bn_bwd(dv, last.y, last.mi, last.bn.weight, v_mask=rec.v, x2=ds.y, mi2=ds.mi,
+                                  gamma2=ds.bn.weight, sync=ctx.sync, dgamma=dg, dbeta=db, dgamma2=dg2, dbeta2=db2)
+        ctx.grads[id(ds.bn.weight)] = dg2
+        ctx.grads[id(ds.bn.bias)] = db2
+    else:
+        b5, b5ds, dz = ops.bn_bwd(dv, last.y, last.mi, last.bn.weight, v_mask=rec.v, sync=ctx.sync, dgamma=dg,
+                                  dbeta=db)
+    ctx.grads[id(last.bn.weight)] = dg
+    ctx.grads[id(last.bn.bias)] = db
+    g, a_relu = dz, False
+    n = len(rec.chain)
+    for i in range(n - 1, -1, -1):
+        r = rec.chain[i]
+        if i > 0:
+            g = backprop_raw(ctx, r, g, b5, a_relu)
+            b5 = bn_bwd_own(ctx, rec.chain[i - 1], g)
+            a_relu = True
+        else:
+            if ds is not None:
+                du = backprop_raw(ctx, r, g, b5, a_relu, need_dx=need_du)
+                du = backprop_raw(ctx, ds, dz, b5ds, False, need_dx=need_du, addend=du, out=du)
+            else:
+                du = backprop_raw(ctx, r, g, b5, a_relu, need_dx=need_du, addend=dz)
+            return du
+
+
+# ------------------------------------------------------------------------------------------ trunks
+def video_forward(ctx, base, x):
+    """R(2+1)D-18 (torchvision VideoResNet).  Returns (feat [B,512], saved record)."""
+    st = base.stem
+    r0 = conv_bn(ctx, x, st[0], st[1])
+    r1 = conv_bn(ctx, r0, st[3], st[4])
+    u = tail(ctx, r1)
+    recs = []
+    for layer in (base.layer1, base.layer2, base.layer3, base.layer4):
+        for blk in layer:
+            chain = [(blk.conv1[0][0], blk.conv1[0][1]), (blk.conv1[0][3], blk.conv1[1]),
+                     (blk.conv2[0][0], blk.conv2[0][1]), (blk.conv2[0][3], blk.conv2[1])]
+            ds = (blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+            rec = block_fwd(ctx, u, chain, ds)
+            recs.append(rec)
+            u = rec.v
+    feat = ops.avgpool_fwd(u)
+    return feat, (x, r0, r1, recs, u)
+
+
+def video_backward(ctx, saved, dfeat):
+    x, r0, r1, recs, u_last = saved
+    dv = ops.avgpool_bwd(dfeat.contiguous(), u_last)
+    for rec in reversed(recs):
+        dv = block_bwd(ctx, rec, dv)
+    b5 = bn_bwd_own(ctx, r1, dv)
+    g = backprop_raw(ctx, r1, dv, b5, True)
+    b5 = bn_bwd_own(ctx, r0, g)
+    backprop_raw(ctx, r0, g, b5, True, need_dx=False)
+
+
+def audio_forward(ctx, base, spec):
+    """ResNet-9/18 on 1 x F x T' spectrograms (torchvision ResNet), 2-D = 3-D with T=1."""
+    x = _as5d(spec)
+    r0 = conv_bn(ctx, x, base.conv1, base.bn1)
+    u, idx = ops.bnrelu_maxpool_fwd(r0.y, r0.ss)
+    recs = []
+    for layer in (base.layer1, base.layer2, base.layer3, base.layer4):
+        for blk in layer:
+            chain = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+            ds = (blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+            rec = block_fwd(ctx, u, chain, ds)
+            recs.append(rec)
+            u = rec.v
+    feat = ops.avgpool_fwd(u)
+    return feat, (x, r0, idx, recs, u)
+
+
+def audio_backward(ctx, saved, dfeat):
+    x, r0, idx, recs, u_last = saved
+    dv = ops.avgpool_bwd(dfeat.contiguous(), u_last)
+    for rec in reversed(recs):
+        dv = block_bwd(ctx, rec, dv)
+    dy0 = ops.maxpool_bwd(dv, idx, tuple(r0.y.shape))
+    b5 = bn_bwd_own(ctx, r0, dy0)
+    backprop_raw(ctx, r0, dy0, b5, True, need_dx=False)

@@ -1,0 +1,118 @@
+"""AVModel facade -- drop-in for /root/reference/model.py (``load_model`` / ``AVModel.forward``).
+
+Same constructor arguments, attributes (``return_features``, ``use_mlp``, ``hc``, ``mlp_v{h}``,
+``mlp_a{h}``, ``video_network.base.{stem,layer1..4}``, ``audio_network.base``) and ``state_dict``
+keys as the reference, so ``main.py``'s loop (main.py:105-114,284) and ``sk_utils`` (:187,:266-282)
+run unchanged; the arithmetic is libselavi_hip.so.
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import nn as snn
+
+
+def get_video_feature_extractor(vid_base_arch='r2plus1d_18', pretrained=False, duration=1):   # model.py:93-100
+    assert vid_base_arch == 'r2plus1d_18', "only r2plus1d_18 is on the hot path"
+    assert not pretrained, "no pretrained weights in this build (no network)"
+    return snn.VideoResNet()
+
+
+def get_audio_feature_extractor(aud_base_arch='resnet9', pretrained=False, duration=1):       # model.py:103-121
+    assert aud_base_arch in ('resnet9', 'resnet18')
+    return snn.AudioResNet((1, 1, 1, 1) if aud_base_arch == 'resnet9' else (2, 2, 2, 2))
+
+
+class VideoBaseNetwork(nn.Module):    # model.py:135-149
+    def __init__(self, vid_base_arch='r2plus1d_18', pretrained=False, norm_feat=False, duration=1):
+        super().__init__()
+        self.base = get_video_feature_extractor(vid_base_arch, pretrained, duration)
+        self.norm_feat = norm_feat
+
+    def forward(self, x):
+        x = self.base(x).squeeze()
+        return F.normalize(x, p=2, dim=1) if self.norm_feat else x
+
+
+class AudioBaseNetwork(nn.Module):    # model.py:152-166
+    def __init__(self, aud_base_arch='resnet9', pretrained=False, norm_feat=False, duration=1):
+        super().__init__()
+        self.base = get_audio_feature_extractor(aud_base_arch, pretrained, duration)
+        self.norm_feat = norm_feat
+
+    def forward(self, x):
+        x = self.base(x).squeeze()
+        return F.normalize(x, p=2, dim=1) if self.norm_feat else x
+
+
+class AVModel(nn.Module):             # model.py:169-252
+    def __init__(self, vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', pretrained=False, norm_feat=True,
+                 use_mlp=False, headcount=1, num_classes=256, use_max_pool=False):
+        super().__init__()
+        self.use_mlp, self.hc, self.norm_feat = use_mlp, headcount, norm_feat
+        self.return_features = False
+        self.video_network = VideoBaseNetwork(vid_base_arch, pretrained=pretrained)
+        self.audio_network = AudioBaseNetwork(aud_base_arch, pretrained=pretrained)
+        mk = (lambda: snn.MLPv2(512, num_classes, n_hidden=512)) if use_mlp else \
+            (lambda: snn.LinearHead(512, num_classes))
+        if self.hc == 1:
+            self.mlp_v, self.mlp_a = mk(), mk()
+        else:
+            for a in range(self.hc):
+                setattr(self, "mlp_v%d" % a, mk())
+                setattr(self, "mlp_a%d" % a, mk())
+        self._dropout_masks = None      # tests may inject (m1, m2) [G][B][512] float masks
+        self.set_sync_bn("auto")
+
+    # ---- SyncBN (main.py:117-118 converts every BN; here it is a switch on the fused BN kernels)
+    def set_sync_bn(self, mode, group=None):
+        """mode: 'auto' (sync iff torch.distributed is initialised with world_size > 1), True, False."""
+        if mode is True:
+            import torch.distributed as dist
+            sync = (group, dist.get_world_size(group))
+        elif mode == "auto":
+            sync = "auto"
+        else:
+            sync = None
+        self._sync = sync
+        self.video_network.base.sync = sync
+        self.audio_network.base.sync = sync
+        for h in self._heads():
+            h.sync = sync
+
+    def _heads(self):
+        if self.hc == 1:
+            return [self.mlp_v, self.mlp_a]
+        return [getattr(self, "mlp_v%d" % h) for h in range(self.hc)] + \
+               [getattr(self, "mlp_a%d" % h) for h in range(self.hc)]
+
+    def forward(self, img, spec, whichhead=0):
+        img_features = self.video_network(img).squeeze()
+        aud_features = self.audio_network(spec).squeeze()
+        if self.return_features:                                  # model.py:226-227
+            return img_features, aud_features
+        if aud_features.dim() == 1:
+            aud_features = aud_features.unsqueeze(0)
+        if img_features.dim() == 1:
+            img_features = img_features.unsqueeze(0)
+        heads = self._heads()
+        spec_ = snn.HeadSpec(heads, self.hc, False, self.use_mlp, self.training,
+                             snn._sync_of(self.video_network.base) if self.training else None,
+                             masks=self._dropout_masks)
+        logits = snn.HeadsFunction.apply(spec_, img_features.contiguous(), aud_features.contiguous(),
+                                         *snn.head_params(heads))
+        if self.norm_feat:
+            logits = F.normalize(logits, p=2, dim=2)
+        if self.hc == 1:
+            return logits[0], logits[1]
+        outs1, outs2 = snn.HeadList(logits[h] for h in range(self.hc)), \
+            snn.HeadList(logits[self.hc + h] for h in range(self.hc))
+        outs1.stacked, outs2.stacked = logits[:self.hc], logits[self.hc:]
+        return outs1, outs2
+
+
+def load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', pretrained=False, norm_feat=True,
+               use_mlp=False, headcount=1, num_classes=256, use_max_pool=False):   # model.py:255-275
+    return AVModel(vid_base_arch=vid_base_arch, aud_base_arch=aud_base_arch, pretrained=pretrained,
+                   norm_feat=norm_feat, use_mlp=use_mlp, headcount=headcount, num_classes=num_classes,
+                   use_max_pool=use_max_pool)

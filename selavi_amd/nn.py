@@ -1,0 +1,435 @@
+"""Parameter-holder modules with torchvision-compatible names, and the autograd glue.
+
+The module tree reproduces the ``state_dict`` layout of the reference model (torchvision 0.4.2
+``r2plus1d_18`` / ``ResNet(BasicBlock)`` as instantiated by /root/reference/model.py:95,114 and the
+``MLPv2`` heads of model.py:62-90), so reference checkpoints load by name.  The holders do not
+compute: the trunks run through ``selavi_amd.engine`` (one ``autograd.Function`` per trunk), the
+heads through ``HeadsFunction`` -- all HIP kernels behind the C ABI.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import engine, ops
+from ._lib import C, ptr, stream
+
+
+# ------------------------------------------------------------------------------------------ holders
+class Conv(nn.Module):
+    """Bias-free convolution weight holder (3-D: [Cout,Cin,kt,kh,kw]; 2-D: [Cout,Cin,kh,kw])."""
+
+    def __init__(self, cin, cout, k, stride, pad, dims=3, init="kaiming_fan_out"):
+        super().__init__()
+        self.in_channels, self.out_channels, self.dims = cin, cout, dims
+        if dims == 3:
+            self.kernel3, self.stride3, self.padding3 = tuple(k), tuple(stride), tuple(pad)
+            shape = (cout, cin) + tuple(k)
+        else:
+            self.kernel3, self.stride3, self.padding3 = (1,) + tuple(k), (1,) + tuple(stride), (0,) + tuple(pad)
+            shape = (cout, cin) + tuple(k)
+        self.weight = nn.Parameter(torch.empty(*shape))
+        if init == "kaiming_fan_out":      # model.py:54 / torchvision ResNet init
+            nn.init.kaiming_normal_(self.weight, mode='fan_out', nonlinearity='relu')
+        else:                              # default nn.Conv2d init (the replaced audio conv1, model.py:117)
+            nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, kernel={self.kernel3}, stride={self.stride3}, pad={self.padding3}"
+
+
+class BatchNorm(nn.Module):
+    """BatchNorm parameter/buffer holder (gamma=1, beta=0, eps 1e-5, momentum 0.1)."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._pending = 0
+
+    def note_batch(self):
+        self._pending += 1          # folded into num_batches_tracked lazily (no per-step kernel)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self._pending:
+            self.num_batches_tracked += self._pending
+            self._pending = 0
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+
+class BatchNorm3d(BatchNorm):
+    pass
+
+
+class BatchNorm2d(BatchNorm):
+    pass
+
+
+class BatchNorm1d(BatchNorm):
+    pass
+
+
+class ReLU(nn.Module):
+    def forward(self, x):            # placeholder keeping torchvision's Sequential indices
+        raise RuntimeError("selavi_amd: ReLU is fused into the conv kernels; run the trunk, not its children")
+
+
+class Identity(nn.Module):           # model.py:43-48
+    def forward(self, x):
+        return x
+
+
+class Flatten(nn.Module):            # model.py:25-31
+    def forward(self, x):
+        return x.view(x.shape[0], -1)
+
+
+class Unsqueeze(nn.Module):          # model.py:34-40
+    def forward(self, x):
+        return x.unsqueeze(-1)
+
+
+def Conv2Plus1D(cin, cout, mid, stride=1):
+    return nn.Sequential(
+        Conv(cin, mid, (1, 3, 3), (1, stride, stride), (0, 1, 1)), BatchNorm3d(mid), ReLU(),
+        Conv(mid, cout, (3, 1, 1), (stride, 1, 1), (1, 0, 0)))
+
+
+class VideoBlock(nn.Module):
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        mid = (inplanes * planes * 3 * 3 * 3) // (inplanes * 3 * 3 + 3 * planes)
+        self.conv1 = nn.Sequential(Conv2Plus1D(inplanes, planes, mid, stride), BatchNorm3d(planes), ReLU())
+        self.conv2 = nn.Sequential(Conv2Plus1D(planes, planes, mid), BatchNorm3d(planes))
+        self.relu = ReLU()
+        self.downsample = downsample
+
+
+class VideoResNet(nn.Module):
+    """r2plus1d_18 holder; ``forward`` runs the fused engine (train: batch stats, eval: running)."""
+
+    def __init__(self):
+        super().__init__()
+        self.stem = nn.Sequential(
+            Conv(3, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)), BatchNorm3d(45), ReLU(),
+            Conv(45, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)), BatchNorm3d(64), ReLU())
+        inpl = 64
+        for i, (planes, stride) in enumerate([(64, 1), (128, 2), (256, 2), (512, 2)]):
+            ds = None
+            if stride != 1 or inpl != planes:
+                ds = nn.Sequential(Conv(inpl, planes, (1, 1, 1), (stride,) * 3, (0, 0, 0)), BatchNorm3d(planes))
+            setattr(self, f"layer{i + 1}", nn.Sequential(VideoBlock(inpl, planes, stride, ds),
+                                                          VideoBlock(planes, planes)))
+            inpl = planes
+        self.avgpool = Identity()
+        self.fc = Identity()           # model.py:99
+        self.sync = None
+
+    def forward(self, x):
+        return TrunkFunction.apply(self, "video", x.contiguous(), *_trunk_params(self))
+
+
+class AudioBlock(nn.Module):
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv(inplanes, planes, (3, 3), (stride, stride), (1, 1), dims=2)
+        self.bn1 = BatchNorm2d(planes)
+        self.relu = ReLU()
+        self.conv2 = Conv(planes, planes, (3, 3), (1, 1), (1, 1), dims=2)
+        self.bn2 = BatchNorm2d(planes)
+        self.downsample = downsample
+
+
+class AudioResNet(nn.Module):
+    """torchvision ResNet(BasicBlock, layers) with the 1-channel conv1 of model.py:117-119."""
+
+    def __init__(self, layers=(1, 1, 1, 1)):
+        super().__init__()
+        self.conv1 = Conv(1, 64, (7, 7), (2, 2), (3, 3), dims=2, init="default")
+        self.bn1 = BatchNorm2d(64)
+        self.relu = ReLU()
+        self.maxpool = Identity()
+        inpl = 64
+        for i, (planes, stride, n) in enumerate(zip((64, 128, 256, 512), (1, 2, 2, 2), layers)):
+            blocks = []
+            for j in range(n):
+                s = stride if j == 0 else 1
+                ds = None
+                if s != 1 or inpl != planes:
+                    ds = nn.Sequential(Conv(inpl, planes, (1, 1), (s, s), (0, 0), dims=2), BatchNorm2d(planes))
+                blocks.append(AudioBlock(inpl, planes, s, ds))
+                inpl = planes
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+        self.avgpool = Identity()
+        self.fc = Identity()
+        self.sync = None
+
+    def forward(self, x):
+        return TrunkFunction.apply(self, "audio", x.contiguous(), *_trunk_params(self))
+
+
+def _trunk_params(trunk):
+    ps = getattr(trunk, "_plist", None)
+    if ps is None:
+        ps = trunk._plist = [p for p in trunk.parameters()]
+    return ps
+
+
+def _sync_of(mod):
+    s = getattr(mod, "sync", None)
+    if s == "auto":
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return (None, dist.get_world_size())
+        return None
+    return s
+
+
+class TrunkFunction(torch.autograd.Function):
+    """One autograd node per trunk: forward = engine schedule, backward = hand-written schedule."""
+
+    @staticmethod
+    def forward(fctx, trunk, kind, x, *params):
+        training = trunk.training
+        need_grad = training and any(fctx.needs_input_grad)
+        ectx = engine.Ctx(training, sync=_sync_of(trunk) if training else None)
+        fwd = engine.video_forward if kind == "video" else engine.audio_forward
+        feat, saved = fwd(ectx, trunk, x)
+        fctx.need = need_grad
+        if need_grad:
+            fctx.saved_rec, fctx.trunk, fctx.kind, fctx.sync = saved, trunk, kind, ectx.sync
+        return feat
+
+    @staticmethod
+    def backward(fctx, dfeat):
+        if not fctx.need:
+            raise RuntimeError("selavi_amd: backward through a trunk that ran in eval / no_grad mode")
+        ectx = engine.Ctx(True, sync=fctx.sync)
+        bwd = engine.video_backward if fctx.kind == "video" else engine.audio_backward
+        bwd(ectx, fctx.saved_rec, dfeat)
+        fctx.saved_rec = None
+        grads = [ectx.grads.get(id(p)) for p in _trunk_params(fctx.trunk)]
+        return (None, None, None) + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------ heads
+class MLPv2(nn.Module):
+    """model.py:62-90.  ``forward`` (one head, e.g. the SK feature-bank pass of sk_utils.py:309-312)
+    runs the MFMA GEMM in eval mode and the grouped kernels (G = 1) in train mode."""
+
+    def __init__(self, n_input, n_classes, n_hidden=512, p=0.3):
+        super().__init__()
+        self.n_input, self.n_classes, self.n_hidden = n_input, n_classes, n_hidden
+        if n_hidden is None:
+            self.block_forward = nn.Sequential(Flatten(), nn.Dropout(p=p), nn.Linear(n_input, n_classes, bias=True))
+        else:
+            self.block_forward = nn.Sequential(
+                Flatten(), nn.Dropout(p=p), nn.Linear(n_input, n_hidden, bias=False), Unsqueeze(),
+                BatchNorm1d(n_hidden), Flatten(), ReLU(), nn.Dropout(p=p), nn.Linear(n_hidden, n_classes, bias=True))
+
+    def forward(self, x):
+        x = x.reshape(x.shape[0], -1).contiguous()
+        if self.training:
+            out = HeadsFunction.apply(HeadSpec([self], 1, True, self.n_hidden is not None, self.training,
+                                               _sync_of(self)), x, x, *head_params([self]))
+            return out[0]
+        bf = self.block_forward
+        if self.n_hidden is None:
+            return ops.gemm_nt(x, bf[2].weight, bf[2].bias)
+        h = ops.gemm_nt(x, bf[2].weight)
+        _, ss = ops.bn_eval_params(bf[4].weight, bf[4].bias, bf[4].running_mean, bf[4].running_var, bf[4].eps)
+        C.slv_rowwise_affine(ptr(h), ptr(ss), 1, ptr(h), h.shape[0], h.shape[1], stream())
+        return ops.gemm_nt(h, bf[8].weight, bf[8].bias)
+
+
+class LinearHead(nn.Linear):
+    """``nn.Linear(512, K)`` head of the use_mlp=False configuration (model.py:207-208,218-219)."""
+
+    def forward(self, x):
+        x = x.reshape(x.shape[0], -1).contiguous()
+        return ops.gemm_nt(x, self.weight, self.bias) if not torch.is_grad_enabled() or not self.training else \
+            HeadsFunction.apply(HeadSpec([self], 1, True, False, True, None), x, x, *head_params([self]))[0]
+
+
+class HeadSpec:
+    def __init__(self, heads, hc, single, has_hidden, training, sync, masks=None):
+        self.heads, self.hc, self.single, self.has_hidden = heads, hc, single, has_hidden
+        self.training, self.sync, self.masks = training, sync, masks
+
+
+def _lin_of(head, idx):
+    return head.block_forward[idx] if isinstance(head, MLPv2) else head
+
+
+def head_params(heads):
+    ps = []
+    for h in heads:
+        ps.extend(list(h.parameters()))
+    return ps
+
+
+class HeadList(list):
+    """List of per-head logits (the reference returns Python lists, model.py:240-252) that also
+    carries the stacked [hc][B][K] tensor so get_loss can run one grouped kernel."""
+    stacked = None
+
+
+class HeadsFunction(torch.autograd.Function):
+    """All heads of both modalities in a handful of grouped launches (csrc/heads.hip).
+
+    Inputs: feat_v [B,512], feat_a [B,512], then the parameters of every head in ``spec.heads`` order.
+    Output: logits [G][B][K] with G = len(spec.heads); heads[:G/2] read feat_v, heads[G/2:] feat_a
+    (``spec.single``: one head reading feat_v)."""
+
+    @staticmethod
+    def forward(fctx, spec, feat_v, feat_a, *params):
+        heads = spec.heads
+        G = len(heads)
+        hcg = 1 if spec.single else G // 2          # heads per modality
+        B = feat_v.shape[0]
+        dev = feat_v.device
+        st = stream()
+        X = torch.stack([feat_v, feat_a]).contiguous() if not spec.single else feat_v.contiguous().unsqueeze(0)
+        shared = 1
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        train = spec.training
+        if spec.has_hidden:
+            lin1 = [_lin_of(h, 2) for h in heads]
+            bns = [h.block_forward[4] for h in heads]
+            lin2 = [_lin_of(h, 8) for h in heads]
+            p = heads[0].block_forward[1].p if train else 0.0
+            IN, HID, K = lin1[0].weight.shape[1], lin1[0].weight.shape[0], lin2[0].weight.shape[0]
+            m1 = m2 = None
+            msc = 1.0
+            if train and p > 0:
+                if spec.masks is not None:
+                    m1, m2 = spec.masks
+                else:
+                    m1 = torch.bernoulli(torch.full((G, B, IN), 1 - p, device=dev))
+                    m2 = torch.bernoulli(torch.full((G, B, HID), 1 - p, device=dev))
+                msc = 1.0 / (1.0 - p)
+            W1 = ops.PtrArray([l.weight for l in lin1])
+            h = f32(G, B, HID)
+            C.slv_heads_linear_fwd(ptr(X), shared, hcg, ptr(m1), msc, W1.p, 0, ptr(h), G, B, IN, HID, st)
+            ga, be = ops.PtrArray([b.weight for b in bns]), ops.PtrArray([b.bias for b in bns])
+            rm, rv = ops.PtrArray([b.running_mean for b in bns]), ops.PtrArray([b.running_var for b in bns])
+            sums = None
+            count = float(B)
+            if train:
+                sums = torch.empty(G, 2, HID, dtype=torch.float64, device=dev)
+                C.slv_heads_bn_stats(ptr(h), ptr(sums), G, B, HID, st)
+                if spec.sync is not None:
+                    ops._allreduce(sums, spec.sync[0])
+                    count *= spec.sync[1]
+                for b in bns:
+                    b.note_batch()
+            a = f32(G, B, HID)
+            mi = f32(G, 2, HID)
+            C.slv_heads_bn_apply(ptr(h), ptr(sums), count, ga.p, be.p, rm.p, rv.p, ptr(m2), msc, bns[0].momentum,
+                                 bns[0].eps, int(train), ptr(a), ptr(mi), G, B, HID, st)
+            W2, b2 = ops.PtrArray([l.weight for l in lin2]), ops.PtrArray([l.bias for l in lin2])
+            logits = f32(G, B, K)
+            C.slv_heads_linear_fwd(ptr(a), 0, hcg, 0, 1.0, W2.p, b2.p, ptr(logits), G, B, HID, K, st)
+            fctx.saved = (X, m1, m2, msc, h, a, mi, count)
+        else:
+            lin = [_lin_of(h, 2) for h in heads]
+            p = heads[0].block_forward[1].p if (train and isinstance(heads[0], MLPv2)) else 0.0
+            IN, K = lin[0].weight.shape[1], lin[0].weight.shape[0]
+            m1, msc = None, 1.0
+            if train and p > 0:
+                m1 = spec.masks[0] if spec.masks is not None else torch.bernoulli(torch.full((G, B, IN), 1 - p, device=dev))
+                msc = 1.0 / (1.0 - p)
+            W, bb = ops.PtrArray([l.weight for l in lin]), ops.PtrArray([l.bias for l in lin])
+            logits = f32(G, B, K)
+            C.slv_heads_linear_fwd(ptr(X), shared, hcg, ptr(m1), msc, W.p, bb.p, ptr(logits), G, B, IN, K, st)
+            fctx.saved = (X, m1, None, msc, None, None, None, float(B))
+        fctx.spec, fctx.hcg = spec, hcg
+        return logits
+
+    @staticmethod
+    def backward(fctx, dlogits):
+        spec, hcg = fctx.spec, fctx.hcg
+        heads = spec.heads
+        G = len(heads)
+        X, m1, m2, msc, h, a, mi, count = fctx.saved
+        fctx.saved = None
+        dev = X.device
+        st = stream()
+        B = X.shape[1]
+        dlogits = dlogits.contiguous()
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        grads = {}
+        if spec.has_hidden:
+            lin1 = [_lin_of(hd, 2) for hd in heads]
+            bns = [hd.block_forward[4] for hd in heads]
+            lin2 = [_lin_of(hd, 8) for hd in heads]
+            IN, HID, K = lin1[0].weight.shape[1], lin1[0].weight.shape[0], lin2[0].weight.shape[0]
+            dW2, db2 = f32(G, K, HID), f32(G, K)
+            C.slv_heads_linear_bwd_w(ptr(dlogits), ptr(a), 0, hcg, 0, 1.0, ptr(dW2), ptr(db2), G, B, HID, K, st)
+            W2 = ops.PtrArray([l.weight for l in lin2])
+            da = f32(G, B, HID)
+            C.slv_heads_linear_bwd_x(ptr(dlogits), W2.p, 0, 1.0, ptr(da), G, B, HID, K, st)
+            ga, be = ops.PtrArray([b.weight for b in bns]), ops.PtrArray([b.bias for b in bns])
+            sums = torch.empty(G, 2, HID, dtype=torch.float64, device=dev)
+            C.slv_heads_bn_bwd_stats(ptr(da), ptr(h), ptr(mi), ga.p, be.p, ptr(m2), msc, ptr(sums), G, B, HID, st)
+            if spec.sync is not None:
+                ops._allreduce(sums, spec.sync[0])
+            dh, dga, dbe = f32(G, B, HID), f32(G, HID), f32(G, HID)
+            C.slv_heads_bn_bwd_apply(ptr(da), ptr(h), ptr(mi), ga.p, be.p, ptr(m2), msc, ptr(sums), count, ptr(dh),
+                                     ptr(dga), ptr(dbe), G, B, HID, st)
+            dW1 = f32(G, HID, IN)
+            C.slv_heads_linear_bwd_w(ptr(dh), ptr(X), 1, hcg, ptr(m1), msc, ptr(dW1), 0, G, B, IN, HID, st)
+            W1 = ops.PtrArray([l.weight for l in lin1])
+            dxg = f32(G, B, IN)
+            C.slv_heads_linear_bwd_x(ptr(dh), W1.p, ptr(m1), msc, ptr(dxg), G, B, IN, HID, st)
+            for g in range(G):
+                grads[id(lin1[g].weight)] = dW1[g]
+                grads[id(bns[g].weight)] = dga[g]
+                grads[id(bns[g].bias)] = dbe[g]
+                grads[id(lin2[g].weight)] = dW2[g]
+                grads[id(lin2[g].bias)] = db2[g]
+        else:
+            lin = [_lin_of(hd, 2) for hd in heads]
+            IN, K = lin[0].weight.shape[1], lin[0].weight.shape[0]
+            dW, db = f32(G, K, IN), f32(G, K)
+            C.slv_heads_linear_bwd_w(ptr(dlogits), ptr(X), 1, hcg, ptr(m1), msc, ptr(dW), ptr(db), G, B, IN, K, st)
+            W = ops.PtrArray([l.weight for l in lin])
+            dxg = f32(G, B, IN)
+            C.slv_heads_linear_bwd_x(ptr(dlogits), W.p, ptr(m1), msc, ptr(dxg), G, B, IN, K, st)
+            for g in range(G):
+                grads[id(lin[g].weight)] = dW[g]
+                grads[id(lin[g].bias)] = db[g]
+        if spec.single:
+            dfv, dfa = dxg[0], None
+        else:
+            dX = f32(2, B, dxg.shape[2])
+            C.slv_heads_sum_groups(ptr(dxg), ptr(dX), hcg, B * dxg.shape[2], st)
+            dfv, dfa = dX[0], dX[1]
+        pg = [grads.get(id(p)) for p in head_params(heads)]
+        return (None, dfv, dfa) + tuple(pg)
+
+
+class GroupedCE(torch.autograd.Function):
+    """mean over heads of mean-over-batch cross entropy (utils.py:377-387) in one kernel."""
+
+    @staticmethod
+    def forward(fctx, logits, targets):
+        G, B, K = logits.shape
+        logits = logits.contiguous()
+        tg = targets.reshape(B, -1).contiguous()
+        hc = tg.shape[1]
+        assert hc == G or hc == 1
+        loss_rows = torch.empty(G * B, dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits)
+        C.slv_heads_ce(ptr(logits), ptr(tg), hc, hc, ptr(loss_rows), ptr(dl), 1.0 / (G * B), G, B, K, stream())
+        fctx.save_for_backward(dl)
+        return loss_rows.sum() / (G * B)
+
+    @staticmethod
+    def backward(fctx, gout):
+        (dl,) = fctx.saved_tensors
+        return dl * gout, None

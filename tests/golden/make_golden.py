@@ -90,7 +90,52 @@ def label_digest(L):
     return hashlib.sha256(np.ascontiguousarray(L.astype(np.int32)).tobytes()).hexdigest()
 
 
+def grad_fixture(ref_model, ref_utils):
+    """All-parameter gradient fixture: fp64 run of the reference model (truth), fp32 run (the
+    reference's own arithmetic noise), first 256 elements + norm of every parameter gradient."""
+    hc, K, B, T, S = 1, 28, 4, 4, 32
+    video = portable_fill_(torch.empty(B, 3, T, S, S), 5, kind="normal")
+    audio = portable_fill_(torch.empty(B, 1, 40, 36), 6, kind="normal")
+    N = 64
+    selflabels = torch.from_numpy((np.arange(N * hc).reshape(N, hc) * 7919 % K).astype(np.int64))
+    selected = torch.tensor([3, 17, 42, 63])
+    res = {}
+    for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        m = ref_model.load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', use_mlp=True,
+                                 num_classes=K, pretrained=False, norm_feat=False, use_max_pool=False, headcount=hc)
+        portable_init_(m, seed=31)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        m = m.to(dtype).train()
+        fv, fa = m(video.to(dtype), audio.to(dtype))
+        labels = selflabels[selected, 0]
+        loss = 0.5 * ref_utils.get_loss(fv, labels, headcount=hc) + 0.5 * ref_utils.get_loss(fa, labels, headcount=hc)
+        loss.backward()
+        res[tag] = {k: p.grad.detach().double() for k, p in m.named_parameters()}
+        res[tag + "_loss"] = loss.item()
+    names = list(res["f64"].keys())
+    heads = np.zeros((len(names), 256))
+    norms = np.zeros(len(names))
+    e_cpu = np.zeros(len(names))
+    for i, k in enumerate(names):
+        g64, g32 = res["f64"][k].flatten(), res["f32"][k].flatten()
+        n = min(256, g64.numel())
+        heads[i, :n] = g64[:n].numpy()
+        norms[i] = g64.norm().item()
+        e_cpu[i] = (g32 - g64).norm().item() / (norms[i] + 1e-300)
+    np.savez_compressed(os.path.join(OUT, "grads_hc1_k28.npz"), names=np.array(names), heads=heads, norms=norms,
+                        e_cpu=e_cpu, loss64=res["f64_loss"], loss32=res["f32_loss"], hc=hc, K=K, B=B, T=T, S=S,
+                        selflabels=selflabels.numpy(), selected=selected.numpy())
+    print("grad fixture: median fp32 noise %.2e max %.2e" % (np.median(e_cpu), e_cpu.max()))
+
+
 def main():
+    if "--only-grads" in sys.argv:
+        ref_model, ref_utils, ref_sk = import_reference()
+        torch.set_num_threads(os.cpu_count())
+        grad_fixture(ref_model, ref_utils)
+        return
     torch.manual_seed(0)
     np.random.seed(0)
     ref_model, ref_utils, ref_sk = import_reference()
@@ -218,6 +263,8 @@ def main():
             for k, s in zip(keys, shapes):
                 f.write(f"{k} {list(s)}\n")
         print("keys", hc, len(keys), sum(p.numel() for p in m.parameters()))
+
+    grad_fixture(ref_model_mod, ref_utils)
 
     # get_loss fixture (utils.py:377-387)
     acts = [portable_fill_(torch.empty(5, 9), 40 + h, kind="normal") for h in range(3)]

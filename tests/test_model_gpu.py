@@ -1,0 +1,183 @@
+"""GPU parity tests of the full model / training step: HIP engine vs the CPU oracle and the golden
+vectors of the executed reference.  Tolerance 1e-3 (BASELINE.json north star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref, step_ref
+from oracle.model_ref import portable_fill_, portable_init_
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(hc, K, use_mlp):
+    from selavi_amd import model as smodel
+    m = smodel.load_model(use_mlp=use_mlp, num_classes=K, norm_feat=False, headcount=hc)
+    portable_init_(m, seed=31)
+    step_ref.set_dropout_p(m, 0.0)
+    return m.cuda()
+
+
+def _check_all_grads(m, golden_dir):
+    """Every parameter gradient vs the fp64 run of the reference model (tests/golden/grads_*.npz).
+    The net at random init is ill-conditioned (BN batch statistics): the reference's OWN fp32 CPU
+    gradients deviate from fp64 by a median ~1e-4 and up to ~1e-2, so the bar is "as accurate as the
+    reference's fp32 arithmetic": err <= max(5 * e_cpu, 10 * median(e_cpu), 2e-3) per tensor, on the
+    first 256 elements and on the norm."""
+    g = np.load(os.path.join(golden_dir, "grads_hc1_k28.npz"))
+    names = [str(n) for n in g["names"]]
+    params = dict(m.named_parameters())
+    assert set(names) == set(params.keys())
+    med = float(np.median(g["e_cpu"]))
+    worst = 0.0
+    for i, name in enumerate(names):
+        gr = params[name].grad.detach().double().cpu()
+        n = min(256, gr.numel())
+        tol = max(5 * float(g["e_cpu"][i]), 10 * med, 2e-3)
+        ref_norm = float(g["norms"][i])
+        assert abs(gr.norm().item() - ref_norm) <= tol * ref_norm + 1e-12, (name, gr.norm().item(), ref_norm)
+        head = torch.from_numpy(g["heads"][i, :n])
+        err = (gr.flatten()[:n] - head).norm().item()
+        # the head error is measured against the WHOLE tensor's rms so tiny leading entries don't dominate
+        scale = ref_norm * (n / gr.numel()) ** 0.5 + 1e-30
+        assert err <= 3 * tol * scale + 1e-12, (name, err, scale, tol)
+        worst = max(worst, err / scale)
+    print(f"worst head error / tensor rms: {worst:.2e} (median fp32-oracle noise {med:.2e})")
+
+
+def _stack(x):
+    return torch.stack(list(x)) if isinstance(x, (list, tuple)) else x.unsqueeze(0)
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    from selavi_amd import model as smodel
+    for hc, K in [(1, 28), (10, 309)]:
+        m = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
+        lines = [l.split(" ", 1) for l in open(os.path.join(golden_dir, f"state_dict_keys_hc{hc}.txt"))]
+        sd = m.state_dict()
+        assert list(sd.keys()) == [k for k, _ in lines]
+        for (k, shp), v in zip(lines, sd.values()):
+            assert list(v.shape) == eval(shp), k
+
+
+@pytest.mark.parametrize("fx", ["model_hc1_k28_mlp1", "model_hc3_k12_mlp1", "model_hc2_k7_mlp0"])
+def test_model_and_two_train_steps_match_reference_golden(golden_dir, fx):
+    from selavi_amd import optim, train
+    g = np.load(os.path.join(golden_dir, fx + ".npz"))
+    hc, K, use_mlp = int(g["hc"]), int(g["K"]), bool(g["use_mlp"])
+    B, T, S = int(g["B"]), int(g["T"]), int(g["S"])
+    m = _build(hc, K, use_mlp)
+    assert len(m.state_dict()) == int(g["n_keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"])
+    video = portable_fill_(torch.empty(B, 3, T, S, S), 5).cuda()
+    audio = portable_fill_(torch.empty(B, 1, 40, 36), 6).cuda()
+    m.eval()
+    with torch.no_grad():
+        fv, fa = m(video, audio)
+        m.return_features = True
+        gv, ga = m(video, audio)
+        m.return_features = False
+    np.testing.assert_allclose(_stack(fv).cpu().numpy(), g["eval_v"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(_stack(fa).cpu().numpy(), g["eval_a"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(gv.cpu().numpy(), g["feat_v"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(ga.cpu().numpy(), g["feat_a"], rtol=1e-3, atol=1e-3)
+    # two training steps (main.py:284-302 with the fused SGD)
+    m.train()
+    opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+    selflabels = torch.from_numpy(g["selflabels"]).cuda()
+    selected = torch.from_numpy(g["selected"]).cuda()
+    losses = []
+    for step in range(2):
+        if step == 0:
+            fv, fa = m(video, audio)
+            np.testing.assert_allclose(_stack(fv).detach().cpu().numpy(), g["train_v"], rtol=1e-3, atol=1e-3)
+            np.testing.assert_allclose(_stack(fa).detach().cpu().numpy(), g["train_a"], rtol=1e-3, atol=1e-3)
+            # undo the running-stat side effect of this probe forward: reload buffers
+            m2 = _build(hc, K, use_mlp)
+            m.load_state_dict(m2.state_dict())
+            for mod in m.modules():
+                if hasattr(mod, "_pending"):
+                    mod._pending = 0
+            if True:
+                # gradient check on the first step
+                from selavi_amd.utils import get_loss
+                fv, fa = m(video, audio)
+                labels = selflabels[selected, 0] if hc == 1 else selflabels[selected, :]
+                loss = 0.5 * get_loss(fv, labels, hc) + 0.5 * get_loss(fa, labels, hc)
+                opt.zero_grad()
+                loss.backward()
+                if fx == "model_hc1_k28_mlp1":
+                    _check_all_grads(m, golden_dir)
+                w_before = {k: v.detach().clone() for k, v in m.named_parameters()}
+                g_before = {k: v.grad.detach().clone() for k, v in m.named_parameters()}
+                opt.step()
+                for k, v in m.named_parameters():     # first SGD step: p -= lr * (g + wd * p)
+                    want = w_before[k] - 1e-2 * (g_before[k] + 1e-5 * w_before[k])
+                    assert torch.allclose(v.detach(), want, rtol=1e-5, atol=1e-6), k
+                losses.append(loss.item())
+        else:
+            losses.append(train.train_step(m, opt, video, audio, selflabels, selected, hc).item())
+    # step 1 is a pure forward: 1e-3 (measured ~3e-6).  Step 2 sees the weights after one lr=1e-2 SGD
+    # step with gradient norms of O(100): the reference's own fp32 CPU run lands 5.9e-3 away from its
+    # fp64 run there (2.62873 vs 2.63459 for the hc=1 fixture; HIP: 2.63605), so step 2 is compared
+    # with the oracle's fp32-vs-fp64 noise band, not 1e-3.
+    np.testing.assert_allclose(losses[0], g["losses"][0], rtol=1e-3)
+    np.testing.assert_allclose(losses[1], g["losses"][1], rtol=1e-2)
+    if fx == "model_hc1_k28_mlp1":
+        assert abs(losses[1] - 2.6345948718456587) <= 3 * abs(2.6287312507629395 - 2.6345948718456587)
+    # Weights after TWO steps are chaotic at this lr (the step-2 gradient norm of the stem is 186 in the
+    # reference's fp64 run and 154 in its fp32 run), so only the BN running statistics are compared
+    # after step 2; the SGD update itself is checked after step 1 in _check_all_grads / below.
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith("post/") and "running_" in k:
+            np.testing.assert_allclose(sd[k[5:]].flatten()[:64].cpu().numpy(), g[k], rtol=5e-2, atol=5e-3)
+    assert int(sd["video_network.base.stem.1.num_batches_tracked"]) == 2
+
+
+def test_dropout_masks_and_larger_batch_match_oracle():
+    """Train-mode logits with an injected dropout mask (p = 0.3) at B = 5, T = 6, hc = 2."""
+    hc, K, B = 2, 9, 5
+    m = _build(hc, K, True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.3
+    o = model_ref.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
+    portable_init_(o, seed=31)
+    video = portable_fill_(torch.empty(B, 3, 6, 24, 24), 15)
+    audio = portable_fill_(torch.empty(B, 1, 33, 30), 16)
+    g = torch.Generator().manual_seed(4)
+    m1 = torch.bernoulli(torch.full((2 * hc, B, 512), 0.7), generator=g)
+    m2 = torch.bernoulli(torch.full((2 * hc, B, 512), 0.7), generator=g)
+    m._dropout_masks = (m1.cuda(), m2.cuda())
+    m.train()
+    fv, fa = m(video.cuda(), audio.cuda())
+    # oracle with the same masks: run trunks, then heads by hand
+    o.train()
+    o.return_features = True
+    with torch.no_grad():
+        gv, ga = o(video, audio)
+    heads = [getattr(o, f"mlp_v{h}") for h in range(hc)] + [getattr(o, f"mlp_a{h}") for h in range(hc)]
+    for gi, hd in enumerate(heads):
+        x = (gv if gi < hc else ga) * m1[gi] / 0.7
+        bf = hd.block_forward
+        h1 = bf[2](x)
+        a = torch.relu(torch.nn.functional.batch_norm(h1, None, None, bf[4].weight, bf[4].bias, True, 0.1, 1e-5))
+        want = bf[8](a * m2[gi] / 0.7)
+        got = (fv if gi < hc else fa)[gi % hc]
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-3, atol=2e-3)
+
+
+def test_single_head_forward_on_feature_bank():
+    """head.forward(N x 512 bank) in eval mode -- the call sk_utils.py:309-312 makes."""
+    m = _build(3, 12, True)
+    o = model_ref.load_model(use_mlp=True, num_classes=12, norm_feat=False, headcount=3)
+    portable_init_(o, seed=31)
+    m.eval(), o.eval()
+    bank = portable_fill_(torch.empty(1000, 512), 3)
+    with torch.no_grad():
+        got = m.mlp_a1.forward(bank.cuda()).cpu()
+        want = o.mlp_a1.forward(bank)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-3, atol=1e-3)
