@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py -- SeLaVi training-step throughput on N MI355X of one node (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one synthetic batch per GPU: R(2+1)D-18 video + ResNet-9
+audio forward, 2*hc MLP heads, cross-entropy on the SK pseudo labels, backward, fused SGD
+(/root/reference/main.py:284-302).  Workload = BASELINE.json configs[1] ("cfg2"): per-GPU batch 16,
+16x112x112 clips, 1x129x100 log-mel, K=309, headcount 10, fp32 (weak scaling: cfg3 at N=8).
+The SK solver is timed separately (iterations/s at the VGG-Sound size N=170752, K=309, row-sharded
+over the N ranks) and reported in the same JSON line.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG2 = dict(batch=16, T=16, S=112, F=129, Tp=100, K=309, hc=10, N=170752)
+# algorithmic work per clip of the forward (fused BN/ReLU): video 81.04 + audio 0.506 GFLOP
+# + heads 0.0168 GFLOP; step = 3x forward (dgrad + wgrad)
+FWD_GFLOP_PER_CLIP = 81.04 + 0.506 + 0.0168
+PEAK_FP32_MFMA_TF = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=CFG2["batch"], help="per-GPU batch (cfg2: 16)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sk", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+def hot_conv_roofline(batch, dev):
+    """Dominant kernel: the implicit-GEMM conv (csrc/igemm.hpp).  Its heaviest single launch in the
+    step is the layer-1 spatial conv Conv3d(64->144,(1,3,3)) on B x 64 x 16 x 56 x 56 (4 forward
+    launches/step + the matching dgrad/wgrad).  Time that exact launch with HIP events on the
+    stream it runs on; achieved = 2*MACs/launch / average duration."""
+    from selavi_amd import ops
+    shape = (batch, 64, 16, 56, 56)
+    plan = ops.ConvPlan.get(shape, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(*shape, device=dev, generator=g)
+    w = torch.randn(144, 64, 1, 3, 3, device=dev, generator=g) * 0.04
+    ss = torch.stack([torch.rand(64, device=dev, generator=g) + 0.5, torch.randn(64, device=dev, generator=g) * 0.1])
+    for _ in range(3):
+        ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True)
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flop = 2.0 * batch * 16 * 56 * 56 * 144 * 64 * 9
+    return dict(kernel="igemm_kernel<MODE_FWD,MT=9,NT=2> layer1 (1,3,3) 64->144", ms=ms, flop=flop,
+                tflops=flop / ms / 1e9)
+
+
+def sk_bench(rank, world, dev, iters=50):
+    """SK iterations/s at the VGG-Sound size, rows sharded over the ranks."""
+    import torch.distributed as dist
+    from selavi_amd import sk_utils
+    N, K = CFG2["N"], CFG2["K"]
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    n = hi - lo
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    lv = torch.randn(n, K, device=dev, generator=g)
+    la = torch.randn(n, K, device=dev, generator=g)
+    P = sk_utils.head_probabilities(lv, la, power=10.0)
+    be = sk_utils._HIP
+    grid = be.default_grid(n, K)
+    ws = be.workspace(K, grid, dev)
+    beta = torch.empty(n, dtype=torch.float64, device=dev)
+    r = torch.full((K,), 1.0 / K, dtype=torch.float64, device=dev)
+    grp = dist.group.WORLD if world > 1 else None
+
+    def run(k):
+        if world == 1:
+            be.iterate(P, beta, r, 0.0, 10 ** 9, k, ws, grid)
+        else:
+            for _ in range(k):
+                be.pass_(P, N, beta, ws, grid)
+                be.local_reduce(K, ws, grid)
+                dist.all_reduce(be.s_view(ws, K, grid), group=grp)
+                be.update(r, K, 0.0, 10 ** 9, False, ws, grid)
+    be.begin(P, N, beta, ws, grid)
+    be.local_reduce(K, ws, grid)
+    if world > 1:
+        dist.all_reduce(be.s_view(ws, K, grid), group=grp)
+    be.update(r, K, 0.0, 10 ** 9, True, ws, grid)
+    run(5)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    run(iters)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    if world > 1:
+        t = torch.tensor([ms], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = t.item()
+    gbs = n * K * 8 / ms / 1e6      # per-GPU algorithmic bytes (one read of the fp64 shard) / time
+    return dict(iters_per_s=1e3 / ms, us_per_iter=ms * 1e3, N=N, K=K, rows_per_gpu=n, grid=grid,
+                roofline=dict(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
+                              traffic=None))
+
+
+def cpu_baseline(batch):
+    """The oracle (oracle/step_ref.py: torch CPU restatement of main.py:284-302, validated against
+    the executed reference) timed on this host's cores, on a bounded sample: cfg2-shaped step at a
+    smaller batch (1 warm-up + 1 timed step)."""
+    from oracle import model_ref, step_ref
+    # torch/oneDNN conv3d backward degrades badly when oversubscribed across sockets (256 threads:
+    # 210 s/step at batch 2 on the GPU box); 32 threads is the fastest setting measured there.
+    cores = min(os.cpu_count(), 32)
+    torch.set_num_threads(cores)
+    m = model_ref.load_model(use_mlp=True, num_classes=CFG2["K"], norm_feat=False, headcount=CFG2["hc"])
+    m.train()
+    opt = step_ref.make_optimizer(m)
+    g = torch.Generator().manual_seed(0)
+    video = torch.randn(batch, 3, CFG2["T"], CFG2["S"], CFG2["S"], generator=g)
+    audio = torch.randn(batch, 1, CFG2["F"], CFG2["Tp"], generator=g)
+    sl = torch.randint(0, CFG2["K"], (1024, CFG2["hc"]), generator=g)
+    sel = torch.randint(0, 1024, (batch,), generator=g)
+    step_ref.train_step(m, opt, video, audio, sl, sel, CFG2["hc"])
+    t0 = time.time()
+    step_ref.train_step(m, opt, video, audio, sl, sel, CFG2["hc"])
+    dt = time.time() - t0
+    return dict(value=batch / dt, unit="clips/s", cores=cores, kind="port",
+                sample=f"cfg2-shaped full step (fwd+loss+bwd+SGD) at batch {batch}, 1 warm-up + 1 timed step, "
+                       f"torch {torch.__version__} CPU fp32, {dt:.2f} s/step")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from selavi_amd import model as smodel, optim, train
+    B, hc, K = a.batch, CFG2["hc"], CFG2["K"]
+    torch.manual_seed(31)            # opt.py:152
+    m = smodel.load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', use_mlp=True, num_classes=K,
+                          pretrained=False, norm_feat=False, use_max_pool=False, headcount=hc).to(dev)
+    m.train()
+    net = m
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[local])      # main.py:156-160
+    opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)       # main.py:132-137
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    video = torch.randn(B, 3, CFG2["T"], CFG2["S"], CFG2["S"], device=dev, generator=g)
+    audio = torch.randn(B, 1, CFG2["F"], CFG2["Tp"], device=dev, generator=g)
+    selflabels = torch.randint(0, K, (CFG2["N"], hc), device=dev, generator=g)
+    selected = torch.randint(0, CFG2["N"], (B,), device=dev, generator=g)
+
+    def step():
+        return train.train_step(net, opt, video, audio, selflabels, selected, hc)
+
+    for _ in range(a.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss_v = float(loss.item())
+    ms_step = dt / a.steps * 1e3
+    clips = world * B * a.steps / dt
+
+    hot = hot_conv_roofline(B, dev)
+    sk = None if a.no_sk else sk_bench(rank, world, dev)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.cpu_batch)
+
+    if rank == 0:
+        step_tflops = 3 * FWD_GFLOP_PER_CLIP * B / ms_step          # per GPU, algorithmic
+        out = {
+            "metric": "clips/sec (video+audio fwd/bwd + loss + SGD; SK timed separately)",
+            "value": clips, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: R(2+1)D-18 + ResNet-9, per-GPU bs=%d, 16x112x112 video, 1x129x100 "
+                                   "log-mel, K=309, headcount=10, SGD(m=0.9, wd=1e-5), fp32" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "sync_bn": world > 1, "loss_last_step": loss_v},
+            "roofline": {"bound": "mfma", "achieved": hot["tflops"], "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
+                         "frac": hot["tflops"] / PEAK_FP32_MFMA_TF, "traffic": None,
+                         "kernel": hot["kernel"], "ms_per_launch": hot["ms"], "flop_per_launch": hot["flop"]},
+            "step_roofline": {"bound": "mfma", "achieved": step_tflops, "peak": PEAK_FP32_MFMA_TF,
+                              "unit": "TFLOP/s per GPU (algorithmic 3 x %.2f GFLOP/clip)" % FWD_GFLOP_PER_CLIP,
+                              "frac": step_tflops / PEAK_FP32_MFMA_TF},
+            "sk": sk,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,7 +99,8 @@ int slv_sk_labels(const double* P, int64_t N_local, int K, const double* beta, v
  *                              as A1*mask*g + A2 + A3*x with mask = relu ? (s*x + h > 0) : 1
  *                              (BN backward folded into per-channel coefficients, slv_bn_bwd_finalize).
  */
-int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out /* host, [C*taps][2] */);
+int32_t slv_conv_table_len(const int32_t* geom, int dgrad); /* int2 entries incl. invalid padding */
+int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out /* host, [table_len][2] */);
 int32_t slv_conv_fwd_nblk(const int32_t* geom);
 int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const int32_t* tab,
                  const float* in_scale_shift /* nullable */, int in_relu, float* y,

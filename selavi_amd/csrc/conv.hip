@@ -94,12 +94,25 @@ using namespace slv;
 
 extern "C" {
 
-// table entry k=(c,tap): {offset, dt | dh<<4 | dw<<8 | c<<12}
+// number of int2 entries of the padded table: C*taps rounded up to 16, plus 16 invalid entries
+int32_t slv_conv_table_len(const int32_t* geom, int dgrad) {
+  Geom g;
+  if (read_geom(geom, g) != 0) return -1;
+  const int n = (dgrad ? g.Cout : g.Cin) * g.kt * g.kh * g.kw;
+  return ((n + 15) / 16) * 16 + 16;
+}
+
+// table entry k=(c,tap): {offset, dt | dh<<4 | dw<<8 | c<<12}; pad entries: {0, -1} (y < 0 = invalid)
 int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out) {
   Geom g;
   SLV_CHECK_ARG(read_geom(geom, g) == 0 && tab_host_out, "invalid geometry");
   const int taps = g.kt * g.kh * g.kw;
   const int C = dgrad ? g.Cout : g.Cin;
+  const int total = ((C * taps + 15) / 16) * 16 + 16;
+  for (int k = C * taps; k < total; ++k) {
+    tab_host_out[2 * k] = 0;
+    tab_host_out[2 * k + 1] = INT32_MIN;  // sign bit = invalid; channel field stays 0 (in range)
+  }
   const int THWi = g.Ti * g.Hi * g.Wi, HWi = g.Hi * g.Wi, Pout = g.To * g.Ho * g.Wo;
   for (int c = 0; c < C; ++c)
     for (int dt = 0; dt < g.kt; ++dt)
@@ -191,6 +204,10 @@ int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_out, con
   a.tab = (const int2*)tab;
   a.M = g.Cout; a.Kd = 0; a.Ntot = (long long)g.Cin * taps; a.ldc = g.Cin * taps;
   a.Ptot = (long long)g.Bn * g.To * g.Ho * g.Wo;
+  SLV_CHECK_ARG(a.Ptot < (1LL << 31), "more than 2^31 output positions");
+  a.dPout = make_fastdiv((unsigned)(g.To * g.Ho * g.Wo));
+  a.dHoWo = make_fastdiv((unsigned)(g.Ho * g.Wo));
+  a.dWo = make_fastdiv((unsigned)g.Wo);
   const int mt = pick_mt(a.M);
   const int nt = mt >= 15 ? 1 : 2;
   const int splits = wgrad_splits(g, mt, nt);

@@ -18,9 +18,15 @@
 // tile is chosen per layer from {64,128,144,240} so the odd channel counts of R(2+1)D-18
 // (45/144/230/460/921) waste < 5 % of the MFMA work.  LDS tiles are [rows][16+2] for K-contiguous
 // operands and [16][BN+16] for position-contiguous operands; both give conflict-free ds_read_b32
-// fragment reads (bank = (a/4) % 32 inside each 32-lane half).  Global->LDS is register staged and
-// double buffered: loads for chunk c+1 are issued before the MFMAs of chunk c, one barrier per chunk.
+// fragment reads (bank = (a/4) % 32 inside each 32-lane half).
+//
+// Pipeline: global->LDS is register staged and double buffered.  Loads of chunk c+1 are issued
+// (unconditionally, from clamped addresses -- no divergent branches) before the MFMAs of chunk c;
+// validity masking and the BN prologue math run when the registers are written to LDS after those
+// MFMAs, so the global latency hides under the matrix pipe.  One barrier per chunk.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace slv {
@@ -30,6 +36,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2, MODE_GEMM = 3 };
 enum { PRO_NONE = 0, PRO_ACT = 1, PRO_BWD = 2 };
 
+// exact unsigned division by a runtime constant (Granlund-Montgomery round-up form)
+struct FastDiv {
+  unsigned m, s1, s2, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s1 = l > 1 ? 1 : l;
+  f.s2 = l > 0 ? l - 1 : 0;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 struct IgemmArgs {
   const float* A;    // FWD/DGRAD/GEMM: dense [M][Kd] ; WGRAD: gradient tensor on the conv-output side
   const float* A2;   // WGRAD + PRO_BWD: raw conv output x (same shape as A)
@@ -37,7 +62,8 @@ struct IgemmArgs {
   const float* B2;   // DGRAD + PRO_BWD: raw conv output x
   const float* pa;   // per-channel prologue params of A (WGRAD): [5][Cout] = s, h, A1, A2, A3
   const float* pb;   // per-channel prologue params of B: PRO_ACT [2][C] = s, h ; PRO_BWD [5][C]
-  const int2* tab;   // FWD/WGRAD: (ci,tap) table ; DGRAD: (co,tap) table  -> {offset, dt|dh<<4|dw<<8|chan<<12}
+  const int2* tab;   // (c,tap) table, padded with invalid entries (y < 0) to a multiple of 16 (+16):
+                     //   {offset, dt | dh<<4 | dw<<8 | c<<12}
   float* C;          // output
   const float* E;    // optional epilogue addend, same shape as C (DGRAD residual / accumulate)
   const float* bias; // GEMM: optional per-column bias
@@ -49,23 +75,25 @@ struct IgemmArgs {
   int Bn, Cin, Ti, Hi, Wi, Cout, To, Ho, Wo;
   int st, sh, sw, pt, ph, pw;
   int a_pro, b_pro, a_relu, b_relu;
-  int chunks_per_split;  // WGRAD: 16-position chunks per grid.y slice
+  int chunks_per_split;  // WGRAD: 16-position chunks per K-slice
   long long Ptot;        // WGRAD: Bn*To*Ho*Wo
   int ldc;               // WGRAD/GEMM: leading dimension of C
+  FastDiv dPout, dHoWo, dWo;  // WGRAD position decode
 };
 
 __device__ __forceinline__ float apply_act(float x, float s, float h, int relu) {
-  float v = x * s + h;
+  const float v = x * s + h;
   return relu ? fmaxf(v, 0.f) : v;
 }
 __device__ __forceinline__ float apply_bwd(float g, float x, float s, float h, float a1, float a2,
                                            float a3, int relu) {
-  if (relu) g = (x * s + h > 0.f) ? g : 0.f;
-  return a1 * g + a2 + a3 * x;
+  const float gm = (relu && !(x * s + h > 0.f)) ? 0.f : g;
+  return a1 * gm + a2 + a3 * x;
 }
 
 template <int MODE, int MT, int NT>
-__global__ __launch_bounds__(256, (MT >= 15 ? 2 : 3)) void igemm_kernel(const IgemmArgs g) {
+__global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD || (MODE == MODE_DGRAD && NT == 2)) ? 2 : 3))
+void igemm_kernel(const IgemmArgs g) {
   constexpr int BM = MT * 16, BN = NT * 64;
   constexpr int AS = 18;
   constexpr bool BKF = (MODE == MODE_WGRAD || MODE == MODE_GEMM);  // B tile K-contiguous?
@@ -73,20 +101,24 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : 3)) void igemm_kernel(const Ig
   constexpr int A_ELEMS = BM * AS;
   constexpr int B_ELEMS = BKF ? BN * 18 : 16 * BS;
   constexpr int BROWS = BN / 16;  // B staging registers per thread (both layouts)
-  __shared__ float smem[2 * (A_ELEMS + B_ELEMS)];
+  constexpr int P_ELEMS = (MODE == MODE_WGRAD) ? (5 * BM + 2 * BN) : 0;
+  __shared__ float smem[2 * (A_ELEMS + B_ELEMS) + P_ELEMS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // ---- XCD-aware block remap (bijective): the nblkM blocks of one column tile share an L2
-  int mblk, nblk;
+  // ---- XCD-aware block remap (bijective): the tiles that share operands share an XCD's L2
+  int mblk, nblk, split;
   {
     const int nb = gridDim.x, id = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = id & 7, loc = id >> 3;
     const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    mblk = nid % g.nblkM;
-    nblk = nid / g.nblkM;
+    const int per = g.nblkM * g.nblkN;
+    split = nid / per;  // WGRAD: K-slice
+    const int rem_ = nid - split * per;
+    mblk = rem_ % g.nblkM;
+    nblk = rem_ / g.nblkM;
   }
   const int m0 = mblk * BM;
   const long long n0 = (long long)nblk * BN;
@@ -101,9 +133,8 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : 3)) void igemm_kernel(const Ig
   // position-contiguous B loader (FWD/DGRAD): one column per thread, BROWS k's
   int nl = 0, kg = 0;
   bool nvalid = false;
-  int pb_, t0 = 0, h0 = 0, w0 = 0;
+  int t0 = 0, h0 = 0, w0 = 0;
   long long bbase = 0;
-  (void)pb_;
   if constexpr (MODE == MODE_FWD || MODE == MODE_DGRAD) {
     nl = tid % BN;
     kg = __builtin_amdgcn_readfirstlane(tid / BN);
@@ -132,157 +163,198 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : 3)) void igemm_kernel(const Ig
       bbase = (long long)b * g.Cout * Pout;
     }
   }
-  // WGRAD position walker: this thread's reduction position p = pcur + a_kk
-  int wb = 0, wto = 0, who = 0, wwo = 0;
-  long long wp = 0, wp_end = 0;
+  // WGRAD: this thread's reduction position p = chunk*16 + a_kk
+  unsigned wp = 0;
   int nchunks;
   if constexpr (MODE == MODE_WGRAD) {
-    const long long c0 = (long long)blockIdx.y * g.chunks_per_split;
+    const long long c0 = (long long)split * g.chunks_per_split;
     const long long call = (g.Ptot + 15) / 16;
     long long c1 = c0 + g.chunks_per_split;
     if (c1 > call) c1 = call;
     nchunks = (int)(c1 > c0 ? c1 - c0 : 0);
-    wp = c0 * 16 + a_kk;
-    wp_end = g.Ptot;
-    const long long pp = wp < wp_end ? wp : 0;
-    wb = (int)(pp / Pout);
-    int rem = (int)(pp - (long long)wb * Pout);
-    wto = rem / HoWo;
-    rem -= wto * HoWo;
-    who = rem / g.Wo;
-    wwo = rem - who * g.Wo;
+    wp = (unsigned)(c0 * 16 + a_kk);
   } else {
     nchunks = (g.Kd + 15) / 16;
   }
 
-  float ra[MT];
-  float rb[BROWS];
+  // staging registers hold RAW loaded values; masking + prologue math run in store_chunk
+  float ra[MT], ra2[MT];
+  float rb[BROWS], rb2[BROWS];
+  unsigned okA = 0, okB = 0;  // per-element validity bits
 
-  // ---------------------------------------------------------------- global -> registers
-  auto load_chunk = [&](int c) {
+  (void)ra2; (void)rb2; (void)okA; (void)okB;
+
+  // WGRAD: loop-invariant table entries of this thread's B rows and per-channel params in LDS
+  int2 wte[BROWS];
+  (void)wte;
+  float* pAs = smem + 2 * (A_ELEMS + B_ELEMS);  // [5][BM]
+  float* pBs = pAs + 5 * BM;                    // [2][BN]
+  if constexpr (MODE == MODE_WGRAD) {
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+      const long long n = n0 + a_r + 16 * i;
+      wte[i] = g.tab[n < g.Ntot ? n : g.Ntot];  // entry Ntot is an invalid (y < 0) pad entry
+    }
+    for (int i = tid; i < 5 * BM; i += 256) {
+      const int which = i / BM, m = i - which * BM;
+      pAs[i] = (g.a_pro == PRO_BWD && m < mrem) ? g.pa[which * g.Cout + m0 + m] : 0.f;
+    }
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, nn = i - which * BN;
+      const long long n = n0 + nn;
+      float v = 0.f;
+      if (g.b_pro == PRO_ACT && n < g.Ntot) v = g.pb[which * g.Cin + ((g.tab[n].y >> 12) & 0x7FFFF)];
+      pBs[i] = v;
+    }
+  }
+
+  // ---------------------------------------------------------------- global -> registers (raw, branch-free)
+  // NB: every lambda is force-inlined -- an out-of-line lambda captures the register arrays by
+  // reference and drags the accumulators into scratch memory (and turns global loads into flat ones).
+  auto load_chunk = [&](int c) __attribute__((always_inline)) {
     const int k0 = c * 16;
     if constexpr (MODE != MODE_WGRAD) {
       // A: dense [M][Kd]
       const int k = k0 + a_kk;
+      const bool kok = k < g.Kd;
+      okA = 0;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int m = a_r + 16 * i;
-        ra[i] = (m < mrem && k < g.Kd) ? g.A[(size_t)(m0 + m) * g.Kd + k] : 0.f;
+        const bool ok = kok && m < mrem;
+        ra[i] = g.A[ok ? (size_t)(m0 + m) * g.Kd + k : 0];
+        okA |= (ok ? 1u : 0u) << i;
       }
     }
     if constexpr (MODE == MODE_GEMM) {
       const int k = k0 + a_kk;
+      okB = 0;
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
         const long long n = n0 + a_r + 16 * i;
-        rb[i] = (n < g.Ntot && k < g.Kd) ? g.B[(size_t)n * g.Kd + k] : 0.f;
+        const bool ok = n < g.Ntot && k < g.Kd;
+        rb[i] = g.B[ok ? (size_t)n * g.Kd + k : 0];
+        okB |= (ok ? 1u : 0u) << i;
       }
     }
     if constexpr (MODE == MODE_FWD) {
+      okB = 0;
 #pragma unroll
       for (int q = 0; q < BROWS; ++q) {
-        const int k = k0 + kg * BROWS + q;  // wave-uniform
-        float v = 0.f;
-        if (k < g.Kd) {
-          const int2 e = g.tab[k];
-          const int dt = e.y & 15, dh = (e.y >> 4) & 15, dw = (e.y >> 8) & 15, ch = e.y >> 12;
-          const bool ok = nvalid && (unsigned)(t0 + dt) < (unsigned)g.Ti &&
-                          (unsigned)(h0 + dh) < (unsigned)g.Hi && (unsigned)(w0 + dw) < (unsigned)g.Wi;
-          if (ok) {
-            v = g.B[bbase + e.x];
-            if (g.b_pro == PRO_ACT) v = apply_act(v, g.pb[ch], g.pb[g.Cin + ch], g.b_relu);
-          }
-        }
-        rb[q] = v;
+        const int k = k0 + kg * BROWS + q;  // wave-uniform; table is padded, no bound check needed
+        const int2 e = g.tab[k];
+        const int dt = e.y & 15, dh = (e.y >> 4) & 15, dw = (e.y >> 8) & 15, ch = (e.y >> 12) & 0x7FFFF;
+        const bool ok = nvalid && e.y >= 0 && (unsigned)(t0 + dt) < (unsigned)g.Ti &&
+                        (unsigned)(h0 + dh) < (unsigned)g.Hi && (unsigned)(w0 + dw) < (unsigned)g.Wi;
+        rb[q] = g.B[ok ? bbase + e.x : 0];
+        okB |= (ok ? 1u : 0u) << q;
+        (void)ch;
       }
     }
     if constexpr (MODE == MODE_DGRAD) {
       const int mt_ = g.st - 1, mh_ = g.sh - 1, mw_ = g.sw - 1;  // strides are 1 or 2
       const int lt_ = g.st >> 1, lh_ = g.sh >> 1, lw_ = g.sw >> 1;
+      okB = 0;
 #pragma unroll
       for (int q = 0; q < BROWS; ++q) {
         const int k = k0 + kg * BROWS + q;
-        float v = 0.f;
-        if (k < g.Kd) {
-          const int2 e = g.tab[k];
-          const int dt = e.y & 15, dh = (e.y >> 4) & 15, dw = (e.y >> 8) & 15, ch = e.y >> 12;
-          const int tt = t0 - dt, hh = h0 - dh, ww = w0 - dw;
-          const int to = tt >> lt_, ho = hh >> lh_, wo = ww >> lw_;
-          const bool ok = nvalid && tt >= 0 && hh >= 0 && ww >= 0 && ((tt & mt_) | (hh & mh_) | (ww & mw_)) == 0 &&
-                          to < g.To && ho < g.Ho && wo < g.Wo;
-          if (ok) {
-            const long long ad = bbase + e.x + (long long)to * HoWo + ho * g.Wo + wo;
-            v = g.B[ad];
-            if (g.b_pro == PRO_BWD) {
-              const int C_ = g.Cout;
-              v = apply_bwd(v, g.B2[ad], g.pb[ch], g.pb[C_ + ch], g.pb[2 * C_ + ch], g.pb[3 * C_ + ch],
-                            g.pb[4 * C_ + ch], g.b_relu);
-            }
-          }
-        }
-        rb[q] = v;
+        const int2 e = g.tab[k];
+        const int dt = e.y & 15, dh = (e.y >> 4) & 15, dw = (e.y >> 8) & 15, ch = (e.y >> 12) & 0x7FFFF;
+        const int tt = t0 - dt, hh = h0 - dh, ww = w0 - dw;
+        const int to = tt >> lt_, ho = hh >> lh_, wo = ww >> lw_;
+        const bool ok = nvalid && e.y >= 0 && (tt | hh | ww) >= 0 && ((tt & mt_) | (hh & mh_) | (ww & mw_)) == 0 &&
+                        to < g.To && ho < g.Ho && wo < g.Wo;
+        const long long ad = ok ? bbase + e.x + (long long)to * HoWo + ho * g.Wo + wo : 0;
+        rb[q] = g.B[ad];
+        if (g.b_pro == PRO_BWD) rb2[q] = g.B2[ad];
+        (void)ch;
+        okB |= (ok ? 1u : 0u) << q;
       }
     }
     if constexpr (MODE == MODE_WGRAD) {
-      const bool pok = wp < wp_end;
-      const int rem = wto * HoWo + who * g.Wo + wwo;
+      const unsigned p = wp + (unsigned)c * 16u;
+      const bool pok = (long long)p < g.Ptot;
+      const unsigned pp = pok ? p : 0u;
+      const unsigned b = fdiv(pp, g.dPout);
+      const unsigned rem = pp - b * (unsigned)Pout;
+      const unsigned to = fdiv(rem, g.dHoWo);
+      const unsigned r2 = rem - to * (unsigned)HoWo;
+      const unsigned ho = fdiv(r2, g.dWo);
+      const unsigned wo = r2 - ho * (unsigned)g.Wo;
+      okA = 0;
+      okB = 0;
       // A[m][p] = dXout[b][m][p]
+      const size_t abase = (size_t)b * g.Cout * Pout + rem;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int m = a_r + 16 * i;
-        float v = 0.f;
-        if (pok && m < mrem) {
-          const int ch = m0 + m;
-          const size_t ad = ((size_t)wb * g.Cout + ch) * Pout + rem;
-          v = g.A[ad];
-          if (g.a_pro == PRO_BWD) {
-            const int C_ = g.Cout;
-            v = apply_bwd(v, g.A2[ad], g.pa[ch], g.pa[C_ + ch], g.pa[2 * C_ + ch], g.pa[3 * C_ + ch],
-                          g.pa[4 * C_ + ch], g.a_relu);
-          }
-        }
-        ra[i] = v;
+        const bool ok = pok && m < mrem;
+        const size_t ad = ok ? abase + (size_t)(m0 + m) * Pout : 0;
+        ra[i] = g.A[ad];
+        if (g.a_pro == PRO_BWD) ra2[i] = g.A2[ad];
+        okA |= (ok ? 1u : 0u) << i;
       }
       // B[n][p] = act(X)[b][ci][in_pos(p, tap)]
-      const int ti0 = wto * g.st - g.pt, hi0 = who * g.sh - g.ph, wi0 = wwo * g.sw - g.pw;
-      const long long xb = (long long)wb * g.Cin * THWi + (long long)ti0 * HWi + hi0 * g.Wi + wi0;
+      const int ti0 = (int)to * g.st - g.pt, hi0 = (int)ho * g.sh - g.ph, wi0 = (int)wo * g.sw - g.pw;
+      const long long xb = (long long)b * g.Cin * THWi + (long long)ti0 * HWi + hi0 * g.Wi + wi0;
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
-        const long long n = n0 + a_r + 16 * i;
-        float v = 0.f;
-        if (pok && n < g.Ntot) {
-          const int2 e = g.tab[n];
-          const int dt = e.y & 15, dh = (e.y >> 4) & 15, dw = (e.y >> 8) & 15, ch = e.y >> 12;
-          const bool ok = (unsigned)(ti0 + dt) < (unsigned)g.Ti && (unsigned)(hi0 + dh) < (unsigned)g.Hi &&
-                          (unsigned)(wi0 + dw) < (unsigned)g.Wi;
-          if (ok) {
-            v = g.B[xb + e.x];
-            if (g.b_pro == PRO_ACT) v = apply_act(v, g.pb[ch], g.pb[g.Cin + ch], g.b_relu);
-          }
-        }
-        rb[i] = v;
+        const int2 e = wte[i];
+        const int dt = e.y & 15, dh = (e.y >> 4) & 15, dw = (e.y >> 8) & 15;
+        const bool ok = pok && e.y >= 0 && (unsigned)(ti0 + dt) < (unsigned)g.Ti &&
+                        (unsigned)(hi0 + dh) < (unsigned)g.Hi && (unsigned)(wi0 + dw) < (unsigned)g.Wi;
+        rb[i] = g.B[ok ? xb + e.x : 0];
+        okB |= (ok ? 1u : 0u) << i;
       }
-      // advance the walker by one chunk (16 positions)
-      wp += 16;
-      wwo += 16;
-      while (wwo >= g.Wo) { wwo -= g.Wo; ++who; }
-      while (who >= g.Ho) { who -= g.Ho; ++wto; }
-      while (wto >= g.To) { wto -= g.To; ++wb; }
     }
   };
 
-  // ---------------------------------------------------------------- registers -> LDS
-  auto store_chunk = [&](int buf) {
+  // ---------------------------------------------------------------- registers -> (mask, prologue) -> LDS
+  auto store_chunk = [&](int buf, int c) __attribute__((always_inline)) {
+    (void)c;
     float* As = smem + buf * (A_ELEMS + B_ELEMS);
     float* Bs = As + A_ELEMS;
+    if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) As[(a_r + 16 * i) * AS + a_kk] = ra[i];
-    if constexpr (BKF) {
+      for (int i = 0; i < MT; ++i) {
+        const int m = a_r + 16 * i;
+        float v = ra[i];
+        if (g.a_pro == PRO_BWD)
+          v = apply_bwd(v, ra2[i], pAs[m], pAs[BM + m], pAs[2 * BM + m], pAs[3 * BM + m], pAs[4 * BM + m], g.a_relu);
+        As[m * AS + a_kk] = ((okA >> i) & 1u) ? v : 0.f;
+      }
 #pragma unroll
-      for (int i = 0; i < BROWS; ++i) Bs[(a_r + 16 * i) * 18 + a_kk] = rb[i];
+      for (int i = 0; i < BROWS; ++i) {
+        const int nn = a_r + 16 * i;
+        float v = rb[i];
+        if (g.b_pro == PRO_ACT) v = apply_act(v, pBs[nn], pBs[BN + nn], g.b_relu);
+        Bs[nn * 18 + a_kk] = ((okB >> i) & 1u) ? v : 0.f;
+      }
     } else {
 #pragma unroll
-      for (int q = 0; q < BROWS; ++q) Bs[(kg * BROWS + q) * BS + nl] = rb[q];
+      for (int i = 0; i < MT; ++i) As[(a_r + 16 * i) * AS + a_kk] = ((okA >> i) & 1u) ? ra[i] : 0.f;
+      if constexpr (MODE == MODE_GEMM) {
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) Bs[(a_r + 16 * i) * 18 + a_kk] = ((okB >> i) & 1u) ? rb[i] : 0.f;
+      } else {
+        // per-k channel params are wave-uniform: short-lived scalar loads here (keeping them live
+        // across the MFMA phase costs 16-40 registers and spills)
+#pragma unroll
+        for (int q = 0; q < BROWS; ++q) {
+          float v = rb[q];
+          if (g.b_pro != PRO_NONE) {
+            const int ch = (g.tab[c * 16 + kg * BROWS + q].y >> 12) & 0x7FFFF;
+            if constexpr (MODE == MODE_FWD) {
+              v = apply_act(v, g.pb[ch], g.pb[g.Cin + ch], g.b_relu);
+            } else {
+              const int C_ = g.Cout;
+              v = apply_bwd(v, rb2[q], g.pb[ch], g.pb[C_ + ch], g.pb[2 * C_ + ch], g.pb[3 * C_ + ch],
+                            g.pb[4 * C_ + ch], g.b_relu);
+            }
+          }
+          Bs[(kg * BROWS + q) * BS + nl] = ((okB >> q) & 1u) ? v : 0.f;
+        }
+      }
     }
   };
 
@@ -293,8 +365,10 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : 3)) void igemm_kernel(const Ig
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fi = lane & 15, fk = lane >> 4;
+  const int mtv = __builtin_amdgcn_readfirstlane((mrem + 15) >> 4);  // valid 16-row tiles (wave-uniform)
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, auto full_tag) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_tag)::value;
     const float* As = smem + buf * (A_ELEMS + B_ELEMS);
     const float* Bs = As + A_ELEMS;
 #pragma unroll
@@ -309,7 +383,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : 3)) void igemm_kernel(const Ig
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        if (i * 16 < mrem) {  // wave-uniform: skip row tiles beyond M
+        if (FULL || i < mtv) {  // wave-uniform: skip row tiles beyond M in ragged blocks
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
@@ -319,17 +393,21 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : 3)) void igemm_kernel(const Ig
   };
 
   // ---------------------------------------------------------------- main loop
-  if (nchunks > 0) {
+  auto main_loop = [&](auto full_tag) __attribute__((always_inline)) {
     load_chunk(0);
-    store_chunk(0);
+    store_chunk(0, 0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
       const bool more = c + 1 < nchunks;
       if (more) load_chunk(c + 1);
-      compute(c & 1);
-      if (more) store_chunk((c + 1) & 1);
+      compute(c & 1, full_tag);
+      if (more) store_chunk((c + 1) & 1, c + 1);
       __syncthreads();
     }
+  };
+  if (nchunks > 0) {
+    if (mtv >= MT) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -348,7 +426,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : 3)) void igemm_kernel(const Ig
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      if (i * 16 < mrem) {
+      if (i < mtv) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = i * 16 + fk * 4 + r;
@@ -406,10 +484,10 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : 3)) void igemm_kernel(const Ig
     }
   } else {
     // WGRAD / GEMM: C[(split)][m][n], row-major with leading dimension ldc
-    float* Cout_ = g.C + (MODE == MODE_WGRAD ? (size_t)blockIdx.y * g.M * g.ldc : 0);
+    float* Cout_ = g.C + (MODE == MODE_WGRAD ? (size_t)split * g.M * g.ldc : 0);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      if (i * 16 < mrem) {
+      if (i < mtv) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = i * 16 + fk * 4 + r;
@@ -434,7 +512,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : 3)) void igemm_kernel(const Ig
 
 template <int MODE, int MT, int NT>
 inline void launch_igemm(const IgemmArgs& a, int splits, hipStream_t st) {
-  dim3 grid(a.nblkM * a.nblkN, splits, 1);
+  dim3 grid(a.nblkM * a.nblkN * splits, 1, 1);
   hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT>), grid, dim3(256), 0, st, a);
 }
 

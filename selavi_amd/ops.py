@@ -33,9 +33,9 @@ class ConvPlan:
                              dtype=np.int32)
         self.gp = self.geom.ctypes.data
         self.device = device
-        tf = np.empty((Cin * self.taps, 2), dtype=np.int32)
+        tf = np.empty((C.slv_conv_table_len(self.gp, 0), 2), dtype=np.int32)
         C.slv_conv_table(self.gp, 0, tf.ctypes.data)
-        td = np.empty((Cout * self.taps, 2), dtype=np.int32)
+        td = np.empty((C.slv_conv_table_len(self.gp, 1), 2), dtype=np.int32)
         C.slv_conv_table(self.gp, 1, td.ctypes.data)
         self.tab_fwd = torch.from_numpy(tf).to(device)
         self.tab_dgrad = torch.from_numpy(td).to(device)

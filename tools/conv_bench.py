@@ -1,0 +1,52 @@
+"""Per-layer timing of the implicit-GEMM conv ops at cfg2 shapes (B=16): TFLOP/s of fwd / dgrad / wgrad
+with the fused BN prologues the engine uses.  Usage: python tools/conv_bench.py [layer-substring] [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from selavi_amd import ops
+
+B = 16
+LAYERS = [  # name, Cin, T, H, W, Cout, k, stride, pad
+    ("stem.0", 3, 16, 112, 112, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
+    ("stem.3", 45, 16, 56, 56, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("l1.spatial", 64, 16, 56, 56, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("l1.temporal", 144, 16, 56, 56, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("l2.0.sp_s2", 64, 16, 56, 56, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("l2.0.tm_s2", 230, 16, 28, 28, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0)),
+    ("l2.1.spatial", 128, 8, 28, 28, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("l2.1.temporal", 288, 8, 28, 28, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("l3.1.spatial", 256, 4, 14, 14, 576, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("l3.1.temporal", 576, 4, 14, 14, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("l4.0.sp_s2", 256, 4, 14, 14, 921, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("l4.1.spatial", 512, 2, 7, 7, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("l4.1.temporal", 1152, 2, 7, 7, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+]
+sel = sys.argv[1] if len(sys.argv) > 1 else ""
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda")
+g = torch.Generator(device=dev).manual_seed(0)
+print(f"{'layer':14s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF':>6s} | {'dgrad ms':>8s} {'TF':>6s} | {'wgrad ms':>8s} {'TF':>6s}")
+for name, Cin, T, H, W, Cout, k, st, pd in LAYERS:
+    if sel not in name:
+        continue
+    plan = ops.ConvPlan.get((B, Cin, T, H, W), Cout, k, st, pd, dev)
+    x = torch.randn(B, Cin, T, H, W, device=dev, generator=g)
+    w = torch.randn(Cout, Cin, *k, device=dev, generator=g) * 0.05
+    ss = torch.stack([torch.rand(Cin, device=dev, generator=g) + 0.5, torch.randn(Cin, device=dev, generator=g) * 0.1])
+    y, _, _ = ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True)
+    dy = torch.randn_like(y)
+    b5 = torch.randn(5, Cout, device=dev, generator=g) * 0.1
+    wt = ops.conv_wt_transform(plan, w)
+    flop = 2.0 * y.numel() * Cin * k[0] * k[1] * k[2]
+    def timeit(fn):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    tf = timeit(lambda: ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True))
+    td = timeit(lambda: ops.conv_dgrad(plan, dy, wt, x_out=y, bwd5=b5, relu=True))
+    tw = timeit(lambda: ops.conv_wgrad(plan, dy, x, x_out=y, bwd5=b5, a_relu=True, in_ss=ss, in_relu=True))
+    print(f"{name:14s} {flop/1e9:8.1f} | {tf:8.3f} {flop/tf/1e9:6.1f} | {td:8.3f} {flop/td/1e9:6.1f} | {tw:8.3f} {flop/tw/1e9:6.1f}")
