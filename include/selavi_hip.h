@@ -99,14 +99,17 @@ int slv_sk_labels(const double* P, int64_t N_local, int K, const double* beta, v
  *                              as A1*mask*g + A2 + A3*x with mask = relu ? (s*x + h > 0) : 1
  *                              (BN backward folded into per-channel coefficients, slv_bn_bwd_finalize).
  */
-int32_t slv_conv_table_len(const int32_t* geom, int dgrad); /* int2 entries incl. invalid padding */
-int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out /* host, [table_len][2] */);
+/* gather tables (host side, upload once per layer): dgrad == 0 -> forward / weight-gradient table,
+ * dgrad == 1 -> one table block per stride-parity class of the backward-data conv.  _len = int32 words. */
+int32_t slv_conv_table_len(const int32_t* geom, int dgrad);
+int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out /* host, table_len words */);
 int32_t slv_conv_fwd_nblk(const int32_t* geom);
 int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const int32_t* tab,
                  const float* in_scale_shift /* nullable */, int in_relu, float* y,
                  float* stat_sum /* nullable */, float* stat_sq, slv_stream_t stream);
-/* wt[ci][co][tap] = w[co][ci][tap]  (the dgrad kernel reads its weight matrix K-contiguous) */
-int slv_conv_wt_transform(const float* w, float* wt, int Cout, int Cin, int taps, slv_stream_t stream);
+/* backward-data weights: per stride-parity class c a K-contiguous matrix wt_c[ci][co*ntaps_c + j] =
+ * w[co][ci][tap_j], classes concatenated (same element count as w) */
+int slv_conv_wt_transform(const int32_t* geom, const float* w, float* wt, slv_stream_t stream);
 /* dx = conv_transpose(dXout) (+ addend);  dXout = bwd5 ? fused(dy, x_out) : dy.  tab = dgrad table */
 int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* x_out /* nullable */,
                    const float* wt, const int32_t* tab, const float* bwd5 /* nullable */, int relu,

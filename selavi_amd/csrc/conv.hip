@@ -15,22 +15,128 @@ static int read_geom(const int32_t* p, Geom& g) {
   if (!p) return -1;
   memcpy(&g, p, sizeof(Geom));
   if (g.Bn <= 0 || g.Cin <= 0 || g.Cout <= 0 || g.Ti <= 0 || g.Hi <= 0 || g.Wi <= 0) return -1;
-  if (g.kt <= 0 || g.kh <= 0 || g.kw <= 0 || g.kt > 15 || g.kh > 15 || g.kw > 15) return -1;
+  if (g.kt <= 0 || g.kh <= 0 || g.kw <= 0 || g.kt * g.kh * g.kw > 63) return -1;
+  if (g.kt > 15 || g.kh > 15 || g.kw > 15 || g.pt > 15 || g.ph > 15 || g.pw > 15) return -1;
   if ((g.st != 1 && g.st != 2) || (g.sh != 1 && g.sh != 2) || (g.sw != 1 && g.sw != 2)) return -1;
   const int To = (g.Ti + 2 * g.pt - g.kt) / g.st + 1, Ho = (g.Hi + 2 * g.ph - g.kh) / g.sh + 1,
             Wo = (g.Wi + 2 * g.pw - g.kw) / g.sw + 1;
   if (To != g.To || Ho != g.Ho || Wo != g.Wo || To <= 0 || Ho <= 0 || Wo <= 0) return -1;
-  if ((long long)g.Cin * g.Ti * g.Hi * g.Wi >= (1LL << 31) || (long long)g.Cout * g.To * g.Ho * g.Wo >= (1LL << 31))
-    return -1;  // per-sample offsets are 32-bit in the tables
-  if (g.Cin >= (1 << 19) || g.Cout >= (1 << 19)) return -1;
+  // 32-bit byte offsets inside the buffer descriptors
+  if ((long long)g.Bn * g.Cin * g.Ti * g.Hi * g.Wi * 4 >= 0xFFFFFFF0LL) return -1;
+  if ((long long)g.Bn * g.Cout * g.To * g.Ho * g.Wo * 4 >= 0xFFFFFFF0LL) return -1;
+  if (g.Cin >= (1 << 22) || g.Cout >= (1 << 22)) return -1;
   return 0;
 }
 
-static void fill_common(IgemmArgs& a, const Geom& g) {
-  memset(&a, 0, sizeof(a));
-  a.Bn = g.Bn; a.Cin = g.Cin; a.Ti = g.Ti; a.Hi = g.Hi; a.Wi = g.Wi;
-  a.Cout = g.Cout; a.To = g.To; a.Ho = g.Ho; a.Wo = g.Wo;
-  a.st = g.st; a.sh = g.sh; a.sw = g.sw; a.pt = g.pt; a.ph = g.ph; a.pw = g.pw;
+// One MODE_CONV launch: the forward conv, or one stride-parity class of the backward-data conv.
+struct Desc {
+  int M, C, Kd, ntaps;
+  int taps[64];            // linear tap ids (kt,kh,kw order) in this launch's k order
+  int delta[64][3];        // source-coordinate delta of each tap
+  int Q[3], mul[3], S[3];  // lattice dims, source multipliers, source dims
+  int dmul[3], dorg[3], D[3];
+  long long Ntot;
+  size_t tab_words;        // int32 words of this launch's table block
+  size_t tab_off;          // word offset inside the layer's table buffer
+  size_t wt_off;           // backward-data: float offset of this class' weight matrix
+};
+
+static int kpad(int Kd) { return ((Kd + 15) / 16) * 16 + 16; }
+
+static void finish(Desc& d, const Geom& g) {
+  d.Kd = d.C * d.ntaps;
+  d.Ntot = (long long)g.Bn * d.Q[0] * d.Q[1] * d.Q[2];
+  d.tab_words = (size_t)2 * kpad(d.Kd) + 64;
+}
+
+static Desc fwd_desc(const Geom& g) {
+  Desc d;
+  memset(&d, 0, sizeof(d));
+  d.M = g.Cout;
+  d.C = g.Cin;
+  const int k[3] = {g.kt, g.kh, g.kw}, p[3] = {g.pt, g.ph, g.pw}, s[3] = {g.st, g.sh, g.sw};
+  const int in[3] = {g.Ti, g.Hi, g.Wi}, out[3] = {g.To, g.Ho, g.Wo};
+  for (int a = 0; a < k[0]; ++a)
+    for (int b = 0; b < k[1]; ++b)
+      for (int c = 0; c < k[2]; ++c) {
+        const int j = d.ntaps++;
+        d.taps[j] = (a * k[1] + b) * k[2] + c;
+        d.delta[j][0] = a - p[0];
+        d.delta[j][1] = b - p[1];
+        d.delta[j][2] = c - p[2];
+      }
+  for (int i = 0; i < 3; ++i) {
+    d.Q[i] = out[i]; d.mul[i] = s[i]; d.S[i] = in[i];
+    d.dmul[i] = 1; d.dorg[i] = 0; d.D[i] = out[i];
+  }
+  finish(d, g);
+  return d;
+}
+
+// class index c in [0, st*sh*sw): parity (c0,c1,c2) of the conv-INPUT position
+static int dgrad_descs(const Geom& g, Desc* out8) {
+  const int k[3] = {g.kt, g.kh, g.kw}, p[3] = {g.pt, g.ph, g.pw}, s[3] = {g.st, g.sh, g.sw};
+  const int in[3] = {g.Ti, g.Hi, g.Wi}, out[3] = {g.To, g.Ho, g.Wo};
+  int n = 0;
+  size_t tab_off = 0, wt_off = 0;
+  for (int c0 = 0; c0 < s[0]; ++c0)
+    for (int c1 = 0; c1 < s[1]; ++c1)
+      for (int c2 = 0; c2 < s[2]; ++c2) {
+        const int cls[3] = {c0, c1, c2};
+        Desc d;
+        memset(&d, 0, sizeof(d));
+        d.M = g.Cin;
+        d.C = g.Cout;
+        bool empty = false;
+        for (int i = 0; i < 3; ++i) {
+          d.Q[i] = (in[i] - cls[i] + s[i] - 1) / s[i];
+          if (d.Q[i] <= 0) empty = true;
+          d.mul[i] = 1; d.S[i] = out[i];
+          d.dmul[i] = s[i]; d.dorg[i] = cls[i]; d.D[i] = in[i];
+        }
+        if (empty) continue;
+        for (int a = 0; a < k[0]; ++a)
+          for (int b = 0; b < k[1]; ++b)
+            for (int c = 0; c < k[2]; ++c) {
+              const int kk[3] = {a, b, c};
+              bool ok = true;
+              int dl[3];
+              for (int i = 0; i < 3; ++i) {
+                const int num = cls[i] + p[i] - kk[i];
+                if (((num % s[i]) + s[i]) % s[i] != 0) ok = false;
+                dl[i] = (num >= 0) ? num / s[i] : -((-num) / s[i]);
+              }
+              if (!ok) continue;
+              const int j = d.ntaps++;
+              d.taps[j] = (a * k[1] + b) * k[2] + c;
+              for (int i = 0; i < 3; ++i) d.delta[j][i] = dl[i];
+            }
+        finish(d, g);
+        d.tab_off = tab_off;
+        d.wt_off = wt_off;
+        tab_off += d.tab_words;
+        wt_off += (size_t)g.Cin * d.Kd;
+        out8[n++] = d;
+      }
+  return n;
+}
+
+static void fill_table(const Desc& d, int32_t* w) {
+  const int Sprod = d.S[0] * d.S[1] * d.S[2];
+  const int KP = kpad(d.Kd);
+  for (int c = 0; c < d.C; ++c)
+    for (int j = 0; j < d.ntaps; ++j) {
+      const int kidx = c * d.ntaps + j;
+      w[2 * kidx] = c * Sprod + d.delta[j][0] * d.S[1] * d.S[2] + d.delta[j][1] * d.S[2] + d.delta[j][2];
+      w[2 * kidx + 1] = j | (c << 8);
+    }
+  for (int kidx = d.Kd; kidx < KP; ++kidx) {
+    w[2 * kidx] = 0;
+    w[2 * kidx + 1] = 63;  // tap 63 is never valid
+  }
+  int32_t* td = w + 2 * KP;
+  for (int j = 0; j < 64; ++j)
+    td[j] = j < d.ntaps ? ((d.delta[j][0] + 64) | ((d.delta[j][1] + 64) << 8) | ((d.delta[j][2] + 64) << 16)) : 0;
 }
 
 // column tile: NT=2 (128 columns) unless that leaves most of the 256 CUs idle
@@ -46,6 +152,7 @@ static int dispatch(const IgemmArgs& a0, int mt, int nt, int splits, hipStream_t
   const int bm = mt * 16, bn = nt * 64;
   a.nblkM = (a.M + bm - 1) / bm;
   a.nblkN = (int)((a.Ntot + bn - 1) / bn);
+  if (a.nblkN == 0) return 0;
 #define SLV_CASE(MT_, NT_) \
   if (mt == MT_ && nt == NT_) { launch_igemm<MODE, MT_, NT_>(a, splits, st); return 0; }
   SLV_CASE(4, 1) SLV_CASE(4, 2) SLV_CASE(8, 1) SLV_CASE(8, 2)
@@ -54,14 +161,35 @@ static int dispatch(const IgemmArgs& a0, int mt, int nt, int splits, hipStream_t
   return -1;
 }
 
+static void conv_args(IgemmArgs& a, const Geom& g, const Desc& d, const int32_t* tab_dev) {
+  memset(&a, 0, sizeof(a));
+  a.M = d.M; a.Kd = d.Kd; a.Ntot = d.Ntot; a.Cb = d.C; a.ntaps = d.ntaps;
+  a.tab = (const int2*)(tab_dev + d.tab_off);
+  a.tapd = (const int*)(tab_dev + d.tab_off + 2 * kpad(d.Kd));
+  a.Q0 = d.Q[0]; a.Q1 = d.Q[1]; a.Q2 = d.Q[2];
+  a.mul0 = d.mul[0]; a.mul1 = d.mul[1]; a.mul2 = d.mul[2];
+  a.S0 = d.S[0]; a.S1 = d.S[1]; a.S2 = d.S[2];
+  a.sbatch = (long long)d.C * d.S[0] * d.S[1] * d.S[2];
+  a.dmul0 = d.dmul[0]; a.dmul1 = d.dmul[1]; a.dmul2 = d.dmul[2];
+  a.dorg0 = d.dorg[0]; a.dorg1 = d.dorg[1]; a.dorg2 = d.dorg[2];
+  a.D0 = d.D[0]; a.D1 = d.D[1]; a.D2 = d.D[2];
+  a.A_bytes = (unsigned)((size_t)d.M * d.Kd * 4);
+  a.B_bytes = (unsigned)((size_t)g.Bn * a.sbatch * 4);
+  a.B2_bytes = a.B_bytes;
+}
+
+struct TapMap {
+  int off[64], nt[64], j[64];
+};
+// wt[class][ci][co*nt + j] = w[co][ci][tap]
 __global__ void wt_transform_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin,
-                                    int taps) {
+                                    int taps, const TapMap tm) {
   const size_t n = (size_t)Cout * Cin * taps;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int tap = (int)(i % taps);
     const size_t r = i / taps;
     const int ci = (int)(r % Cin), co = (int)(r / Cin);
-    wt[((size_t)ci * Cout + co) * taps + tap] = w[i];
+    wt[(size_t)tm.off[tap] + ((size_t)ci * Cout + co) * tm.nt[tap] + tm.j[tap]] = w[i];
   }
 }
 
@@ -94,34 +222,28 @@ using namespace slv;
 
 extern "C" {
 
-// number of int2 entries of the padded table: C*taps rounded up to 16, plus 16 invalid entries
+// int32 words of the table buffer: dgrad == 0 -> forward/weight-gradient table, 1 -> all parity classes
 int32_t slv_conv_table_len(const int32_t* geom, int dgrad) {
   Geom g;
   if (read_geom(geom, g) != 0) return -1;
-  const int n = (dgrad ? g.Cout : g.Cin) * g.kt * g.kh * g.kw;
-  return ((n + 15) / 16) * 16 + 16;
+  if (!dgrad) return (int32_t)fwd_desc(g).tab_words;
+  Desc ds[8];
+  const int n = dgrad_descs(g, ds);
+  size_t t = 0;
+  for (int i = 0; i < n; ++i) t += ds[i].tab_words;
+  return (int32_t)t;
 }
 
-// table entry k=(c,tap): {offset, dt | dh<<4 | dw<<8 | c<<12}; pad entries: {0, -1} (y < 0 = invalid)
 int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out) {
   Geom g;
   SLV_CHECK_ARG(read_geom(geom, g) == 0 && tab_host_out, "invalid geometry");
-  const int taps = g.kt * g.kh * g.kw;
-  const int C = dgrad ? g.Cout : g.Cin;
-  const int total = ((C * taps + 15) / 16) * 16 + 16;
-  for (int k = C * taps; k < total; ++k) {
-    tab_host_out[2 * k] = 0;
-    tab_host_out[2 * k + 1] = INT32_MIN;  // sign bit = invalid; channel field stays 0 (in range)
+  if (!dgrad) {
+    fill_table(fwd_desc(g), tab_host_out);
+    return 0;
   }
-  const int THWi = g.Ti * g.Hi * g.Wi, HWi = g.Hi * g.Wi, Pout = g.To * g.Ho * g.Wo;
-  for (int c = 0; c < C; ++c)
-    for (int dt = 0; dt < g.kt; ++dt)
-      for (int dh = 0; dh < g.kh; ++dh)
-        for (int dw = 0; dw < g.kw; ++dw) {
-          const int k = c * taps + (dt * g.kh + dh) * g.kw + dw;
-          tab_host_out[2 * k] = dgrad ? c * Pout : c * THWi + dt * HWi + dh * g.Wi + dw;
-          tab_host_out[2 * k + 1] = dt | (dh << 4) | (dw << 8) | (c << 12);
-        }
+  Desc ds[8];
+  const int n = dgrad_descs(g, ds);
+  for (int i = 0; i < n; ++i) fill_table(ds[i], tab_host_out + ds[i].tab_off);
   return 0;
 }
 
@@ -140,25 +262,40 @@ int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const int3
   Geom g;
   SLV_CHECK_ARG(read_geom(geom, g) == 0, "invalid geometry");
   SLV_CHECK_ARG(x && w && tab && y, "null pointer");
+  const Desc d = fwd_desc(g);
   IgemmArgs a;
-  fill_common(a, g);
-  a.A = w; a.B = x; a.tab = (const int2*)tab; a.C = y;
+  conv_args(a, g, d, tab);
+  a.A = w; a.B = x; a.C = y;
   a.pb = in_scale_shift; a.b_pro = in_scale_shift ? PRO_ACT : PRO_NONE; a.b_relu = in_relu;
   a.stat_sum = stat_sum; a.stat_sq = stat_sq;
-  a.M = g.Cout; a.Kd = g.Cin * g.kt * g.kh * g.kw;
-  a.Ntot = (long long)g.Bn * g.To * g.Ho * g.Wo;
   const int mt = pick_mt(a.M);
   const int nt = pick_nt(a.Ntot, (a.M + mt * 16 - 1) / (mt * 16), mt);
-  SLV_CHECK_ARG(dispatch<MODE_FWD>(a, mt, nt, 1, (hipStream_t)stream) == 0, "no kernel for tile");
+  SLV_CHECK_ARG(dispatch<MODE_CONV>(a, mt, nt, 1, (hipStream_t)stream) == 0, "no kernel for tile");
   SLV_LAUNCH_CHECK();
   return 0;
 }
 
-int slv_conv_wt_transform(const float* w, float* wt, int Cout, int Cin, int taps, slv_stream_t stream) {
-  SLV_CHECK_ARG(w && wt && Cout > 0 && Cin > 0 && taps > 0, "null pointer or empty shape");
-  const size_t n = (size_t)Cout * Cin * taps;
-  hipLaunchKernelGGL(wt_transform_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)),
-                     dim3(256), 0, (hipStream_t)stream, w, wt, Cout, Cin, taps);
+/* wt: per stride-parity class c a [Cin][Cout*ntaps_c] matrix, classes concatenated (same total size as w) */
+int slv_conv_wt_transform(const int32_t* geom, const float* w, float* wt, slv_stream_t stream) {
+  Geom g;
+  SLV_CHECK_ARG(read_geom(geom, g) == 0 && w && wt, "invalid geometry or null pointer");
+  Desc ds[8];
+  const int n = dgrad_descs(g, ds);
+  TapMap tm;
+  memset(&tm, 0, sizeof(tm));
+  const int taps = g.kt * g.kh * g.kw;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < ds[i].ntaps; ++j) {
+      const int t = ds[i].taps[j];
+      tm.off[t] = (int)ds[i].wt_off;
+      tm.nt[t] = ds[i].ntaps;
+      tm.j[t] = j;
+    }
+  // taps that belong to no materialised class (class lattice empty) keep nt = 0: route them nowhere harmful
+  for (int t = 0; t < taps; ++t) SLV_CHECK_ARG(tm.nt[t] > 0, "tap without a parity class (input smaller than stride)");
+  const size_t nel = (size_t)g.Cout * g.Cin * taps;
+  hipLaunchKernelGGL(wt_transform_kernel, dim3((unsigned)((nel + 255) / 256 < 4096 ? (nel + 255) / 256 : 4096)),
+                     dim3(256), 0, (hipStream_t)stream, w, wt, g.Cout, g.Cin, taps, tm);
   SLV_LAUNCH_CHECK();
   return 0;
 }
@@ -169,16 +306,19 @@ int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* x_out, con
   Geom g;
   SLV_CHECK_ARG(read_geom(geom, g) == 0, "invalid geometry");
   SLV_CHECK_ARG(dy && wt && tab && dx && (!bwd5 || x_out), "null pointer");
-  IgemmArgs a;
-  fill_common(a, g);
-  a.A = wt; a.B = dy; a.B2 = x_out; a.tab = (const int2*)tab; a.C = dx; a.E = addend;
-  a.pb = bwd5; a.b_pro = bwd5 ? PRO_BWD : PRO_NONE; a.b_relu = relu;
-  a.M = g.Cin; a.Kd = g.Cout * g.kt * g.kh * g.kw;
-  a.Ntot = (long long)g.Bn * g.Ti * g.Hi * g.Wi;
-  const int mt = pick_mt(a.M);
-  const int nt = pick_nt(a.Ntot, (a.M + mt * 16 - 1) / (mt * 16), mt);
-  SLV_CHECK_ARG(dispatch<MODE_DGRAD>(a, mt, nt, 1, (hipStream_t)stream) == 0, "no kernel for tile");
-  SLV_LAUNCH_CHECK();
+  Desc ds[8];
+  const int n = dgrad_descs(g, ds);
+  for (int i = 0; i < n; ++i) {
+    const Desc& d = ds[i];
+    IgemmArgs a;
+    conv_args(a, g, d, tab);
+    a.A = wt + d.wt_off; a.B = dy; a.B2 = x_out; a.C = dx; a.E = addend;
+    a.pb = bwd5; a.b_pro = bwd5 ? PRO_BWD : PRO_NONE; a.b_relu = relu;
+    const int mt = pick_mt(a.M);
+    const int nt = pick_nt(a.Ntot, (a.M + mt * 16 - 1) / (mt * 16), mt);
+    SLV_CHECK_ARG(dispatch<MODE_CONV>(a, mt, nt, 1, (hipStream_t)stream) == 0, "no kernel for tile");
+    SLV_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -196,12 +336,18 @@ int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_out, con
   Geom g;
   SLV_CHECK_ARG(read_geom(geom, g) == 0, "invalid geometry");
   SLV_CHECK_ARG(dy && x_in && tab && dw && (!bwd5 || x_out), "null pointer");
+  const Desc d = fwd_desc(g);
   IgemmArgs a;
-  fill_common(a, g);
+  memset(&a, 0, sizeof(a));
   const int taps = g.kt * g.kh * g.kw;
+  a.tab = (const int2*)tab;
+  a.tapd = (const int*)(tab + 2 * kpad(d.Kd));
+  a.Cin = g.Cin; a.Ti = g.Ti; a.Hi = g.Hi; a.Wi = g.Wi; a.Cout = g.Cout; a.To = g.To; a.Ho = g.Ho; a.Wo = g.Wo;
+  a.st = g.st; a.sh = g.sh; a.sw = g.sw; a.pt = g.pt; a.ph = g.ph; a.pw = g.pw;
   a.A = dy; a.A2 = x_out; a.pa = bwd5; a.a_pro = bwd5 ? PRO_BWD : PRO_NONE; a.a_relu = a_relu;
   a.B = x_in; a.pb = in_scale_shift; a.b_pro = in_scale_shift ? PRO_ACT : PRO_NONE; a.b_relu = in_relu;
-  a.tab = (const int2*)tab;
+  a.A_bytes = a.A2_bytes = (unsigned)((size_t)g.Bn * g.Cout * g.To * g.Ho * g.Wo * 4);
+  a.B_bytes = (unsigned)((size_t)g.Bn * g.Cin * g.Ti * g.Hi * g.Wi * 4);
   a.M = g.Cout; a.Kd = 0; a.Ntot = (long long)g.Cin * taps; a.ldc = g.Cin * taps;
   a.Ptot = (long long)g.Bn * g.To * g.Ho * g.Wo;
   SLV_CHECK_ARG(a.Ptot < (1LL << 31), "more than 2^31 output positions");
@@ -233,10 +379,12 @@ int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_out, con
 int slv_gemm_nt(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc,
                 slv_stream_t stream) {
   SLV_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N, "null pointer or empty shape");
+  SLV_CHECK_ARG((long long)M * K * 4 < 0xFFFFFFF0LL && (long long)N * K * 4 < 0xFFFFFFF0LL, "operand larger than 4 GiB");
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.B = B; a.bias = bias; a.C = C; a.M = M; a.Kd = K; a.Ntot = N; a.ldc = ldc;
-  a.Hi = a.Wi = a.Ti = a.Ho = a.Wo = a.To = 1;
+  a.A_bytes = (unsigned)((size_t)M * K * 4);
+  a.B_bytes = (unsigned)((size_t)N * K * 4);
   const int mt = pick_mt(M);
   const int nt = pick_nt(N, (M + mt * 16 - 1) / (mt * 16), mt);
   SLV_CHECK_ARG(dispatch<MODE_GEMM>(a, mt, nt, 1, (hipStream_t)stream) == 0, "no kernel for tile");

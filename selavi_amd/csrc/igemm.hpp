@@ -1,12 +1,15 @@
 // Implicit-GEMM convolution / GEMM core for gfx950 (MI355X), fp32 in / fp32 accumulate on the
 // matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, 157 TF peak = fp32 vector peak).
 //
-// One kernel template covers the four GEMM-shaped ops of the SeLaVi training step
+// One kernel template covers the GEMM-shaped ops of the SeLaVi training step
 // (reference: torchvision Conv3d/Conv2d + autograd called from model.py:145-166, main.py:284-301):
-//   MODE_FWD    Y[co, p]      = sum_{ci,tap} W[co, ci, tap]  * act(X)[ci, p*stride + tap - pad]
-//   MODE_DGRAD  dX[ci, q]     = sum_{co,tap} Wt[ci, co, tap] * dXout[co, (q + pad - tap)/stride]
-//   MODE_WGRAD  dW[co, ci,tap] = sum_p dXout[co, p] * act(X)[ci, p*stride + tap - pad]
-//   MODE_GEMM   C[m, n]       = sum_k A[m, k] * B[n, k]          (dense "NT" GEMM for the heads)
+//   MODE_CONV   Y[m, q]   = sum_{c,tap} A[m, (c,tap)] * pro(X)[c, q*mul + delta(tap)]
+//               - forward conv:   m = co, lattice q = output positions, mul = stride, delta = tap - pad
+//               - backward data:  m = ci, one launch per stride-parity class of the INPUT positions
+//                                 (q*stride + class), taps restricted to the class, delta = (class+pad-tap)/stride
+//                                 -> no wasted MFMA work for stride-2 layers, all offsets stay linear
+//   MODE_WGRAD  dW[co, (ci,tap)] = sum_p pro(dXout)[co, p] * pro(X)[ci, p*stride + tap - pad]
+//   MODE_GEMM   C[m, n]   = sum_k A[m, k] * B[n, k]          (dense "NT" GEMM for the heads)
 // with the BatchNorm that surrounds every conv of the model fused into the operand loaders:
 //   PRO_ACT  v = relu?(x*scale[c] + shift[c])                (consumer-side BN apply + ReLU)
 //   PRO_BWD  v = A1[c]*mask*g + A2[c] + A3[c]*x              (BN backward of the conv's own output)
@@ -20,10 +23,12 @@
 // operands and [16][BN+16] for position-contiguous operands; both give conflict-free ds_read_b32
 // fragment reads (bank = (a/4) % 32 inside each 32-lane half).
 //
-// Pipeline: global->LDS is register staged and double buffered.  Loads of chunk c+1 are issued
-// (unconditionally, from clamped addresses -- no divergent branches) before the MFMAs of chunk c;
-// validity masking and the BN prologue math run when the registers are written to LDS after those
-// MFMAs, so the global latency hides under the matrix pipe.  One barrier per chunk.
+// Loads: raw buffer loads (SGPR descriptor + 32-bit byte offset).  Out-of-range elements (padding,
+// tile tails) are given an out-of-bounds offset and come back as 0 from the hardware range check,
+// so the loaders have no branches and no 64-bit address math; tap validity is a per-thread bitmask
+// computed once per block.  Global->LDS is register staged and double buffered: loads of chunk c+1
+// are issued before the MFMAs of chunk c, masking/prologue math runs when the registers are written
+// to LDS after those MFMAs.  One barrier per chunk.
 #pragma once
 #include <type_traits>
 
@@ -33,7 +38,7 @@ namespace slv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2, MODE_GEMM = 3 };
+enum { MODE_CONV = 0, MODE_WGRAD = 2, MODE_GEMM = 3 };
 enum { PRO_NONE = 0, PRO_ACT = 1, PRO_BWD = 2 };
 
 // exact unsigned division by a runtime constant (Granlund-Montgomery round-up form)
@@ -55,30 +60,41 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
   return (t + ((n - t) >> f.s1)) >> f.s2;
 }
 
+constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond any buffer -> load returns 0
+
 struct IgemmArgs {
-  const float* A;    // FWD/DGRAD/GEMM: dense [M][Kd] ; WGRAD: gradient tensor on the conv-output side
-  const float* A2;   // WGRAD + PRO_BWD: raw conv output x (same shape as A)
-  const float* B;    // FWD/WGRAD: conv input tensor ; DGRAD: gradient on the conv-output side ; GEMM: dense [N][Kd]
-  const float* B2;   // DGRAD + PRO_BWD: raw conv output x
-  const float* pa;   // per-channel prologue params of A (WGRAD): [5][Cout] = s, h, A1, A2, A3
-  const float* pb;   // per-channel prologue params of B: PRO_ACT [2][C] = s, h ; PRO_BWD [5][C]
-  const int2* tab;   // (c,tap) table, padded with invalid entries (y < 0) to a multiple of 16 (+16):
-                     //   {offset, dt | dh<<4 | dw<<8 | c<<12}
+  // operands (device pointers + byte sizes for the buffer descriptors)
+  const float* A;  unsigned A_bytes;    // CONV/GEMM: dense [M][Kd]; WGRAD: gradient tensor (conv-output side)
+  const float* A2; unsigned A2_bytes;   // WGRAD + PRO_BWD: raw conv output x
+  const float* B;  unsigned B_bytes;    // CONV: gathered tensor; WGRAD: conv input; GEMM: dense [N][Kd]
+  const float* B2; unsigned B2_bytes;   // CONV + PRO_BWD: raw conv output x (same shape as B)
+  const float* pa;   // WGRAD A prologue params [5][Cout] = s, h, A1, A2, A3
+  const float* pb;   // B prologue params: PRO_ACT [2][Cb] = s, h ; PRO_BWD [5][Cb]
+  const int2* tab;   // per-k (CONV) / per-column (WGRAD) entries {element offset, tap | chan << 8}; padded with
+                     // invalid entries {0, 63} to a multiple of 16 (+16)
+  const int* tapd;   // per-tap packed deltas: (d0+64) | (d1+64)<<8 | (d2+64)<<16, 64 entries
   float* C;          // output
-  const float* E;    // optional epilogue addend, same shape as C (DGRAD residual / accumulate)
+  const float* E;    // optional epilogue addend, same indexing as C
   const float* bias; // GEMM: optional per-column bias
-  float* stat_sum;   // FWD: [M][nblkN] per-channel partial sums of the output (or null)
+  float* stat_sum;   // CONV: [M][nblkN] per-channel partial sums of the output (or null)
   float* stat_sq;
   int M, Kd;
-  long long Ntot;    // columns: positions (FWD/DGRAD) or Cin*taps (WGRAD) or N (GEMM)
+  long long Ntot;    // columns: lattice positions (CONV) or Cin*taps (WGRAD) or N (GEMM)
   int nblkM, nblkN;
-  int Bn, Cin, Ti, Hi, Wi, Cout, To, Ho, Wo;
-  int st, sh, sw, pt, ph, pw;
+  int Cb;            // channels of the B tensor (prologue param stride)
+  // gather lattice (CONV): column n -> (b, q0, q1, q2); source coord = q*mul + delta(tap), bounds S
+  int Q0, Q1, Q2, mul0, mul1, mul2, S0, S1, S2;
+  long long sbatch;  // elements per sample of the B tensor
+  // destination lattice (CONV): dst coord = q*dmul + dorg inside [D0][D1][D2]
+  int dmul0, dmul1, dmul2, dorg0, dorg1, dorg2, D0, D1, D2;
+  int ntaps;
   int a_pro, b_pro, a_relu, b_relu;
-  int chunks_per_split;  // WGRAD: 16-position chunks per K-slice
-  long long Ptot;        // WGRAD: Bn*To*Ho*Wo
-  int ldc;               // WGRAD/GEMM: leading dimension of C
-  FastDiv dPout, dHoWo, dWo;  // WGRAD position decode
+  // WGRAD geometry
+  int Cin, Ti, Hi, Wi, Cout, To, Ho, Wo, st, sh, sw, pt, ph, pw;
+  int chunks_per_split;
+  long long Ptot;
+  int ldc;
+  FastDiv dPout, dHoWo, dWo;
 };
 
 __device__ __forceinline__ float apply_act(float x, float s, float h, int relu) {
@@ -90,10 +106,12 @@ __device__ __forceinline__ float apply_bwd(float g, float x, float s, float h, f
   const float gm = (relu && !(x * s + h > 0.f)) ? 0.f : g;
   return a1 * gm + a2 + a3 * x;
 }
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
 
 template <int MODE, int MT, int NT>
-__global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD || (MODE == MODE_DGRAD && NT == 2)) ? 2 : 3))
-void igemm_kernel(const IgemmArgs g) {
+__global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) void igemm_kernel(const IgemmArgs g) {
   constexpr int BM = MT * 16, BN = NT * 64;
   constexpr int AS = 18;
   constexpr bool BKF = (MODE == MODE_WGRAD || MODE == MODE_GEMM);  // B tile K-contiguous?
@@ -124,46 +142,48 @@ void igemm_kernel(const IgemmArgs g) {
   const long long n0 = (long long)nblk * BN;
   const int mrem = g.M - m0;  // valid rows in this block (may exceed BM)
 
-  const int HWi = g.Hi * g.Wi, THWi = g.Ti * HWi;
-  const int HoWo = g.Ho * g.Wo, Pout = g.To * HoWo;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)g.A_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)g.B_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(g.A2 ? g.A2 : g.A), 0, (int)(g.A2 ? g.A2_bytes : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(g.B2 ? g.B2 : g.B), 0, (int)(g.B2 ? g.B2_bytes : 0), 0x00020000);
 
   // ---- per-thread constants of the loaders
   const int a_kk = tid & 15, a_r = tid >> 4;  // K-contiguous loader: 16 k's x 16 rows per pass
 
-  // position-contiguous B loader (FWD/DGRAD): one column per thread, BROWS k's
+  // CONV: one lattice column per thread, BROWS k's per chunk
   int nl = 0, kg = 0;
-  bool nvalid = false;
-  int t0 = 0, h0 = 0, w0 = 0;
-  long long bbase = 0;
-  if constexpr (MODE == MODE_FWD || MODE == MODE_DGRAD) {
+  unsigned lbase = 0;           // element offset of this thread's column in the B tensor (may wrap; masked)
+  unsigned mlo = 0, mhi = 0;    // tap validity bitmask of this column
+  if constexpr (MODE == MODE_CONV) {
     nl = tid % BN;
     kg = __builtin_amdgcn_readfirstlane(tid / BN);
     const long long n = n0 + nl;
-    nvalid = n < g.Ntot;
+    const bool nvalid = n < g.Ntot;
     const long long nn = nvalid ? n : 0;
-    if constexpr (MODE == MODE_FWD) {
-      const int b = (int)(nn / Pout);
-      int rem = (int)(nn - (long long)b * Pout);
-      const int to = rem / HoWo;
-      rem -= to * HoWo;
-      const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
-      t0 = to * g.st - g.pt;
-      h0 = ho * g.sh - g.ph;
-      w0 = wo * g.sw - g.pw;
-      bbase = (long long)b * g.Cin * THWi + (long long)t0 * HWi + h0 * g.Wi + w0;
-    } else {
-      const int b = (int)(nn / THWi);
-      int rem = (int)(nn - (long long)b * THWi);
-      const int ti = rem / HWi;
-      rem -= ti * HWi;
-      const int hi = rem / g.Wi, wi = rem - hi * g.Wi;
-      t0 = ti + g.pt;
-      h0 = hi + g.ph;
-      w0 = wi + g.pw;
-      bbase = (long long)b * g.Cout * Pout;
+    const int NQ = g.Q0 * g.Q1 * g.Q2, Q12 = g.Q1 * g.Q2;
+    const int b = (int)(nn / NQ);
+    int rem = (int)(nn - (long long)b * NQ);
+    const int q0 = rem / Q12;
+    rem -= q0 * Q12;
+    const int q1 = rem / g.Q2, q2 = rem - q1 * g.Q2;
+    const int c0 = q0 * g.mul0, c1 = q1 * g.mul1, c2 = q2 * g.mul2;
+    lbase = (unsigned)((long long)b * g.sbatch + (long long)c0 * (g.S1 * g.S2) + c1 * g.S2 + c2);
+    if (nvalid) {
+      for (int t = 0; t < g.ntaps; ++t) {
+        const int d = g.tapd[t];
+        const bool ok = (unsigned)(c0 + (d & 255) - 64) < (unsigned)g.S0 &&
+                        (unsigned)(c1 + ((d >> 8) & 255) - 64) < (unsigned)g.S1 &&
+                        (unsigned)(c2 + ((d >> 16) & 255) - 64) < (unsigned)g.S2;
+        if (t < 32) mlo |= (ok ? 1u : 0u) << t;
+        else mhi |= (ok ? 1u : 0u) << (t - 32);
+      }
     }
   }
   // WGRAD: this thread's reduction position p = chunk*16 + a_kk
+  const int HWi = g.Hi * g.Wi, THWi = g.Ti * HWi;
+  const int HoWo = g.Ho * g.Wo, Pout = g.To * HoWo;
   unsigned wp = 0;
   int nchunks;
   if constexpr (MODE == MODE_WGRAD) {
@@ -180,20 +200,21 @@ void igemm_kernel(const IgemmArgs g) {
   // staging registers hold RAW loaded values; masking + prologue math run in store_chunk
   float ra[MT], ra2[MT];
   float rb[BROWS], rb2[BROWS];
-  unsigned okA = 0, okB = 0;  // per-element validity bits
-
+  unsigned okA = 0, okB = 0;  // validity bits (only consulted when a prologue must be masked)
   (void)ra2; (void)rb2; (void)okA; (void)okB;
 
   // WGRAD: loop-invariant table entries of this thread's B rows and per-channel params in LDS
-  int2 wte[BROWS];
-  (void)wte;
+  int wt_off[BROWS], wt_d[BROWS];
+  (void)wt_off; (void)wt_d;
   float* pAs = smem + 2 * (A_ELEMS + B_ELEMS);  // [5][BM]
   float* pBs = pAs + 5 * BM;                    // [2][BN]
   if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
       const long long n = n0 + a_r + 16 * i;
-      wte[i] = g.tab[n < g.Ntot ? n : g.Ntot];  // entry Ntot is an invalid (y < 0) pad entry
+      const int2 e = g.tab[n < g.Ntot ? n : g.Ntot];  // entry Ntot is an invalid pad entry (tap 63)
+      wt_off[i] = e.x;
+      wt_d[i] = ((e.y & 63) == 63) ? -1 : g.tapd[e.y & 63];
     }
     for (int i = tid; i < 5 * BM; i += 256) {
       const int which = i / BM, m = i - which * BM;
@@ -203,71 +224,45 @@ void igemm_kernel(const IgemmArgs g) {
       const int which = i / BN, nn = i - which * BN;
       const long long n = n0 + nn;
       float v = 0.f;
-      if (g.b_pro == PRO_ACT && n < g.Ntot) v = g.pb[which * g.Cin + ((g.tab[n].y >> 12) & 0x7FFFF)];
+      if (g.b_pro == PRO_ACT && n < g.Ntot) v = g.pb[which * g.Cin + (g.tab[n].y >> 8)];
       pBs[i] = v;
     }
   }
 
-  // ---------------------------------------------------------------- global -> registers (raw, branch-free)
   // NB: every lambda is force-inlined -- an out-of-line lambda captures the register arrays by
-  // reference and drags the accumulators into scratch memory (and turns global loads into flat ones).
+  // reference and drags the accumulators into scratch memory.
+  // ---------------------------------------------------------------- global -> registers (raw, branch-free)
   auto load_chunk = [&](int c) __attribute__((always_inline)) {
     const int k0 = c * 16;
     if constexpr (MODE != MODE_WGRAD) {
-      // A: dense [M][Kd]
-      const int k = k0 + a_kk;
-      const bool kok = k < g.Kd;
-      okA = 0;
+      // A: dense [M][Kd]; rows >= M fall outside the buffer (-> 0), the k tail is neutralised by B == 0
+      const unsigned abase = (unsigned)(((m0 + a_r) * (long long)g.Kd + k0 + a_kk) * 4);
+      const bool kok = (MODE != MODE_GEMM) || (k0 + a_kk < g.Kd);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const int m = a_r + 16 * i;
-        const bool ok = kok && m < mrem;
-        ra[i] = g.A[ok ? (size_t)(m0 + m) * g.Kd + k : 0];
-        okA |= (ok ? 1u : 0u) << i;
+        const unsigned off = abase + (unsigned)(i * 16 * g.Kd * 4);
+        ra[i] = bload(rA, kok ? off : OOB);
       }
     }
     if constexpr (MODE == MODE_GEMM) {
       const int k = k0 + a_kk;
-      okB = 0;
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
         const long long n = n0 + a_r + 16 * i;
-        const bool ok = n < g.Ntot && k < g.Kd;
-        rb[i] = g.B[ok ? (size_t)n * g.Kd + k : 0];
-        okB |= (ok ? 1u : 0u) << i;
+        rb[i] = bload(rB, (n < g.Ntot && k < g.Kd) ? (unsigned)((n * g.Kd + k) * 4) : OOB);
       }
     }
-    if constexpr (MODE == MODE_FWD) {
+    if constexpr (MODE == MODE_CONV) {
       okB = 0;
 #pragma unroll
       for (int q = 0; q < BROWS; ++q) {
-        const int k = k0 + kg * BROWS + q;  // wave-uniform; table is padded, no bound check needed
-        const int2 e = g.tab[k];
-        const int dt = e.y & 15, dh = (e.y >> 4) & 15, dw = (e.y >> 8) & 15, ch = (e.y >> 12) & 0x7FFFF;
-        const bool ok = nvalid && e.y >= 0 && (unsigned)(t0 + dt) < (unsigned)g.Ti &&
-                        (unsigned)(h0 + dh) < (unsigned)g.Hi && (unsigned)(w0 + dw) < (unsigned)g.Wi;
-        rb[q] = g.B[ok ? bbase + e.x : 0];
-        okB |= (ok ? 1u : 0u) << q;
-        (void)ch;
-      }
-    }
-    if constexpr (MODE == MODE_DGRAD) {
-      const int mt_ = g.st - 1, mh_ = g.sh - 1, mw_ = g.sw - 1;  // strides are 1 or 2
-      const int lt_ = g.st >> 1, lh_ = g.sh >> 1, lw_ = g.sw >> 1;
-      okB = 0;
-#pragma unroll
-      for (int q = 0; q < BROWS; ++q) {
-        const int k = k0 + kg * BROWS + q;
-        const int2 e = g.tab[k];
-        const int dt = e.y & 15, dh = (e.y >> 4) & 15, dw = (e.y >> 8) & 15, ch = (e.y >> 12) & 0x7FFFF;
-        const int tt = t0 - dt, hh = h0 - dh, ww = w0 - dw;
-        const int to = tt >> lt_, ho = hh >> lh_, wo = ww >> lw_;
-        const bool ok = nvalid && e.y >= 0 && (tt | hh | ww) >= 0 && ((tt & mt_) | (hh & mh_) | (ww & mw_)) == 0 &&
-                        to < g.To && ho < g.Ho && wo < g.Wo;
-        const long long ad = ok ? bbase + e.x + (long long)to * HoWo + ho * g.Wo + wo : 0;
-        rb[q] = g.B[ad];
-        if (g.b_pro == PRO_BWD) rb2[q] = g.B2[ad];
-        (void)ch;
+        const int2 e = g.tab[k0 + kg * BROWS + q];  // wave-uniform (scalar load); table is padded
+        const int tap = e.y & 63;
+        const unsigned half = tap < 32 ? mlo : mhi;
+        const bool ok = (half >> (tap & 31)) & 1u;
+        const unsigned off = ok ? ((lbase + (unsigned)e.x) << 2) : OOB;
+        rb[q] = bload(rB, off);
+        if (g.b_pro == PRO_BWD) rb2[q] = bload(rB2, off);
         okB |= (ok ? 1u : 0u) << q;
       }
     }
@@ -281,29 +276,27 @@ void igemm_kernel(const IgemmArgs g) {
       const unsigned r2 = rem - to * (unsigned)HoWo;
       const unsigned ho = fdiv(r2, g.dWo);
       const unsigned wo = r2 - ho * (unsigned)g.Wo;
-      okA = 0;
+      okA = pok ? 1u : 0u;
       okB = 0;
-      // A[m][p] = dXout[b][m][p]
-      const size_t abase = (size_t)b * g.Cout * Pout + rem;
+      // A[m][p] = dXout[b][m][p]   (rows >= M read garbage that is never stored)
+      const unsigned abase = (b * (unsigned)g.Cout + (unsigned)(m0 + a_r)) * (unsigned)Pout + rem;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const int m = a_r + 16 * i;
-        const bool ok = pok && m < mrem;
-        const size_t ad = ok ? abase + (size_t)(m0 + m) * Pout : 0;
-        ra[i] = g.A[ad];
-        if (g.a_pro == PRO_BWD) ra2[i] = g.A2[ad];
-        okA |= (ok ? 1u : 0u) << i;
+        const unsigned off = pok ? ((abase + (unsigned)(16 * i) * (unsigned)Pout) << 2) : OOB;
+        ra[i] = bload(rA, off);
+        if (g.a_pro == PRO_BWD) ra2[i] = bload(rA2, off);
       }
       // B[n][p] = act(X)[b][ci][in_pos(p, tap)]
-      const int ti0 = (int)to * g.st - g.pt, hi0 = (int)ho * g.sh - g.ph, wi0 = (int)wo * g.sw - g.pw;
-      const long long xb = (long long)b * g.Cin * THWi + (long long)ti0 * HWi + hi0 * g.Wi + wi0;
+      // table offsets / tap deltas already contain "- pad" (same table as the forward conv)
+      const int ti0 = (int)to * g.st - 64, hi0 = (int)ho * g.sh - 64, wi0 = (int)wo * g.sw - 64;
+      const unsigned xb = b * (unsigned)(g.Cin * THWi) + (unsigned)((ti0 + 64) * HWi + (hi0 + 64) * g.Wi + wi0 + 64);
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
-        const int2 e = wte[i];
-        const int dt = e.y & 15, dh = (e.y >> 4) & 15, dw = (e.y >> 8) & 15;
-        const bool ok = pok && e.y >= 0 && (unsigned)(ti0 + dt) < (unsigned)g.Ti &&
-                        (unsigned)(hi0 + dh) < (unsigned)g.Hi && (unsigned)(wi0 + dw) < (unsigned)g.Wi;
-        rb[i] = g.B[ok ? xb + e.x : 0];
+        const int d = wt_d[i];
+        const bool ok = pok && d >= 0 && (unsigned)(ti0 + (d & 255)) < (unsigned)g.Ti &&
+                        (unsigned)(hi0 + ((d >> 8) & 255)) < (unsigned)g.Hi &&
+                        (unsigned)(wi0 + ((d >> 16) & 255)) < (unsigned)g.Wi;
+        rb[i] = bload(rB, ok ? ((xb + (unsigned)wt_off[i]) << 2) : OOB);
         okB |= (ok ? 1u : 0u) << i;
       }
     }
@@ -319,40 +312,46 @@ void igemm_kernel(const IgemmArgs g) {
       for (int i = 0; i < MT; ++i) {
         const int m = a_r + 16 * i;
         float v = ra[i];
-        if (g.a_pro == PRO_BWD)
+        if (g.a_pro == PRO_BWD) {
           v = apply_bwd(v, ra2[i], pAs[m], pAs[BM + m], pAs[2 * BM + m], pAs[3 * BM + m], pAs[4 * BM + m], g.a_relu);
-        As[m * AS + a_kk] = ((okA >> i) & 1u) ? v : 0.f;
+          v = okA ? v : 0.f;
+        }
+        As[m * AS + a_kk] = v;
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
         const int nn = a_r + 16 * i;
         float v = rb[i];
-        if (g.b_pro == PRO_ACT) v = apply_act(v, pBs[nn], pBs[BN + nn], g.b_relu);
-        Bs[nn * 18 + a_kk] = ((okB >> i) & 1u) ? v : 0.f;
+        if (g.b_pro == PRO_ACT) {
+          v = apply_act(v, pBs[nn], pBs[BN + nn], g.b_relu);
+          v = ((okB >> i) & 1u) ? v : 0.f;
+        }
+        Bs[nn * 18 + a_kk] = v;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) As[(a_r + 16 * i) * AS + a_kk] = ((okA >> i) & 1u) ? ra[i] : 0.f;
+      for (int i = 0; i < MT; ++i) As[(a_r + 16 * i) * AS + a_kk] = ra[i];
       if constexpr (MODE == MODE_GEMM) {
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) Bs[(a_r + 16 * i) * 18 + a_kk] = ((okB >> i) & 1u) ? rb[i] : 0.f;
+        for (int i = 0; i < BROWS; ++i) Bs[(a_r + 16 * i) * 18 + a_kk] = rb[i];
       } else {
         // per-k channel params are wave-uniform: short-lived scalar loads here (keeping them live
-        // across the MFMA phase costs 16-40 registers and spills)
+        // across the MFMA phase costs 16-40 registers)
 #pragma unroll
         for (int q = 0; q < BROWS; ++q) {
           float v = rb[q];
           if (g.b_pro != PRO_NONE) {
-            const int ch = (g.tab[c * 16 + kg * BROWS + q].y >> 12) & 0x7FFFF;
-            if constexpr (MODE == MODE_FWD) {
-              v = apply_act(v, g.pb[ch], g.pb[g.Cin + ch], g.b_relu);
+            const int ch = g.tab[c * 16 + kg * BROWS + q].y >> 8;
+            if (g.b_pro == PRO_ACT) {
+              v = apply_act(v, g.pb[ch], g.pb[g.Cb + ch], g.b_relu);
             } else {
-              const int C_ = g.Cout;
+              const int C_ = g.Cb;
               v = apply_bwd(v, rb2[q], g.pb[ch], g.pb[C_ + ch], g.pb[2 * C_ + ch], g.pb[3 * C_ + ch],
                             g.pb[4 * C_ + ch], g.b_relu);
             }
+            v = ((okB >> q) & 1u) ? v : 0.f;
           }
-          Bs[(kg * BROWS + q) * BS + nl] = ((okB >> q) & 1u) ? v : 0.f;
+          Bs[(kg * BROWS + q) * BS + nl] = v;
         }
       }
     }
@@ -412,17 +411,23 @@ void igemm_kernel(const IgemmArgs g) {
 
   // ---------------------------------------------------------------- epilogue
   // accumulator layout: row = i*16 + fk*4 + r, col = (wave*NT + j)*16 + fi
-  if constexpr (MODE == MODE_FWD || MODE == MODE_DGRAD) {
-    const int Pc = (MODE == MODE_FWD) ? Pout : THWi;  // positions per sample on the output side
+  if constexpr (MODE == MODE_CONV) {
+    const int dP = g.D0 * g.D1 * g.D2;
     size_t obase[NT];
     bool cok[NT];
+    const int NQ = g.Q0 * g.Q1 * g.Q2, Q12 = g.Q1 * g.Q2;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const long long n = n0 + (wave * NT + j) * 16 + fi;
       cok[j] = n < g.Ntot;
       const long long nn = cok[j] ? n : 0;
-      const long long b = nn / Pc;
-      obase[j] = (size_t)b * g.M * Pc + (size_t)(nn - b * Pc);
+      const int b = (int)(nn / NQ);
+      int rem = (int)(nn - (long long)b * NQ);
+      const int q0 = rem / Q12;
+      rem -= q0 * Q12;
+      const int q1 = rem / g.Q2, q2 = rem - q1 * g.Q2;
+      obase[j] = (size_t)b * g.M * dP + (size_t)(q0 * g.dmul0 + g.dorg0) * (g.D1 * g.D2) +
+                 (size_t)(q1 * g.dmul1 + g.dorg1) * g.D2 + (size_t)(q2 * g.dmul2 + g.dorg2);
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -434,7 +439,7 @@ void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
               if (cok[j]) {
-                const size_t ad = obase[j] + (size_t)(m0 + m) * Pc;
+                const size_t ad = obase[j] + (size_t)(m0 + m) * dP;
                 float v = acc[i][j][r];
                 if (g.E) v += g.E[ad];
                 g.C[ad] = v;
@@ -444,41 +449,39 @@ void igemm_kernel(const IgemmArgs g) {
         }
       }
     }
-    if constexpr (MODE == MODE_FWD) {
-      if (g.stat_sum) {
-        // per-channel partial statistics of this block's columns (fixed order -> deterministic)
-        float* red = smem;  // [2][4 waves][BM]   (main loop ended with a barrier)
+    if (g.stat_sum) {
+      // per-channel partial statistics of this block's columns (fixed order -> deterministic)
+      float* red = smem;  // [2][4 waves][BM]   (main loop ended with a barrier)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+      for (int i = 0; i < MT; ++i) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float s = 0.f, q = 0.f;
+        for (int r = 0; r < 4; ++r) {
+          float s = 0.f, q = 0.f;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              const float v = cok[j] ? acc[i][j][r] : 0.f;
-              s += v;
-              q += v * v;
-            }
+          for (int j = 0; j < NT; ++j) {
+            const float v = cok[j] ? acc[i][j][r] : 0.f;
+            s += v;
+            q += v * v;
+          }
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-              s += __shfl_xor(s, o, 64);
-              q += __shfl_xor(q, o, 64);
-            }
-            if (fi == 0) {
-              const int m = i * 16 + fk * 4 + r;
-              red[wave * BM + m] = s;
-              red[(4 + wave) * BM + m] = q;
-            }
+          for (int o = 1; o < 16; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+          }
+          if (fi == 0) {
+            const int m = i * 16 + fk * 4 + r;
+            red[wave * BM + m] = s;
+            red[(4 + wave) * BM + m] = q;
           }
         }
-        __syncthreads();
-        for (int m = tid; m < BM; m += 256) {
-          if (m < mrem) {
-            const float s = ((red[m] + red[BM + m]) + red[2 * BM + m]) + red[3 * BM + m];
-            const float q = ((red[4 * BM + m] + red[5 * BM + m]) + red[6 * BM + m]) + red[7 * BM + m];
-            g.stat_sum[(size_t)(m0 + m) * g.nblkN + nblk] = s;
-            g.stat_sq[(size_t)(m0 + m) * g.nblkN + nblk] = q;
-          }
+      }
+      __syncthreads();
+      for (int m = tid; m < BM; m += 256) {
+        if (m < mrem) {
+          const float s = ((red[m] + red[BM + m]) + red[2 * BM + m]) + red[3 * BM + m];
+          const float q = ((red[4 * BM + m] + red[5 * BM + m]) + red[6 * BM + m]) + red[7 * BM + m];
+          g.stat_sum[(size_t)(m0 + m) * g.nblkN + nblk] = s;
+          g.stat_sq[(size_t)(m0 + m) * g.nblkN + nblk] = q;
         }
       }
     }

@@ -33,9 +33,9 @@ class ConvPlan:
                              dtype=np.int32)
         self.gp = self.geom.ctypes.data
         self.device = device
-        tf = np.empty((C.slv_conv_table_len(self.gp, 0), 2), dtype=np.int32)
+        tf = np.empty(C.slv_conv_table_len(self.gp, 0), dtype=np.int32)
         C.slv_conv_table(self.gp, 0, tf.ctypes.data)
-        td = np.empty((C.slv_conv_table_len(self.gp, 1), 2), dtype=np.int32)
+        td = np.empty(C.slv_conv_table_len(self.gp, 1), dtype=np.int32)
         C.slv_conv_table(self.gp, 1, td.ctypes.data)
         self.tab_fwd = torch.from_numpy(tf).to(device)
         self.tab_dgrad = torch.from_numpy(td).to(device)
@@ -80,7 +80,7 @@ def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True):
 
 def conv_wt_transform(plan, w, out=None):
     wt = out if out is not None else torch.empty_like(w)
-    C.slv_conv_wt_transform(ptr(w), ptr(wt), plan.Cout, plan.Cin, plan.taps, stream())
+    C.slv_conv_wt_transform(plan.gp, ptr(w), ptr(wt), stream())
     return wt
 
 
