@@ -155,6 +155,9 @@ int slv_bn_bwd_finalize(const double* sums, double count, const float* gamma, co
                         const float* scale_shift /* nullable: no relu mask */, float* bwd5 /* [5][C] */,
                         float* dgamma /* nullable */, float* dbeta, int accumulate, int C,
                         slv_stream_t stream);
+/* out = A1*mask*g + A2 + A3*x : the gradient w.r.t. the raw conv output, materialised (may alias g) */
+int slv_bn_bwd_apply(const float* g, const float* x, const float* bwd5, int relu, float* out, int Bn,
+                     int C, int64_t P, slv_stream_t stream);
 int slv_avgpool_fwd(const float* v, float* out, int rows, int P, slv_stream_t stream);
 int slv_avgpool_bwd(const float* dout, float* dv, int rows, int P, slv_stream_t stream);
 int slv_bnrelu_maxpool_fwd(const float* x, const float* scale_shift, float* out, uint8_t* idx, int Bn,

@@ -41,7 +41,8 @@ struct Desc {
   size_t wt_off;           // backward-data: float offset of this class' weight matrix
 };
 
-static int kpad(int Kd) { return ((Kd + 15) / 16) * 16 + 16; }
+// the loader waves run two chunks past the end (branch-free schedule): 48 invalid pad entries
+static int kpad(int Kd) { return ((Kd + 15) / 16) * 16 + 48; }
 
 static void finish(Desc& d, const Geom& g) {
   d.Kd = d.C * d.ntaps;
@@ -187,6 +188,7 @@ __global__ void wt_transform_kernel(const float* __restrict__ w, float* __restri
   const size_t n = (size_t)Cout * Cin * taps;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int tap = (int)(i % taps);
+    if (tm.nt[tap] == 0) continue;
     const size_t r = i / taps;
     const int ci = (int)(r % Cin), co = (int)(r / Cin);
     wt[(size_t)tm.off[tap] + ((size_t)ci * Cout + co) * tm.nt[tap] + tm.j[tap]] = w[i];
@@ -291,8 +293,8 @@ int slv_conv_wt_transform(const int32_t* geom, const float* w, float* wt, slv_st
       tm.nt[t] = ds[i].ntaps;
       tm.j[t] = j;
     }
-  // taps that belong to no materialised class (class lattice empty) keep nt = 0: route them nowhere harmful
-  for (int t = 0; t < taps; ++t) SLV_CHECK_ARG(tm.nt[t] > 0, "tap without a parity class (input smaller than stride)");
+  // taps whose parity class has an empty lattice (input extent smaller than the stride) keep nt = 0:
+  // no input position ever sees them, the kernel skips them
   const size_t nel = (size_t)g.Cout * g.Cin * taps;
   hipLaunchKernelGGL(wt_transform_kernel, dim3((unsigned)((nel + 255) / 256 < 4096 ? (nel + 255) / 256 : 4096)),
                      dim3(256), 0, (hipStream_t)stream, w, wt, g.Cout, g.Cin, taps, tm);

@@ -192,6 +192,19 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
   }
 }
 
+// materialise the gradient w.r.t. a raw conv output: out = A1*mask*g + A2 + A3*x  (bwd5 = s,h,A1,A2,A3)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                          const float* __restrict__ b5, int relu,
+                                                          float* __restrict__ out, int C, int P, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / P) % C);
+    const float xv = x[i];
+    float gv = g[i];
+    if (relu && !(xv * b5[c] + b5[C + c] > 0.f)) gv = 0.f;
+    out[i] = b5[2 * C + c] * gv + b5[3 * C + c] + b5[4 * C + c] * xv;
+  }
+}
+
 // ------------------------------------------------------------------ pools
 // adaptive average pool to 1: out[row] = mean_p v[row][p], one wave per row
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ v, float* __restrict__ out,
@@ -407,6 +420,16 @@ int slv_bn_bwd_finalize(const double* sums, double count, const float* gamma, co
   SLV_CHECK_ARG(sums && gamma && mean_invstd && bwd5 && C > 0 && count > 0, "bad argument");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, count,
                      gamma, mean_invstd, scale_shift, bwd5, dgamma, dbeta, accumulate, C);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_bn_bwd_apply(const float* g, const float* x, const float* bwd5, int relu, float* out, int Bn, int C,
+                     int64_t P, slv_stream_t stream) {
+  SLV_CHECK_ARG(g && x && bwd5 && out && Bn > 0 && C > 0 && P > 0, "bad argument");
+  const size_t total = (size_t)Bn * C * P;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, g, x,
+                     bwd5, relu, out, C, (int)P, total);
   SLV_LAUNCH_CHECK();
   return 0;
 }

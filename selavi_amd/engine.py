@@ -8,9 +8,13 @@ conv's epilogue, and in the backward pass BN-backward is folded into per-channel
 (bwd5) applied when dgrad/wgrad load the gradient (PRO_BWD).  Only block outputs (two consumers)
 are materialised.  See csrc/igemm.hpp.
 """
+import os
+
 import torch
 
 from . import ops
+
+FUSE_BN_BWD_ON_LOAD = os.environ.get("SELAVI_FUSE_BN_BWD", "0") == "1"
 
 
 class Raw:
@@ -63,7 +67,7 @@ def _wt(r):
     return ops.conv_wt_transform(r.plan, r.conv.weight)
 
 
-def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None):
+def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, keep_g=False):
     """Backward through conv `r.conv` given the gradient `g` w.r.t. the ACTIVATED output of r's BN
     (or the masked tail gradient when a_relu is False) and its folded BN-backward coefficients.
     Writes the weight gradient; returns the gradient w.r.t. the conv input (activated, if the
@@ -73,11 +77,22 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None):
         xin, in_ss = src.y, src.ss
     else:
         xin, in_ss = src, None
-    dw = ops.conv_wgrad(r.plan, g, xin, x_out=r.y, bwd5=b5, a_relu=a_relu, in_ss=in_ss, in_relu=in_ss is not None)
+    if FUSE_BN_BWD_ON_LOAD:
+        # BN backward folded into the wgrad/dgrad operand loaders (no extra HBM pass, heavier loaders)
+        dw = ops.conv_wgrad(r.plan, g, xin, x_out=r.y, bwd5=b5, a_relu=a_relu, in_ss=in_ss,
+                            in_relu=in_ss is not None)
+        ctx.grads[id(r.conv.weight)] = dw.view_as(r.conv.weight)
+        if not need_dx:
+            return None
+        return ops.conv_dgrad(r.plan, g, _wt(r), x_out=r.y, bwd5=b5, relu=a_relu, addend=addend, out=out)
+    # default: materialise dXout once (in place over g, which is dead afterwards unless it doubles
+    # as the residual addend) and feed plain tensors to both GEMMs
+    dxo = ops.bn_bwd_apply(g, r.y, b5, a_relu, out=torch.empty_like(g) if (keep_g or addend is g) else None)
+    dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None)
     ctx.grads[id(r.conv.weight)] = dw.view_as(r.conv.weight)
     if not need_dx:
         return None
-    return ops.conv_dgrad(r.plan, g, _wt(r), x_out=r.y, bwd5=b5, relu=a_relu, addend=addend, out=out)
+    return ops.conv_dgrad(r.plan, dxo, _wt(r), addend=addend, out=out)
 
 
 def bn_bwd_own(ctx, r, g):
@@ -129,12 +144,12 @@ def block_bwd(ctx, rec, dv, need_du=True):
     for i in range(n - 1, -1, -1):
         r = rec.chain[i]
         if i > 0:
-            g = backprop_raw(ctx, r, g, b5, a_relu)
+            g = backprop_raw(ctx, r, g, b5, a_relu, keep_g=(i == n - 1))  # dz is reused by the shortcut
             b5 = bn_bwd_own(ctx, rec.chain[i - 1], g)
             a_relu = True
         else:
             if ds is not None:
-                du = backprop_raw(ctx, r, g, b5, a_relu, need_dx=need_du)
+                du = backprop_raw(ctx, r, g, b5, a_relu, need_dx=need_du, keep_g=(n == 1))
                 du = backprop_raw(ctx, ds, dz, b5ds, False, need_dx=need_du, addend=du, out=du)
             else:
                 du = backprop_raw(ctx, r, g, b5, a_relu, need_dx=need_du, addend=dz)

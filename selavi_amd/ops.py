@@ -182,6 +182,15 @@ def bn_bwd(g, x, mi, gamma, ss_mask=None, v_mask=None, x2=None, mi2=None, gamma2
     return outs[0], outs[1], gout
 
 
+def bn_bwd_apply(g, x, b5, relu, out=None):
+    """dXout = A1*mask*g + A2 + A3*x (in place over g by default)."""
+    Bn, Cc = x.shape[0], x.shape[1]
+    P = x.numel() // (Bn * Cc)
+    out = g if out is None else out
+    C.slv_bn_bwd_apply(ptr(g), ptr(x), ptr(b5), int(relu), ptr(out), Bn, Cc, P, stream())
+    return out
+
+
 def avgpool_fwd(v):
     Bn, Cc = v.shape[0], v.shape[1]
     P = v.numel() // (Bn * Cc)

@@ -24,6 +24,8 @@ GEOMS = [
     (3, 64, 1, 10, 9, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # audio 3x3 stride 2
     (3, 128, 1, 5, 5, 256, (1, 1, 1), (1, 2, 2), (0, 0, 0)),     # audio downsample
     (1, 5, 1, 3, 1, 7, (1, 3, 3), (1, 1, 1), (0, 1, 1)),         # degenerate W = 1
+    (2, 16, 1, 4, 4, 8, (3, 1, 1), (2, 1, 1), (1, 0, 0)),        # T = 1 under temporal stride 2 (empty parity class)
+    (2, 8, 3, 5, 5, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0)),        # 1x1x1 stride 2 on odd extents
 ]
 
 

@@ -47,6 +47,13 @@ for name, Cin, T, H, W, Cout, k, st, pd in LAYERS:
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
     tf = timeit(lambda: ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True))
-    td = timeit(lambda: ops.conv_dgrad(plan, dy, wt, x_out=y, bwd5=b5, relu=True))
-    tw = timeit(lambda: ops.conv_wgrad(plan, dy, x, x_out=y, bwd5=b5, a_relu=True, in_ss=ss, in_relu=True))
-    print(f"{name:14s} {flop/1e9:8.1f} | {tf:8.3f} {flop/tf/1e9:6.1f} | {td:8.3f} {flop/td/1e9:6.1f} | {tw:8.3f} {flop/tw/1e9:6.1f}")
+    if os.environ.get("SELAVI_FUSE_BN_BWD", "0") == "1":
+        ta = 0.0
+        td = timeit(lambda: ops.conv_dgrad(plan, dy, wt, x_out=y, bwd5=b5, relu=True))
+        tw = timeit(lambda: ops.conv_wgrad(plan, dy, x, x_out=y, bwd5=b5, a_relu=True, in_ss=ss, in_relu=True))
+    else:
+        dxo = torch.empty_like(dy)
+        ta = timeit(lambda: ops.bn_bwd_apply(dy, y, b5, True, out=dxo))
+        td = timeit(lambda: ops.conv_dgrad(plan, dxo, wt))
+        tw = timeit(lambda: ops.conv_wgrad(plan, dxo, x, in_ss=ss, in_relu=True))
+    print(f"{name:14s} {flop/1e9:8.1f} | {tf:8.3f} {flop/tf/1e9:6.1f} | {td:8.3f} {flop/td/1e9:6.1f} | {tw:8.3f} {flop/tw/1e9:6.1f} | apply {ta:6.3f}")
