@@ -140,11 +140,30 @@ static void fill_table(const Desc& d, int32_t* w) {
     td[j] = j < d.ntaps ? ((d.delta[j][0] + 64) | ((d.delta[j][1] + 64) << 8) | ((d.delta[j][2] + 64) << 16)) : 0;
 }
 
-// column tile: NT=2 (128 columns) unless that leaves most of the 256 CUs idle
-static int pick_nt(long long ncols, int nblkM_for_nt2, int mt) {
-  if (mt >= 15) return 1;  // 240-row tiles keep 60 accumulators per wave; NT=2 would spill
-  const long long blocks2 = ((ncols + 127) / 128) * nblkM_for_nt2;
-  return blocks2 >= 384 ? 2 : 1;
+// Tile choice for the M x ncols output: minimise  padded work / (tile efficiency * chip fill).
+// Big tiles amortise the operand loads best but the small late layers (B*T*H*W = 1568 columns at
+// cfg2's layer4) would leave most of the 256 CUs idle with them; measured relative efficiencies.
+static void pick_tile(int M, long long ncols, int* mt_out, int* nt_out) {
+  static const struct { int mt, nt; double eff; } cand[] = {
+      {9, 2, 1.00}, {8, 2, 0.97}, {15, 1, 0.90}, {4, 2, 0.90}, {9, 1, 0.85}, {8, 1, 0.82}, {4, 1, 0.70}};
+  {  // large outputs: least-padding row tile, 128-column tile (many workgroups per CU anyway)
+    const int mt = pick_mt(M), nt = mt >= 15 ? 1 : 2;
+    const long long blocks = (long long)((M + mt * 16 - 1) / (mt * 16)) * ((ncols + nt * 64 - 1) / (nt * 64));
+    *mt_out = mt;
+    *nt_out = nt;
+    if (blocks >= 768) return;
+  }
+  double best = 1e300;
+  for (const auto& c : cand) {
+    const long long bm = c.mt * 16, bn = c.nt * 64;
+    const long long nbm = (M + bm - 1) / bm, nbn = (ncols + bn - 1) / bn;
+    const double blocks = (double)(nbm * nbn);
+    const double slots = 512.0;  // ~2 resident workgroups per CU
+    const double waves = (double)((long long)((blocks + slots - 1) / slots));
+    const double fill = blocks / (waves * slots);
+    const double cost = (double)(nbm * bm) * (double)(nbn * bn) / (c.eff * fill);
+    if (cost < best) { best = cost; *mt_out = c.mt; *nt_out = c.nt; }
+  }
 }
 
 template <int MODE>
@@ -252,9 +271,9 @@ int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out) {
 int32_t slv_conv_fwd_nblk(const int32_t* geom) {
   Geom g;
   if (read_geom(geom, g) != 0) return -1;
-  const int mt = pick_mt(g.Cout);
   const long long P = (long long)g.Bn * g.To * g.Ho * g.Wo;
-  const int nt = pick_nt(P, (g.Cout + mt * 16 - 1) / (mt * 16), mt);
+  int mt, nt;
+  pick_tile(g.Cout, P, &mt, &nt);
   return (int32_t)((P + nt * 64 - 1) / (nt * 64));
 }
 
@@ -270,8 +289,8 @@ int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const int3
   a.A = w; a.B = x; a.C = y;
   a.pb = in_scale_shift; a.b_pro = in_scale_shift ? PRO_ACT : PRO_NONE; a.b_relu = in_relu;
   a.stat_sum = stat_sum; a.stat_sq = stat_sq;
-  const int mt = pick_mt(a.M);
-  const int nt = pick_nt(a.Ntot, (a.M + mt * 16 - 1) / (mt * 16), mt);
+  int mt, nt;
+  pick_tile(a.M, a.Ntot, &mt, &nt);
   SLV_CHECK_ARG(dispatch<MODE_CONV>(a, mt, nt, 1, (hipStream_t)stream) == 0, "no kernel for tile");
   SLV_LAUNCH_CHECK();
   return 0;
@@ -316,8 +335,8 @@ int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* x_out, con
     conv_args(a, g, d, tab);
     a.A = wt + d.wt_off; a.B = dy; a.B2 = x_out; a.C = dx; a.E = addend;
     a.pb = bwd5; a.b_pro = bwd5 ? PRO_BWD : PRO_NONE; a.b_relu = relu;
-    const int mt = pick_mt(a.M);
-    const int nt = pick_nt(a.Ntot, (a.M + mt * 16 - 1) / (mt * 16), mt);
+    int mt, nt;
+    pick_tile(a.M, a.Ntot, &mt, &nt);
     SLV_CHECK_ARG(dispatch<MODE_CONV>(a, mt, nt, 1, (hipStream_t)stream) == 0, "no kernel for tile");
     SLV_LAUNCH_CHECK();
   }
@@ -387,8 +406,8 @@ int slv_gemm_nt(const float* A, const float* B, const float* bias, float* C, int
   a.A = A; a.B = B; a.bias = bias; a.C = C; a.M = M; a.Kd = K; a.Ntot = N; a.ldc = ldc;
   a.A_bytes = (unsigned)((size_t)M * K * 4);
   a.B_bytes = (unsigned)((size_t)N * K * 4);
-  const int mt = pick_mt(M);
-  const int nt = pick_nt(N, (M + mt * 16 - 1) / (mt * 16), mt);
+  int mt, nt;
+  pick_tile(M, N, &mt, &nt);
   SLV_CHECK_ARG(dispatch<MODE_GEMM>(a, mt, nt, 1, (hipStream_t)stream) == 0, "no kernel for tile");
   SLV_LAUNCH_CHECK();
   return 0;

@@ -201,6 +201,8 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
   float ra[MT], ra2[MT];
   float rb[BROWS], rb2[BROWS];
   unsigned okA = 0, okB = 0;  // validity bits (only consulted when a prologue must be masked)
+  float sp0[BROWS], sp1[BROWS];  // CONV + PRO_ACT: per-k scale/shift (wave-uniform)
+  (void)sp0; (void)sp1;
   (void)ra2; (void)rb2; (void)okA; (void)okB;
 
   // WGRAD: loop-invariant table entries of this thread's B rows and per-channel params in LDS
@@ -264,6 +266,10 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
         rb[q] = bload(rB, off);
         if (g.b_pro == PRO_BWD) rb2[q] = bload(rB2, off);
         okB |= (ok ? 1u : 0u) << q;
+        if (g.b_pro == PRO_ACT) {  // wave-uniform scalar loads, consumed after the MFMAs of this chunk
+          sp0[q] = g.pb[e.y >> 8];
+          sp1[q] = g.pb[g.Cb + (e.y >> 8)];
+        }
       }
     }
     if constexpr (MODE == MODE_WGRAD) {
@@ -341,10 +347,10 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
         for (int q = 0; q < BROWS; ++q) {
           float v = rb[q];
           if (g.b_pro != PRO_NONE) {
-            const int ch = g.tab[c * 16 + kg * BROWS + q].y >> 8;
             if (g.b_pro == PRO_ACT) {
-              v = apply_act(v, g.pb[ch], g.pb[g.Cb + ch], g.b_relu);
+              v = apply_act(v, sp0[q], sp1[q], g.b_relu);  // params fetched with the data (no latency chain here)
             } else {
+              const int ch = g.tab[c * 16 + kg * BROWS + q].y >> 8;
               const int C_ = g.Cb;
               v = apply_bwd(v, rb2[q], g.pb[ch], g.pb[C_ + ch], g.pb[2 * C_ + ch], g.pb[3 * C_ + ch],
                             g.pb[4 * C_ + ch], g.b_relu);
