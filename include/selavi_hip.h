@@ -78,6 +78,9 @@ int slv_sk_iterate(const double* P, int64_t N, int K, double* beta, const double
                    int max_iter, int n_iters, void* ws, int grid, slv_stream_t stream);
 /* host_out: 4 doubles {counter, done, err, reserved} in (pinned) host memory                 */
 int slv_sk_status(void* ws, int K, int grid, double* host_out, slv_stream_t stream);
+/* match_order (sk_utils.py:424-467): out[i][j] = sum_n |e1[n][i] - e2[n][j]|; partial = nsplit*K*K doubles */
+int slv_sk_l1_cost_matrix(const double* e1, const double* e2, int64_t N, int K, double* partial,
+                          int nsplit, double* out /* K*K */, slv_stream_t stream);
 int slv_sk_labels(const double* P, int64_t N_local, int K, const double* beta, void* ws, int grid,
                   int64_t* labels /* N_local */, double* logsum_out /* 1 double, device */,
                   slv_stream_t stream);

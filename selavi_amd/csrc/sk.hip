@@ -379,6 +379,60 @@ __global__ __launch_bounds__(512) void sk_sum_errp_kernel(SkWs w, int grid, doub
   if (threadIdx.x == 0) out[0] = she[0];
 }
 
+// 64x64 tile of the L1 column-distance matrix over one slice of the rows; thread (ty,tx) owns a 4x4 patch
+__global__ __launch_bounds__(256) void sk_l1_cost_kernel(const double* __restrict__ e1, const double* __restrict__ e2,
+                                                        int64_t N, int K, double* __restrict__ partial,
+                                                        int nsplit) {
+  __shared__ double s1[16][64], s2[16][64];
+  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+  const int64_t per = (N + nsplit - 1) / nsplit;
+  const int64_t r0 = blockIdx.z * per, r1 = (r0 + per < N) ? r0 + per : N;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int64_t r = r0; r < r1; r += 16) {
+    for (int t = threadIdx.x; t < 16 * 64; t += 256) {
+      const int rr = t >> 6, cc = t & 63;
+      const bool ok = r + rr < r1;
+      s1[rr][cc] = (ok && i0 + cc < K) ? e1[(r + rr) * K + i0 + cc] : 0.0;
+      s2[rr][cc] = (ok && j0 + cc < K) ? e2[(r + rr) * K + j0 + cc] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      double a_[4], b_[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) a_[a] = s1[rr][ty * 4 + a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) b_[b] = s2[rr][tx * 4 + b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] += fabs(a_[a] - b_[b]);
+    }
+    __syncthreads();
+  }
+  // rows beyond r1 contributed |0 - 0| = 0
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = i0 + ty * 4 + a, j = j0 + tx * 4 + b;
+      if (i < K && j < K) partial[((size_t)blockIdx.z * K + i) * K + j] = acc[a][b];
+    }
+}
+__global__ void sk_sum_splits_kernel(const double* __restrict__ partial, double* __restrict__ out, size_t n,
+                                     int nsplit) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = 0.0;
+  for (int s = 0; s < nsplit; ++s) v += partial[(size_t)s * n + i];
+  out[i] = v;
+}
+
 // ---- KJ dispatch -----------------------------------------------------------------------------
 #define SK_DISPATCH_KJ(K, ...)                                             \
   do {                                                                     \
@@ -554,6 +608,22 @@ int slv_sk_status(void* ws, int K, int grid, double* host_out, slv_stream_t stre
   hipLaunchKernelGGL(sk_status_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, w, stage);
   SLV_LAUNCH_CHECK();
   SLV_HIP(hipMemcpyAsync(host_out, stage, 4 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+
+// match_order (sk_utils.py:424-467): C[i][j] = sum_n |e1[n][i] - e2[n][j]| -- the whole hill-climb then
+// runs on this K x K table instead of 100k synced column reductions.  partial [S][K][K], fixed order.
+int slv_sk_l1_cost_matrix(const double* e1, const double* e2, int64_t N, int K, double* partial, int nsplit,
+                          double* out, slv_stream_t stream) {
+  SLV_CHECK_ARG(e1 && e2 && partial && out && N > 0 && K > 0 && nsplit > 0, "bad argument");
+  const int T = (K + 63) / 64;
+  hipLaunchKernelGGL(sk_l1_cost_kernel, dim3(T, T, nsplit), dim3(256), 0, (hipStream_t)stream, e1, e2, N, K,
+                     partial, nsplit);
+  SLV_LAUNCH_CHECK();
+  const size_t kk = (size_t)K * K;
+  hipLaunchKernelGGL(sk_sum_splits_kernel, dim3((unsigned)((kk + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     partial, out, kk, nsplit);
+  SLV_LAUNCH_CHECK();
   return 0;
 }
 

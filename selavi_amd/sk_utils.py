@@ -230,3 +230,213 @@ def optimize_L_sk_gpu(args, PS, hc, logger=None, group=None, N_global=None, back
 
 
 optimize_L_sk = optimize_L_sk_gpu      # the name BASELINE.json's north_star uses
+
+
+# ======================================================================================================
+# match_order / get_cluster_assignments_gpu / cluster  (sk_utils.py:23-356,424-467)
+# ======================================================================================================
+def l1_cost_matrix(emb1, emb2, group=None, backend=None):
+    """C[i][j] = sum_n |emb1[n, i] - emb2[n, j]| over ALL rows (all-reduced over the row shards)."""
+    N, K = emb1.shape
+    nsplit = max(1, min(64, N // 256))
+    part = torch.empty(nsplit, K, K, dtype=torch.float64, device=emb1.device)
+    out = torch.empty(K, K, dtype=torch.float64, device=emb1.device)
+    C.slv_sk_l1_cost_matrix(ptr(emb1.contiguous()), ptr(emb2.contiguous()), N, K, ptr(part), nsplit, ptr(out),
+                            stream())
+    if group is not None:
+        _allreduce(out, group)
+    return out
+
+
+def _hill_climb(Cm, steps, restarts, logger=None):
+    """The random pair-swap search of sk_utils.py:436-461 on the K x K column-distance table (host).
+    Consumes ``np.random.choice(K, 2, replace=False)`` exactly like the reference."""
+    import numpy as np
+    K = Cm.shape[0]
+    cost0 = float(np.trace(Cm))
+    best_cost, fin_perm = cost0, np.arange(K)
+    if logger is not None:
+        logger.info(f'initial cost: {cost0:.1f}')
+    last_iter = 0                                   # (:441: not reset between restarts in the reference)
+    for _ in range(restarts):
+        perm = np.arange(K)                         # emb2 column currently sitting at position i
+        for _iter in range(steps):
+            i, j = np.random.choice(K, 2, replace=False)
+            current = Cm[i, perm[i]] + Cm[j, perm[j]]
+            future = Cm[i, perm[j]] + Cm[j, perm[i]]
+            if current - future > 0:
+                perm[i], perm[j] = perm[j], perm[i]
+                last_iter = _iter
+            if _iter - last_iter > 1000:
+                break
+        cost_try = float(Cm[np.arange(K), perm].sum())
+        if logger is not None:
+            logger.info(f"cost of this try: {cost_try:.2f}")
+        if cost_try < best_cost:
+            best_cost, fin_perm = cost_try, perm.copy()
+    return fin_perm, best_cost
+
+
+@torch.no_grad()
+def match_order(args, emb1, emb2_in, W2, steps=50000, restarts=2, logger=None, group=None):
+    """Drop-in for ``sk_utils.match_order`` (:424-467): align the audio head's clusters with the video
+    head's by permuting the rows of the audio head's last Linear.  ``emb*`` may be row shards
+    (``group``): the K x K L1 table is all-reduced, rank 0 searches, the permutation is broadcast."""
+    import torch.distributed as dist
+    K = emb1.shape[1]
+    Cm = l1_cost_matrix(emb1, emb2_in, group=group)
+    fin_perm = torch.arange(0, K, device=emb1.device)
+    distributed = dist.is_available() and dist.is_initialized()
+    if getattr(args, "rank", 0) == 0:
+        assert type(W2) == torch.nn.modules.linear.Linear or isinstance(W2, torch.nn.Linear)
+        perm, best = _hill_climb(Cm.cpu().numpy(), steps, restarts, logger)
+        fin_perm = torch.from_numpy(perm).to(emb1.device)
+        if logger is not None:
+            logger.info(f"final cost: {best:.2f}")
+    if distributed and dist.get_world_size() > 1:
+        dist.broadcast(fin_perm, 0)
+    W2.bias.data = W2.bias.data[fin_perm]
+    W2.weight.data = W2.weight.data[fin_perm]
+    return fin_perm
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+@torch.no_grad()
+def get_cluster_assignments_gpu(args, dataset, model, logger=None, writer=None, group=None, iter_num=0):
+    """Drop-in for ``sk_utils.get_cluster_assignments_gpu`` (:137-356), re-designed for sharded HBM:
+
+    every rank runs the eval-mode feature pass over ITS contiguous dataset slice (:157-163), keeps the
+    features it produced (no all_gather to rank 0, no per-batch barrier), applies each head to its shard
+    with the MFMA GEMM, and the Sinkhorn-Knopp solve runs row-sharded over all ranks (one K+1 fp64
+    all-reduce per iteration).  Labels are all-gathered at the end (replaces ``broadcast(L)``, :345-348).
+    Returns L: N x headcount int64 on the device (rows beyond W*(N//W) stay zero, as in the reference)."""
+    import numpy as np
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    world = dist.get_world_size() if distributed else 1
+    rank = dist.get_rank() if distributed else 0
+    grp = (group if group is not None else dist.group.WORLD) if distributed else None
+    net = _unwrap(model)
+    was_training = model.training
+    model.eval()                                                                       # :150
+    N = len(dataset)
+    local_n = N // world                                                               # :158
+    lo = rank * local_n
+    dev = next(net.parameters()).device
+    hc = args.headcount
+    assert args.ind_groups <= hc                                                       # :183
+    if hc > 1:
+        net.return_features = True                                                     # :185-187
+    L = torch.zeros((N, hc), dtype=torch.long, device=dev)
+    order_heads = list(range(hc))
+    np.random.shuffle(order_heads)                                                     # :191-192
+    bs = 64                                                                            # :168
+    idx_local = torch.arange(lo, lo + local_n)
+    for hd_grp_idx in range(args.ind_groups):                                          # :194
+        # 1. feature pass over this rank's slice (every head group re-runs it: "decorrelated heads")
+        order = idx_local[torch.randperm(local_n)] if getattr(args, "shuffle_sk_pass", True) else idx_local
+        bank_v = bank_a = None
+        indices = torch.empty(local_n, dtype=torch.long, device=dev)
+        fr = 0
+        for b0 in range(0, local_n, bs):
+            ids = order[b0:b0 + bs]
+            batch = [dataset[int(i)] for i in ids]
+            video = torch.stack([b[0] for b in batch]).to(dev, non_blocking=True)
+            audio = torch.stack([b[1] for b in batch]).to(dev, non_blocking=True)
+            idx = torch.as_tensor([int(b[3]) for b in batch], device=dev)
+            feat_v, feat_a = model(video, audio)                                       # :206
+            if feat_v.dim() == 1:
+                feat_v, feat_a = feat_v.unsqueeze(0), feat_a.unsqueeze(0)
+            if bank_v is None:
+                bank_v = torch.empty(local_n, feat_v.shape[1], dtype=torch.float32, device=dev)
+                bank_a = torch.empty_like(bank_v)
+            to = fr + feat_v.shape[0]
+            bank_v[fr:to], bank_a[fr:to], indices[fr:to] = feat_v, feat_a, idx
+            fr = to
+        heads = order_heads[hd_grp_idx::args.ind_groups]
+        # 2. optional audio/video head alignment at the very first SK (:257-286)
+        if args.match and iter_num == 0:
+            for head in heads:
+                if hc == 1:
+                    head_a, lv, la = net.mlp_a, bank_v, bank_a          # hc == 1: banks already hold logits
+                else:
+                    head_a, head_v = getattr(net, f'mlp_a{head}'), getattr(net, f'mlp_v{head}')
+                    lv, la = head_v.forward(bank_v), head_a.forward(bank_a)
+                W2 = list(head_a.modules())[-1] if net.use_mlp else head_a
+                match_order(args, softmax64(lv), softmax64(la), W2, steps=50000, restarts=2, logger=logger,
+                            group=grp)
+        # 3. Sinkhorn-Knopp per head, row-sharded (:300-327)
+        costs = {}
+        for head in heads:
+            t0 = time.time()
+            if hc == 1:
+                lv, la = bank_v, bank_a
+            else:
+                lv = getattr(net, f'mlp_v{head}').forward(bank_v)                       # :309-312
+                la = getattr(net, f'mlp_a{head}').forward(bank_a)
+            PS = head_probabilities(lv, la)                                            # :309-315 fused
+            cost, L_head = optimize_L_sk_gpu(args, PS, head, logger, group=grp, N_global=local_n * world)
+            L[indices, head] = L_head                                                   # :323 (local rows)
+            costs[head] = cost
+            if logger is not None and rank == 0:
+                logger.info(f"Head {head}, Cost: (video): {cost:.3f}; time: {time.time() - t0:.3f}")
+        if logger is not None and rank == 0 and costs:
+            logger.info(f"Final Cost: (video): {np.mean(list(costs.values())):.3f}")
+        if writer and costs:
+            writer.add_scalar('train/LP-cost', np.mean(list(costs.values())), iter_num)
+    if distributed:
+        # each rank filled only its own rows (disjoint): a sum all-reduce assembles L everywhere
+        dist.all_reduce(L, op=dist.ReduceOp.SUM, group=grp)
+    net.return_features = False                                                        # :354
+    model.train(was_training or True)                                                  # :355
+    return L
+
+
+def cluster(args, selflabels, dataset, model, sk_counter, logger, writer, group, iter_num):
+    """Drop-in for ``sk_utils.cluster`` (:23-134): one SK round + NMI logging (sklearn on the host, as
+    in the reference).  Returns the new ``selflabels`` (N x headcount int64, device)."""
+    import numpy as np
+    from sklearn.metrics.cluster import adjusted_mutual_info_score, normalized_mutual_info_score
+    selflabels_old = selflabels.clone()
+    with torch.no_grad():
+        selflabels = get_cluster_assignments_gpu(args, dataset, model, logger, writer, group, iter_num)
+    self_labels_np = selflabels[:, 0].cpu().numpy()
+    sk_counter += 1                                                                     # :42 (local, as in the reference)
+    rank0 = getattr(args, "rank", 0) == 0
+    nmi_v = normalized_mutual_info_score(self_labels_np, selflabels_old[:, 0].cpu().numpy(),
+                                         average_method='arithmetic')
+    if rank0 and logger is not None:
+        logger.info(f'NMI_v: {nmi_v}')
+    if writer:
+        writer.add_scalar('train/nmi_v/iter', nmi_v, iter_num)
+        writer.add_scalar('train/optim_count/iter', sk_counter, iter_num)
+    if hasattr(dataset, "_labels"):
+        true_labels = np.array(dataset._labels)[dataset.valid_indices]
+        nmi_l = normalized_mutual_info_score(self_labels_np, true_labels, average_method='arithmetic')
+        anmi_l = adjusted_mutual_info_score(self_labels_np, true_labels, average_method='arithmetic')
+        if rank0 and logger is not None:
+            logger.info(f"NMI-tolabels: {nmi_l}")
+            logger.info(f"aNMI-tolabels: {anmi_l}")
+        if writer:
+            writer.add_scalar('train/nmi-tolabels_v/iter', nmi_l, iter_num)
+            writer.add_scalar('train/a-nmi-tolabels_v/iter', anmi_l, iter_num)
+        if sk_counter % 10 == 0:                                                        # :89-122
+            from scipy.stats import entropy
+            ents, purs = [], []
+            for lab in np.unique(self_labels_np):
+                sel = self_labels_np == lab
+                if sel.sum() != 0:
+                    _, counts = np.unique(true_labels[sel], return_counts=True)
+                    purs.append(max(counts) / sum(1.0 * counts))
+                    ents.append(entropy(counts / sum(1.0 * counts)))
+            if logger is not None:
+                logger.info(f"Avg entropy: {np.mean(ents)}")
+                logger.info(f"Avg purity: {np.mean(purs)}")
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier(group=group) if group is not None else dist.barrier()
+    cluster.last_nmi = nmi_v
+    return selflabels

@@ -1,0 +1,145 @@
+"""GPU tests of the SK round orchestration (sk_utils.cluster / get_cluster_assignments_gpu / match_order)
+and of the data-parallel wiring (DDP gradient averaging + SyncBN) on one GPU with two gloo ranks."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sk_ref, step_ref
+from oracle.model_ref import portable_fill_, portable_init_
+
+pytestmark = pytest.mark.gpu
+
+
+class Args:
+    def __init__(self, **kw):
+        self.distribution, self.dist, self.diff_dist_every = 'default', None, False
+        self.diff_dist_per_head, self.gauss_sd, self.headcount = True, 0.1, 1
+        self.lamb, self.rank, self.ind_groups, self.match = 20, 0, 1, False
+        self.shuffle_sk_pass = False
+        self.__dict__.update(kw)
+
+
+def test_l1_cost_matrix_and_match_order_golden(golden_dir):
+    from selavi_amd import sk_utils
+    g = np.load(os.path.join(golden_dir, "match_order.npz"))
+    e1, e2 = torch.from_numpy(g["emb1"]).cuda(), torch.from_numpy(g["emb2"]).cuda()
+    Cm = sk_utils.l1_cost_matrix(e1, e2).cpu().numpy()
+    want = np.abs(g["emb1"][:, :, None] - g["emb2"][:, None, :]).sum(0)
+    np.testing.assert_allclose(Cm, want, rtol=1e-12)
+    K = e1.shape[1]
+    W2 = torch.nn.Linear(16, K).cuda()
+    W2.weight.data = torch.from_numpy(g["w_before"]).cuda()
+    W2.bias.data = torch.from_numpy(g["b_before"]).cuda()
+    it = iter(list(g["pairs"]))
+    orig = np.random.choice
+    np.random.choice = lambda *a, **k: next(it)
+    try:
+        # the fixture was recorded with steps=3000
+        sk_utils.match_order(Args(), e1, e2, W2, steps=3000, restarts=2)
+    finally:
+        np.random.choice = orig
+    np.testing.assert_array_equal(W2.weight.data.cpu().numpy(), g["w_after"])
+    np.testing.assert_array_equal(W2.bias.data.cpu().numpy(), g["b_after"])
+    # a larger ragged case
+    a = torch.rand(1000, 70, dtype=torch.float64, device="cuda")
+    b = torch.rand(1000, 70, dtype=torch.float64, device="cuda")
+    got = sk_utils.l1_cost_matrix(a, b)
+    want = (a[:, :, None] - b[:, None, :]).abs().sum(0)
+    assert torch.allclose(got, want, rtol=1e-12)
+
+
+@pytest.mark.parametrize("hc,K", [(2, 8), (1, 6)])
+def test_cluster_round_matches_oracle_reenactment(hc, K):
+    """One SK round through ``cluster`` vs the oracle SK applied to the same per-head probabilities."""
+    from selavi_amd import model as smodel, sk_utils
+    from selavi_amd.data import SyntheticAVDataset
+    ds = SyntheticAVDataset(n=192, T=4, S=32, F=40, Tp=36, n_classes=K)
+    m = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
+    portable_init_(m, seed=31)
+    m = m.cuda().train()
+    # seed the BN running statistics like warmup_batchnorm does (utils.py:389-418)
+    from selavi_amd.utils import warmup_batchnorm
+    loader = [(torch.stack([ds[i][0] for i in range(b, b + 16)]), torch.stack([ds[i][1] for i in range(b, b + 16)]))
+              for b in range(0, 64, 16)]
+    warmup_batchnorm(Args(), m, loader, batches=4)
+    args = Args(headcount=hc)
+    logs = []
+
+    class Lg:
+        def info(self, s, **k):
+            logs.append(s)
+    np.random.seed(3)
+    old = torch.zeros(192, hc, dtype=torch.long, device="cuda")
+    new = sk_utils.cluster(args, old, ds, m, 0, Lg(), None, None, 0)
+    assert new.shape == (192, hc) and new.dtype == torch.long and m.training
+    assert any("NMI-tolabels" in s for s in logs) and any("Cost" in s for s in logs)
+    # oracle re-enactment from the model's own eval-mode outputs
+    m.eval()
+    with torch.no_grad():
+        V = torch.stack([ds[i][0] for i in range(192)]).cuda()
+        A = torch.stack([ds[i][1] for i in range(192)]).cuda()
+        outs = [m(V[i:i + 64], A[i:i + 64]) for i in range(0, 192, 64)]
+    for h in range(hc):
+        lv = torch.cat([(o[0][h] if hc > 1 else o[0]) for o in outs]).cpu().numpy()
+        la = torch.cat([(o[1][h] if hc > 1 else o[1]) for o in outs]).cpu().numpy()
+        _, L_o, _ = sk_ref.optimize_L_sk(sk_ref.head_probabilities(lv, la))
+        agree = (new[:, h].cpu().numpy() == L_o).mean()
+        assert agree == 1.0, f"head {h}: {agree:.3f} agreement with the oracle"
+
+
+def _ddp_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from selavi_amd import model as smodel, optim, train
+        torch.cuda.set_device(0)
+        hc, K = 2, 7
+        m = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
+        portable_init_(m, seed=31)
+        step_ref.set_dropout_p(m, 0.0)
+        m = m.cuda().train()
+        net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)
+        opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+        video = portable_fill_(torch.empty(4, 3, 4, 32, 32), 5)[rank * 2:(rank + 1) * 2].cuda()
+        audio = portable_fill_(torch.empty(4, 1, 40, 36), 6)[rank * 2:(rank + 1) * 2].cuda()
+        sl = torch.from_numpy((np.arange(64 * hc).reshape(64, hc) * 7919 % K).astype(np.int64)).cuda()
+        sel = torch.tensor([3, 17, 42, 63])[rank * 2:(rank + 1) * 2].cuda()
+        loss = train.train_step(net, opt, video, audio, sl, sel, hc)
+        sd = m.state_dict()
+        ret[rank] = (float(loss), {k: sd[k].flatten()[:32].cpu().numpy().copy() for k in (
+            "video_network.base.layer2.0.conv1.0.0.weight", "video_network.base.stem.1.running_var",
+            "audio_network.base.layer3.0.bn2.bias", "mlp_v1.block_forward.4.running_mean",
+            "mlp_a0.block_forward.8.weight")})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_ddp_syncbn_equals_single_process_large_batch():
+    """DDP (grad averaging) + SyncBN on W ranks x b clips == one process with batch W*b
+    (SURVEY.md Appendix B), here W = 2, b = 2 on one GPU over gloo."""
+    import torch.multiprocessing as mp
+    from selavi_amd import model as smodel, optim, train
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ddp_worker, args=(2, 29400 + os.getpid() % 500, ret), nprocs=2, join=True)
+    hc, K = 2, 7
+    m = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
+    portable_init_(m, seed=31)
+    step_ref.set_dropout_p(m, 0.0)
+    m = m.cuda().train()
+    opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+    video = portable_fill_(torch.empty(4, 3, 4, 32, 32), 5).cuda()
+    audio = portable_fill_(torch.empty(4, 1, 40, 36), 6).cuda()
+    sl = torch.from_numpy((np.arange(64 * hc).reshape(64, hc) * 7919 % K).astype(np.int64)).cuda()
+    sel = torch.tensor([3, 17, 42, 63]).cuda()
+    loss = float(train.train_step(m, opt, video, audio, sl, sel, hc))
+    sd = m.state_dict()
+    l0, w0 = ret[0]
+    l1, w1 = ret[1]
+    assert abs(0.5 * (l0 + l1) - loss) <= 2e-4 * abs(loss)      # mean of the per-rank losses
+    for k in w0:
+        np.testing.assert_array_equal(w0[k], w1[k])             # ranks stay in lock-step
+        np.testing.assert_allclose(w0[k], sd[k].flatten()[:32].cpu().numpy(), rtol=5e-3, atol=2e-4)
