@@ -33,6 +33,18 @@ PEAK_FP32_MFMA_TF = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32-inp
 PEAK_HBM_GBS = 8000.0
 
 
+def _pmc_traffic(prefix):
+    """Measured HBM bytes/launch recorded by the PMC passes of this round (None if not recorded)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+        for k, v in d.items():
+            if k.startswith(prefix) and isinstance(v, dict) and "hbm_bytes_per_launch" in v:
+                return v["hbm_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,7 +133,7 @@ def sk_bench(rank, world, dev, iters=50):
     gbs = n * K * 8 / ms / 1e6      # per-GPU algorithmic bytes (one read of the fp64 shard) / time
     return dict(iters_per_s=1e3 / ms, us_per_iter=ms * 1e3, N=N, K=K, rows_per_gpu=n, grid=grid,
                 roofline=dict(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
-                              traffic=None))
+                              traffic=_pmc_traffic("sk_pass_kernel") if world == 1 else None))
 
 
 def cpu_baseline(batch):
@@ -222,7 +234,10 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "sync_bn": world > 1, "loss_last_step": loss_v},
             "roofline": {"bound": "mfma", "achieved": hot["tflops"], "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
-                         "frac": hot["tflops"] / PEAK_FP32_MFMA_TF, "traffic": None,
+                         "frac": hot["tflops"] / PEAK_FP32_MFMA_TF,
+                         # HBM bytes per launch of this kernel at B=16 from rocprofv3 PMC passes
+                         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r01_pmc.json
+                         "traffic": _pmc_traffic("igemm_kernel<0,9,2>") if B == CFG2["batch"] else None,
                          "kernel": hot["kernel"], "ms_per_launch": hot["ms"], "flop_per_launch": hot["flop"]},
             "step_roofline": {"bound": "mfma", "achieved": step_tflops, "peak": PEAK_FP32_MFMA_TF,
                               "unit": "TFLOP/s per GPU (algorithmic 3 x %.2f GFLOP/clip)" % FWD_GFLOP_PER_CLIP,

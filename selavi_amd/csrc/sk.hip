@@ -230,31 +230,30 @@ __global__ __launch_bounds__(SK_THREADS) void sk_pass_kernel(const double* __res
   block_reduce_cols<KJ>(acc, e, w, sh);
 }
 
-// grid-level fixed-order reduce: s[k] = sum_b partial[b][k];  s[K] = sum_b errp[b]
-__global__ __launch_bounds__(512) void sk_local_reduce_kernel(SkWs w, int K, int grid, int respect_done) {
+// grid-level fixed-order reduce: s[k] = sum_b partial[b][k];  s[K] = sum_b errp[b].
+// 16 columns x 64 block-groups per workgroup: short per-thread chains (latency bound otherwise:
+// the 5-workgroup version took 12 us of a 94 us iteration), fixed-order LDS tree -> deterministic.
+__global__ __launch_bounds__(1024) void sk_local_reduce_kernel(SkWs w, int K, int grid, int respect_done) {
   if (respect_done && w.ctrl->done) return;
-  __shared__ double sh[8][64];
-  const int kx = threadIdx.x & 63, by = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + kx;
+  __shared__ double sh[64][17];
+  __shared__ double she[1024];
+  const int kx = threadIdx.x & 15, by = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + kx;
   double v = 0.0;
-  for (int b = by; b < grid; b += 8) v += w.partial[(size_t)b * w.Kp + k];
+  for (int b = by; b < grid; b += 64) v += w.partial[(size_t)b * w.Kp + k];
   sh[by][kx] = v;
   __syncthreads();
-  if (by == 0 && k < K) {
-    double t = 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) t += sh[q][kx];
-    w.s[k] = t;
-  }
-  if (blockIdx.x == 0) {
+  for (int o = 32; o > 0; o >>= 1) {
+    if (by < o) sh[by][kx] += sh[by + o][kx];
     __syncthreads();
+  }
+  if (by == 0 && k < K) w.s[k] = sh[0][kx];
+  if (blockIdx.x == 0) {
     double ev = 0.0;
-    for (int b = threadIdx.x; b < grid; b += 512) ev += w.errp[b];
-    // fixed-order tree over the 512 threads
-    __shared__ double she[512];
+    for (int b = threadIdx.x; b < grid; b += 1024) ev += w.errp[b];
     she[threadIdx.x] = ev;
     __syncthreads();
-    for (int o = 256; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
       if ((int)threadIdx.x < o) she[threadIdx.x] += she[threadIdx.x + o];
       __syncthreads();
     }
@@ -478,7 +477,7 @@ size_t slv_sk_workspace_bytes(int K, int grid) {
 
 int32_t slv_sk_default_grid(int64_t N, int K) {
   // 2 workgroups of 8 waves per CU on a 256-CU part; never more blocks than 8-row chunks
-  int64_t g = 512;
+  int64_t g = 2048;  // 8 workgroups per CU's worth of 8-row chunks: best tail balance (81 vs 85 us at 256)
   const int64_t maxg = (N + 7) / 8;
   if (g > maxg) g = maxg;
   if (g < 1) g = 1;
@@ -536,7 +535,7 @@ int slv_sk_colsum(const double* P, const double* row_weight, int64_t N, int K, d
   SkWs w = carve(ws, K, grid);
   int rc = launch_colsum(P, row_weight, 1.0, N, K, w, grid, (hipStream_t)stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(sk_local_reduce_kernel, dim3(w.Kp / 64), dim3(512), 0, (hipStream_t)stream, w, K, grid,
+  hipLaunchKernelGGL(sk_local_reduce_kernel, dim3(w.Kp / 16), dim3(1024), 0, (hipStream_t)stream, w, K, grid,
                      0);
   SLV_LAUNCH_CHECK();
   SLV_HIP(hipMemcpyAsync(out, w.s, sizeof(double) * K, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -584,7 +583,7 @@ int slv_sk_iterate(const double* P, int64_t N, int K, double* beta, const double
 int slv_sk_local_reduce(int K, void* ws, int grid, slv_stream_t stream) {
   SLV_CHECK_ARG(ws && K > 0 && grid > 0, "null pointer or empty shape");
   SkWs w = carve(ws, K, grid);
-  hipLaunchKernelGGL(sk_local_reduce_kernel, dim3(w.Kp / 64), dim3(512), 0, (hipStream_t)stream, w, K, grid,
+  hipLaunchKernelGGL(sk_local_reduce_kernel, dim3(w.Kp / 16), dim3(1024), 0, (hipStream_t)stream, w, K, grid,
                      1);
   SLV_LAUNCH_CHECK();
   return 0;
