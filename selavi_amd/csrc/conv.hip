@@ -2,6 +2,8 @@
 // Replaces cuDNN conv3d/conv2d forward, backward-data and backward-weight as reached from the
 // torchvision nets instantiated by /root/reference/model.py:95,114 and their autograd backward
 // (main.py:301).
+#include <stdlib.h>
+
 #include "igemm.hpp"
 #include "../../include/selavi_hip.h"
 
@@ -173,8 +175,13 @@ static int dispatch(const IgemmArgs& a0, int mt, int nt, int splits, hipStream_t
   a.nblkM = (a.M + bm - 1) / bm;
   a.nblkN = (int)((a.Ntot + bn - 1) / bn);
   if (a.nblkN == 0) return 0;
+  // 16-byte A loads when the layout allows it (see igemm.hpp, template flag VA)
+  bool vec_a;
+  if (MODE == MODE_WGRAD) vec_a = ((a.To * a.Ho * a.Wo) % 4 == 0) && a.a_pro == PRO_NONE && (a.Ptot % 4 == 0);
+  else vec_a = (a.Kd % 4 == 0) && (((size_t)a.A & 15) == 0);
+  if (getenv("SLV_NO_VECA")) vec_a = false;
 #define SLV_CASE(MT_, NT_) \
-  if (mt == MT_ && nt == NT_) { launch_igemm<MODE, MT_, NT_>(a, splits, st); return 0; }
+  if (mt == MT_ && nt == NT_) { launch_igemm<MODE, MT_, NT_>(a, splits, vec_a, st); return 0; }
   SLV_CASE(4, 1) SLV_CASE(4, 2) SLV_CASE(8, 1) SLV_CASE(8, 2)
   SLV_CASE(9, 1) SLV_CASE(9, 2) SLV_CASE(15, 1)
 #undef SLV_CASE

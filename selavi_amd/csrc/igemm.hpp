@@ -109,8 +109,13 @@ __device__ __forceinline__ float apply_bwd(float g, float x, float s, float h, f
 __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {  // 16-byte aligned offset
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
 
-template <int MODE, int MT, int NT>
+// VA: the A operand is read with 16-byte loads (4 consecutive k per lane).  Host-checked
+// preconditions: CONV/GEMM Kd % 4 == 0; WGRAD To*Ho*Wo % 4 == 0 and no A prologue.
+template <int MODE, int MT, int NT, bool VA>
 __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) void igemm_kernel(const IgemmArgs g) {
   constexpr int BM = MT * 16, BN = NT * 64;
   constexpr int AS = 18;
@@ -198,7 +203,11 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
   }
 
   // staging registers hold RAW loaded values; masking + prologue math run in store_chunk
-  float ra[MT], ra2[MT];
+  float ra[VA ? 1 : MT], ra2[VA ? 1 : MT];
+  constexpr int NP = (BM + 63) / 64;  // VA: passes of 64 rows x 4 k-quads
+  f32x4 ra4[VA ? NP : 1];
+  (void)ra; (void)ra4;
+  const int v_kq = tid & 3, v_mr = tid >> 2;
   float rb[BROWS], rb2[BROWS];
   unsigned okA = 0, okB = 0;  // validity bits (only consulted when a prologue must be masked)
   float sp0[BROWS], sp1[BROWS];  // CONV + PRO_ACT: per-k scale/shift (wave-uniform)
@@ -238,12 +247,22 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
     const int k0 = c * 16;
     if constexpr (MODE != MODE_WGRAD) {
       // A: dense [M][Kd]; rows >= M fall outside the buffer (-> 0), the k tail is neutralised by B == 0
-      const unsigned abase = (unsigned)(((m0 + a_r) * (long long)g.Kd + k0 + a_kk) * 4);
-      const bool kok = (MODE != MODE_GEMM) || (k0 + a_kk < g.Kd);
+      if constexpr (VA) {
+        const unsigned abase = (unsigned)(((m0 + v_mr) * (long long)g.Kd + k0 + 4 * v_kq) * 4);
+        const bool kok = (MODE != MODE_GEMM) || (k0 + 4 * v_kq < g.Kd);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const unsigned off = abase + (unsigned)(i * 16 * g.Kd * 4);
-        ra[i] = bload(rA, kok ? off : OOB);
+        for (int i = 0; i < NP; ++i) {
+          const unsigned off = abase + (unsigned)(i * 64 * g.Kd * 4);
+          ra4[i] = bload4(rA, (kok && v_mr + 64 * i < BM) ? off : OOB);
+        }
+      } else {
+        const unsigned abase = (unsigned)(((m0 + a_r) * (long long)g.Kd + k0 + a_kk) * 4);
+        const bool kok = (MODE != MODE_GEMM) || (k0 + a_kk < g.Kd);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const unsigned off = abase + (unsigned)(i * 16 * g.Kd * 4);
+          ra[i] = bload(rA, kok ? off : OOB);
+        }
       }
     }
     if constexpr (MODE == MODE_GEMM) {
@@ -285,12 +304,27 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
       okA = pok ? 1u : 0u;
       okB = 0;
       // A[m][p] = dXout[b][m][p]   (rows >= M read garbage that is never stored)
-      const unsigned abase = (b * (unsigned)g.Cout + (unsigned)(m0 + a_r)) * (unsigned)Pout + rem;
+      if constexpr (VA) {
+        // 4 consecutive positions per lane (Pout % 4 == 0: a quad never straddles two samples)
+        const unsigned pq = (wp - (unsigned)a_kk) + (unsigned)c * 16u + 4u * (unsigned)v_kq;
+        const bool qok = (long long)pq < g.Ptot;
+        const unsigned pqq = qok ? pq : 0u;
+        const unsigned bq = fdiv(pqq, g.dPout);
+        const unsigned remq = pqq - bq * (unsigned)Pout;
+        const unsigned abase = (bq * (unsigned)g.Cout + (unsigned)(m0 + v_mr)) * (unsigned)Pout + remq;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const unsigned off = pok ? ((abase + (unsigned)(16 * i) * (unsigned)Pout) << 2) : OOB;
-        ra[i] = bload(rA, off);
-        if (g.a_pro == PRO_BWD) ra2[i] = bload(rA2, off);
+        for (int i = 0; i < NP; ++i) {
+          const unsigned off = (qok && v_mr + 64 * i < BM) ? ((abase + (unsigned)(64 * i) * (unsigned)Pout) << 2) : OOB;
+          ra4[i] = bload4(rA, off);
+        }
+      } else {
+        const unsigned abase = (b * (unsigned)g.Cout + (unsigned)(m0 + a_r)) * (unsigned)Pout + rem;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const unsigned off = pok ? ((abase + (unsigned)(16 * i) * (unsigned)Pout) << 2) : OOB;
+          ra[i] = bload(rA, off);
+          if (g.a_pro == PRO_BWD) ra2[i] = bload(rA2, off);
+        }
       }
       // B[n][p] = act(X)[b][ci][in_pos(p, tap)]
       // table offsets / tap deltas already contain "- pad" (same table as the forward conv)
@@ -313,16 +347,29 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
     (void)c;
     float* As = smem + buf * (A_ELEMS + B_ELEMS);
     float* Bs = As + A_ELEMS;
-    if constexpr (MODE == MODE_WGRAD) {
+    if constexpr (VA) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = a_r + 16 * i;
-        float v = ra[i];
-        if (g.a_pro == PRO_BWD) {
-          v = apply_bwd(v, ra2[i], pAs[m], pAs[BM + m], pAs[2 * BM + m], pAs[3 * BM + m], pAs[4 * BM + m], g.a_relu);
-          v = okA ? v : 0.f;
+      for (int i = 0; i < NP; ++i) {
+        const int m = v_mr + 64 * i;
+        if (m < BM) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) As[m * AS + 4 * v_kq + j] = ra4[i][j];
         }
-        As[m * AS + a_kk] = v;
+      }
+    }
+    if constexpr (MODE == MODE_WGRAD) {
+      if constexpr (!VA) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = a_r + 16 * i;
+          float v = ra[i];
+          if (g.a_pro == PRO_BWD) {
+            v = apply_bwd(v, ra2[i], pAs[m], pAs[BM + m], pAs[2 * BM + m], pAs[3 * BM + m], pAs[4 * BM + m],
+                          g.a_relu);
+            v = okA ? v : 0.f;
+          }
+          As[m * AS + a_kk] = v;
+        }
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
@@ -335,8 +382,10 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
         Bs[nn * 18 + a_kk] = v;
       }
     } else {
+      if constexpr (!VA) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) As[(a_r + 16 * i) * AS + a_kk] = ra[i];
+        for (int i = 0; i < MT; ++i) As[(a_r + 16 * i) * AS + a_kk] = ra[i];
+      }
       if constexpr (MODE == MODE_GEMM) {
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) Bs[(a_r + 16 * i) * 18 + a_kk] = rb[i];
@@ -520,9 +569,10 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
 }
 
 template <int MODE, int MT, int NT>
-inline void launch_igemm(const IgemmArgs& a, int splits, hipStream_t st) {
+inline void launch_igemm(const IgemmArgs& a, int splits, bool vec_a, hipStream_t st) {
   dim3 grid(a.nblkM * a.nblkN * splits, 1, 1);
-  hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT>), grid, dim3(256), 0, st, a);
+  if (vec_a) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, false>), grid, dim3(256), 0, st, a);
 }
 
 // choose the row-tile: returns MT for a given M (rows) -- see header comment
