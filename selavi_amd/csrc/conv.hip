@@ -333,7 +333,9 @@ int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* x_out, con
                    slv_stream_t stream) {
   Geom g;
   SLV_CHECK_ARG(read_geom(geom, g) == 0, "invalid geometry");
-  SLV_CHECK_ARG(dy && wt && tab && dx && (!bwd5 || x_out), "null pointer");
+  SLV_CHECK_ARG(dy && wt && tab && dx, "null pointer");
+  SLV_CHECK_ARG(!bwd5 && !x_out, "the on-load BN-backward prologue was removed: materialise dXout with slv_bn_bwd_apply");
+  (void)relu;
   Desc ds[8];
   const int n = dgrad_descs(g, ds);
   for (int i = 0; i < n; ++i) {
@@ -341,7 +343,7 @@ int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* x_out, con
     IgemmArgs a;
     conv_args(a, g, d, tab);
     a.A = wt + d.wt_off; a.B = dy; a.B2 = x_out; a.C = dx; a.E = addend;
-    a.pb = bwd5; a.b_pro = bwd5 ? PRO_BWD : PRO_NONE; a.b_relu = relu;
+    a.b_pro = PRO_NONE;
     int mt, nt;
     pick_tile(a.M, a.Ntot, &mt, &nt);
     SLV_CHECK_ARG(dispatch<MODE_CONV>(a, mt, nt, 1, (hipStream_t)stream) == 0, "no kernel for tile");
@@ -363,7 +365,9 @@ int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_out, con
                    float* dw, void* ws, size_t ws_bytes, slv_stream_t stream) {
   Geom g;
   SLV_CHECK_ARG(read_geom(geom, g) == 0, "invalid geometry");
-  SLV_CHECK_ARG(dy && x_in && tab && dw && (!bwd5 || x_out), "null pointer");
+  SLV_CHECK_ARG(dy && x_in && tab && dw, "null pointer");
+  SLV_CHECK_ARG(!bwd5 && !x_out, "the on-load BN-backward prologue was removed: materialise dXout with slv_bn_bwd_apply");
+  (void)a_relu;
   const Desc d = fwd_desc(g);
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
@@ -372,7 +376,7 @@ int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_out, con
   a.tapd = (const int*)(tab + 2 * kpad(d.Kd));
   a.Cin = g.Cin; a.Ti = g.Ti; a.Hi = g.Hi; a.Wi = g.Wi; a.Cout = g.Cout; a.To = g.To; a.Ho = g.Ho; a.Wo = g.Wo;
   a.st = g.st; a.sh = g.sh; a.sw = g.sw; a.pt = g.pt; a.ph = g.ph; a.pw = g.pw;
-  a.A = dy; a.A2 = x_out; a.pa = bwd5; a.a_pro = bwd5 ? PRO_BWD : PRO_NONE; a.a_relu = a_relu;
+  a.A = dy; a.a_pro = PRO_NONE;
   a.B = x_in; a.pb = in_scale_shift; a.b_pro = in_scale_shift ? PRO_ACT : PRO_NONE; a.b_relu = in_relu;
   a.A_bytes = a.A2_bytes = (unsigned)((size_t)g.Bn * g.Cout * g.To * g.Ho * g.Wo * 4);
   a.B_bytes = (unsigned)((size_t)g.Bn * g.Cin * g.Ti * g.Hi * g.Wi * 4);

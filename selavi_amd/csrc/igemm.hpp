@@ -12,8 +12,8 @@
 //   MODE_GEMM   C[m, n]   = sum_k A[m, k] * B[n, k]          (dense "NT" GEMM for the heads)
 // with the BatchNorm that surrounds every conv of the model fused into the operand loaders:
 //   PRO_ACT  v = relu?(x*scale[c] + shift[c])                (consumer-side BN apply + ReLU)
-//   PRO_BWD  v = A1[c]*mask*g + A2[c] + A3[c]*x              (BN backward of the conv's own output)
-// so activated tensors and BN input gradients are never materialised in HBM, and the forward
+// so activated tensors are never materialised in HBM (the BN-backward gradient is materialised once
+// per layer by slv_bn_bwd_apply: measured 1.8x faster than folding it into the loaders), and the forward
 // epilogue emits per-channel sum / sum-of-squares partials (training-mode batch statistics).
 //
 // Tiling (wave64, 256 threads = 4 waves): block tile (MT*16) x (NT*64) x 16; each wave owns all
@@ -115,7 +115,9 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 
 // VA: the A operand is read with 16-byte loads (4 consecutive k per lane).  Host-checked
 // preconditions: CONV/GEMM Kd % 4 == 0; WGRAD To*Ho*Wo % 4 == 0 and no A prologue.
-template <int MODE, int MT, int NT, bool VA>
+// PRO: prologue of the gathered B operand (PRO_NONE / PRO_ACT) -- a template parameter so that the
+// steady-state loop stays one basic block.
+template <int MODE, int MT, int NT, bool VA, int PRO>
 __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) void igemm_kernel(const IgemmArgs g) {
   constexpr int BM = MT * 16, BN = NT * 64;
   constexpr int AS = 18;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
   constexpr int A_ELEMS = BM * AS;
   constexpr int B_ELEMS = BKF ? BN * 18 : 16 * BS;
   constexpr int BROWS = BN / 16;  // B staging registers per thread (both layouts)
-  constexpr int P_ELEMS = (MODE == MODE_WGRAD) ? (5 * BM + 2 * BN) : 0;
+  constexpr int P_ELEMS = (MODE == MODE_WGRAD && PRO == PRO_ACT) ? 2 * BN : 0;
   __shared__ float smem[2 * (A_ELEMS + B_ELEMS) + P_ELEMS];
 
   const int tid = threadIdx.x;
@@ -149,10 +151,6 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)g.A_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)g.B_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rA2 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(g.A2 ? g.A2 : g.A), 0, (int)(g.A2 ? g.A2_bytes : 0), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB2 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(g.B2 ? g.B2 : g.B), 0, (int)(g.B2 ? g.B2_bytes : 0), 0x00020000);
 
   // ---- per-thread constants of the loaders
   const int a_kk = tid & 15, a_r = tid >> 4;  // K-contiguous loader: 16 k's x 16 rows per pass
@@ -203,22 +201,21 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
   }
 
   // staging registers hold RAW loaded values; masking + prologue math run in store_chunk
-  float ra[VA ? 1 : MT], ra2[VA ? 1 : MT];
+  float ra[VA ? 1 : MT];
   constexpr int NP = (BM + 63) / 64;  // VA: passes of 64 rows x 4 k-quads
   f32x4 ra4[VA ? NP : 1];
   (void)ra; (void)ra4;
   const int v_kq = tid & 3, v_mr = tid >> 2;
-  float rb[BROWS], rb2[BROWS];
+  float rb[BROWS];
   unsigned okA = 0, okB = 0;  // validity bits (only consulted when a prologue must be masked)
   float sp0[BROWS], sp1[BROWS];  // CONV + PRO_ACT: per-k scale/shift (wave-uniform)
   (void)sp0; (void)sp1;
-  (void)ra2; (void)rb2; (void)okA; (void)okB;
+  (void)okA; (void)okB;
 
   // WGRAD: loop-invariant table entries of this thread's B rows and per-channel params in LDS
   int wt_off[BROWS], wt_d[BROWS];
   (void)wt_off; (void)wt_d;
-  float* pAs = smem + 2 * (A_ELEMS + B_ELEMS);  // [5][BM]
-  float* pBs = pAs + 5 * BM;                    // [2][BN]
+  float* pBs = smem + 2 * (A_ELEMS + B_ELEMS);  // [2][BN]
   if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
@@ -227,16 +224,12 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
       wt_off[i] = e.x;
       wt_d[i] = ((e.y & 63) == 63) ? -1 : g.tapd[e.y & 63];
     }
-    for (int i = tid; i < 5 * BM; i += 256) {
-      const int which = i / BM, m = i - which * BM;
-      pAs[i] = (g.a_pro == PRO_BWD && m < mrem) ? g.pa[which * g.Cout + m0 + m] : 0.f;
-    }
-    for (int i = tid; i < 2 * BN; i += 256) {
-      const int which = i / BN, nn = i - which * BN;
-      const long long n = n0 + nn;
-      float v = 0.f;
-      if (g.b_pro == PRO_ACT && n < g.Ntot) v = g.pb[which * g.Cin + (g.tab[n].y >> 8)];
-      pBs[i] = v;
+    if constexpr (PRO == PRO_ACT) {
+      for (int i = tid; i < 2 * BN; i += 256) {
+        const int which = i / BN, nn = i - which * BN;
+        const long long n = n0 + nn;
+        pBs[i] = (n < g.Ntot) ? g.pb[which * g.Cin + (g.tab[n].y >> 8)] : 0.f;
+      }
     }
   }
 
@@ -283,9 +276,8 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
         const bool ok = (half >> (tap & 31)) & 1u;
         const unsigned off = ok ? ((lbase + (unsigned)e.x) << 2) : OOB;
         rb[q] = bload(rB, off);
-        if (g.b_pro == PRO_BWD) rb2[q] = bload(rB2, off);
         okB |= (ok ? 1u : 0u) << q;
-        if (g.b_pro == PRO_ACT) {  // wave-uniform scalar loads, consumed after the MFMAs of this chunk
+        if constexpr (PRO == PRO_ACT) {  // wave-uniform scalar loads, consumed after the MFMAs of this chunk
           sp0[q] = g.pb[e.y >> 8];
           sp1[q] = g.pb[g.Cb + (e.y >> 8)];
         }
@@ -323,7 +315,6 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
         for (int i = 0; i < MT; ++i) {
           const unsigned off = pok ? ((abase + (unsigned)(16 * i) * (unsigned)Pout) << 2) : OOB;
           ra[i] = bload(rA, off);
-          if (g.a_pro == PRO_BWD) ra2[i] = bload(rA2, off);
         }
       }
       // B[n][p] = act(X)[b][ci][in_pos(p, tap)]
@@ -362,20 +353,14 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int m = a_r + 16 * i;
-          float v = ra[i];
-          if (g.a_pro == PRO_BWD) {
-            v = apply_bwd(v, ra2[i], pAs[m], pAs[BM + m], pAs[2 * BM + m], pAs[3 * BM + m], pAs[4 * BM + m],
-                          g.a_relu);
-            v = okA ? v : 0.f;
-          }
-          As[m * AS + a_kk] = v;
+          As[m * AS + a_kk] = ra[i];
         }
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
         const int nn = a_r + 16 * i;
         float v = rb[i];
-        if (g.b_pro == PRO_ACT) {
+        if constexpr (PRO == PRO_ACT) {
           v = apply_act(v, pBs[nn], pBs[BN + nn], g.b_relu);
           v = ((okB >> i) & 1u) ? v : 0.f;
         }
@@ -395,15 +380,8 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
 #pragma unroll
         for (int q = 0; q < BROWS; ++q) {
           float v = rb[q];
-          if (g.b_pro != PRO_NONE) {
-            if (g.b_pro == PRO_ACT) {
-              v = apply_act(v, sp0[q], sp1[q], g.b_relu);  // params fetched with the data (no latency chain here)
-            } else {
-              const int ch = g.tab[c * 16 + kg * BROWS + q].y >> 8;
-              const int C_ = g.Cb;
-              v = apply_bwd(v, rb2[q], g.pb[ch], g.pb[C_ + ch], g.pb[2 * C_ + ch], g.pb[3 * C_ + ch],
-                            g.pb[4 * C_ + ch], g.b_relu);
-            }
+          if constexpr (PRO == PRO_ACT) {
+            v = apply_act(v, sp0[q], sp1[q], g.b_relu);  // params fetched with the data (no latency chain here)
             v = ((okB >> q) & 1u) ? v : 0.f;
           }
           Bs[(kg * BROWS + q) * BS + nl] = v;
@@ -451,13 +429,16 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
     load_chunk(0);
     store_chunk(0, 0);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-      const bool more = c + 1 < nchunks;
-      if (more) load_chunk(c + 1);
+    // steady state is ONE basic block (no conditionals): the compiler interleaves the next chunk's
+    // loads, this chunk's MFMAs and the LDS writes; any branch in here costs 30-40 % (measured).
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      load_chunk(c + 1);
       compute(c & 1, full_tag);
-      if (more) store_chunk((c + 1) & 1, c + 1);
+      store_chunk((c + 1) & 1, c + 1);
       __syncthreads();
     }
+    compute((nchunks - 1) & 1, full_tag);
+    __syncthreads();
   };
   if (nchunks > 0) {
     if (mtv >= MT) main_loop(std::true_type{});
@@ -571,8 +552,15 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
 template <int MODE, int MT, int NT>
 inline void launch_igemm(const IgemmArgs& a, int splits, bool vec_a, hipStream_t st) {
   dim3 grid(a.nblkM * a.nblkN * splits, 1, 1);
-  if (vec_a) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, false>), grid, dim3(256), 0, st, a);
+  const bool act = (MODE != MODE_GEMM) && a.b_pro == PRO_ACT;
+#define SLV_L(VA_, PRO_) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, VA_, PRO_>), grid, dim3(256), 0, st, a)
+  if constexpr (MODE == MODE_GEMM) {
+    if (vec_a) SLV_L(true, PRO_NONE); else SLV_L(false, PRO_NONE);
+  } else {
+    if (vec_a) { if (act) SLV_L(true, PRO_ACT); else SLV_L(true, PRO_NONE); }
+    else { if (act) SLV_L(false, PRO_ACT); else SLV_L(false, PRO_NONE); }
+  }
+#undef SLV_L
 }
 
 // choose the row-tile: returns MT for a given M (rows) -- see header comment

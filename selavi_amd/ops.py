@@ -86,16 +86,19 @@ def conv_wt_transform(plan, w, out=None):
 
 def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out=None):
     dx = out if out is not None else _f32(*plan.in_shape, device=dy.device)
-    C.slv_conv_dgrad(plan.gp, ptr(dy), ptr(x_out), ptr(wt), ptr(plan.tab_dgrad), ptr(bwd5), int(relu), ptr(dx),
-                     ptr(addend), stream())
+    if bwd5 is not None:     # BN backward of the conv's own output: materialised, then a plain dgrad
+        dy = bn_bwd_apply(dy, x_out, bwd5, relu, out=torch.empty_like(dy))
+    C.slv_conv_dgrad(plan.gp, ptr(dy), 0, ptr(wt), ptr(plan.tab_dgrad), 0, 0, ptr(dx), ptr(addend), stream())
     return dx
 
 
 def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, in_relu=False, out=None):
     dw = out if out is not None else _f32(plan.Cout, plan.Cin * plan.taps, device=dy.device)
     ws = workspace(plan.ws_bytes, dy.device) if plan.ws_bytes else None
-    C.slv_conv_wgrad(plan.gp, ptr(dy), ptr(x_out), ptr(bwd5), int(a_relu), ptr(x_in), ptr(in_ss), int(in_relu),
-                     ptr(plan.tab_fwd), ptr(dw), ptr(ws), plan.ws_bytes, stream())
+    if bwd5 is not None:
+        dy = bn_bwd_apply(dy, x_out, bwd5, a_relu, out=torch.empty_like(dy))
+    C.slv_conv_wgrad(plan.gp, ptr(dy), 0, 0, 0, ptr(x_in), ptr(in_ss), int(in_relu), ptr(plan.tab_fwd), ptr(dw),
+                     ptr(ws), plan.ws_bytes, stream())
     return dw
 
 
