@@ -177,7 +177,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
-    from selavi_amd import model as smodel, optim, train
+    from selavi_amd import model as smodel, ops, optim, train
+    ops.set_benchmark(True)          # main.py:187 cudnn.benchmark = True: per-shape launch-config timing (in warm-up)
     B, hc, K = a.batch, CFG2["hc"], CFG2["K"]
     torch.manual_seed(31)            # opt.py:152
     m = smodel.load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', use_mlp=True, num_classes=K,

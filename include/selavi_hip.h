@@ -98,31 +98,38 @@ int slv_sk_labels(const double* P, int64_t N_local, int K, const double* beta, v
  *   in_scale_shift [2][Cin]  : the input is read as relu?(x*scale[c] + shift[c]) (zero padding applied
  *                              AFTER the affine), i.e. the producer's BN+ReLU is applied on load;
  *   stat_sum/stat_sq [Cout][slv_conv_fwd_nblk()] : per-channel partial sum / sum of squares of y;
- *   bwd5 [5][Cout] = {s, h, A1, A2, A3} : the gradient w.r.t. the raw conv output is formed on load
- *                              as A1*mask*g + A2 + A3*x with mask = relu ? (s*x + h > 0) : 1
- *                              (BN backward folded into per-channel coefficients, slv_bn_bwd_finalize).
+ * The backward GEMMs take the gradient w.r.t. the RAW conv output (dXout), which slv_bn_bwd_apply
+ * materialises once per layer from the folded BN-backward coefficients of slv_bn_bwd_finalize.
  */
 /* gather tables (host side, upload once per layer): dgrad == 0 -> forward / weight-gradient table,
  * dgrad == 1 -> one table block per stride-parity class of the backward-data conv.  _len = int32 words. */
 int32_t slv_conv_table_len(const int32_t* geom, int dgrad);
 int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out /* host, table_len words */);
-int32_t slv_conv_fwd_nblk(const int32_t* geom);
+/* Launch configuration `cfg`: 0 = built-in heuristic, otherwise one of the values enumerated by
+ * slv_conv_configs (tile rows/16 | tile cols/64 << 8 | K-slices << 16).  The host may time the
+ * candidates once per layer shape -- what the reference gets from cudnn.benchmark = True (main.py:187).
+ * op: 0 forward, 1 backward-data, 2 backward-weight.  Returns the number of candidates written. */
+int32_t slv_conv_configs(const int32_t* geom, int op, int32_t* cfg_out, int32_t max_out);
+int32_t slv_conv_fwd_nblk(const int32_t* geom, int32_t cfg);
+/* split-K scratch (late layers: few columns, deep K): 0 when the layer runs unsplit */
+size_t slv_conv_fwd_ws_bytes(const int32_t* geom, int32_t cfg);
 int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const int32_t* tab,
                  const float* in_scale_shift /* nullable */, int in_relu, float* y,
-                 float* stat_sum /* nullable */, float* stat_sq, slv_stream_t stream);
+                 float* stat_sum /* nullable */, float* stat_sq, void* ws /* nullable if 0 bytes */,
+                 size_t ws_bytes, int32_t cfg, slv_stream_t stream);
 /* backward-data weights: per stride-parity class c a K-contiguous matrix wt_c[ci][co*ntaps_c + j] =
  * w[co][ci][tap_j], classes concatenated (same element count as w) */
 int slv_conv_wt_transform(const int32_t* geom, const float* w, float* wt, slv_stream_t stream);
-/* dx = conv_transpose(dXout) (+ addend);  dXout = bwd5 ? fused(dy, x_out) : dy.  tab = dgrad table */
-int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* x_out /* nullable */,
-                   const float* wt, const int32_t* tab, const float* bwd5 /* nullable */, int relu,
-                   float* dx, const float* addend /* nullable, may alias dx */, slv_stream_t stream);
-size_t slv_conv_wgrad_ws_bytes(const int32_t* geom);
-/* dw = sum_p dXout[co,p] * act(x_in)[ci, p*stride+tap-pad]; deterministic split-K via `ws`.  tab = fwd table */
-int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_out /* nullable */,
-                   const float* bwd5 /* nullable */, int a_relu, const float* x_in,
+/* dx = conv_transpose(dy) (+ addend);  dy = gradient w.r.t. the raw conv output.  tab = dgrad table */
+size_t slv_conv_dgrad_ws_bytes(const int32_t* geom, int32_t cfg);
+int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* wt, const int32_t* tab,
+                   float* dx, const float* addend /* nullable, may alias dx */, void* ws /* nullable if 0 bytes */,
+                   size_t ws_bytes, int32_t cfg, slv_stream_t stream);
+size_t slv_conv_wgrad_ws_bytes(const int32_t* geom, int32_t cfg);
+/* dw = sum_p dy[co,p] * act(x_in)[ci, p*stride+tap-pad]; deterministic split-K via `ws`.  tab = fwd table */
+int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_in,
                    const float* in_scale_shift /* nullable */, int in_relu, const int32_t* tab,
-                   float* dw, void* ws, size_t ws_bytes, slv_stream_t stream);
+                   float* dw, void* ws, size_t ws_bytes, int32_t cfg, slv_stream_t stream);
 /* C[m][n] = sum_k A[m][k] * B[n][k] (+ bias[n]);  A [M][K], B [N][K] row-major (nn.Linear layout) */
 int slv_gemm_nt(const float* A, const float* B, const float* bias /* nullable */, float* C, int M,
                 int N, int K, int ldc, slv_stream_t stream);

@@ -168,6 +168,84 @@ static void pick_tile(int M, long long ncols, int* mt_out, int* nt_out) {
   }
 }
 
+// Split-K for the CONV launches of the late layers: with B*T*H*W of a few thousand columns even the
+// smallest tile leaves most CUs idle, but K = Cin*taps is thousands deep.  The K range is cut into
+// `splits` slices, each slice writes a private partial output (workspace) and a fixed-order reduce
+// kernel sums them (+ residual addend / BN statistics).  Deterministic; no atomics.
+static int conv_max_splits() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SLV_CONV_SPLITS");
+    v = e ? atoi(e) : 8;
+    if (v < 1) v = 1;
+    if (v > 16) v = 16;
+  }
+  return v;
+}
+static void plan_conv(int M, long long ncols, int Kd, int* mt_out, int* nt_out, int* splits_out) {
+  *splits_out = 1;
+  const int mt = pick_mt(M), nt = mt >= 15 ? 1 : 2;
+  const long long blocks = (long long)((M + mt * 16 - 1) / (mt * 16)) * ((ncols + nt * 64 - 1) / (nt * 64));
+  if (blocks > 0 && blocks < 768) {
+    const int chunks = (Kd + 15) / 16;
+    static const int target = getenv("SLV_SPLIT_TARGET") ? atoi(getenv("SLV_SPLIT_TARGET")) : 1536;
+    static const int minch = getenv("SLV_SPLIT_MINCH") ? atoi(getenv("SLV_SPLIT_MINCH")) : 32;
+    long long sp = (target + blocks - 1) / blocks;
+    if (sp > chunks / minch) sp = chunks / minch;   // >= 32 chunks (512 k) per slice
+    if (sp > conv_max_splits()) sp = conv_max_splits();
+    if (sp >= 2) {
+      const int cps = (chunks + (int)sp - 1) / (int)sp;
+      *mt_out = mt;
+      *nt_out = nt;
+      *splits_out = (chunks + cps - 1) / cps;
+      return;
+    }
+  }
+  pick_tile(M, ncols, mt_out, nt_out);
+}
+
+// out[i] = sum_s partial[s][i] (+ addend[i])   (fixed order; addend may alias out)
+__global__ void conv_splitk_reduce_kernel(const float* __restrict__ part, const float* addend, float* out, size_t n,
+                                          int splits) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = part[i];
+    for (int s = 1; s < splits; ++s) v += part[(size_t)s * n + i];
+    if (addend) v += addend[i];
+    out[i] = v;
+  }
+}
+// forward conv: y = sum of the K-slice partials + the per-channel statistics partials the fused epilogue
+// would have produced.  One wave per (channel, column block of BN lattice columns).
+__global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(const float* __restrict__ part,
+                                                                        float* __restrict__ y, float* __restrict__ ssum,
+                                                                        float* __restrict__ ssq, int M, long long Ntot,
+                                                                        int P, int BN, int nblkN, size_t total,
+                                                                        int splits) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long long n0 = (long long)blockIdx.x * BN;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < BN; c += 64) {
+    const long long n = n0 + c;
+    if (n < Ntot) {
+      const long long b = n / P;
+      const size_t ad = ((size_t)b * M + m) * P + (size_t)(n - b * P);
+      float v = part[ad];
+      for (int s = 1; s < splits; ++s) v += part[(size_t)s * total + ad];
+      y[ad] = v;
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    ssum[(size_t)m * nblkN + blockIdx.x] = s1;
+    ssq[(size_t)m * nblkN + blockIdx.x] = s2;
+  }
+}
+
 template <int MODE>
 static int dispatch(const IgemmArgs& a0, int mt, int nt, int splits, hipStream_t st) {
   IgemmArgs a = a0;
@@ -275,31 +353,172 @@ int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out) {
   return 0;
 }
 
-int32_t slv_conv_fwd_nblk(const int32_t* geom) {
-  Geom g;
-  if (read_geom(geom, g) != 0) return -1;
+// ---- launch configurations --------------------------------------------------------------------
+// cfg == 0: built-in heuristic.  Otherwise mt | nt << 8 | splits << 16, one of slv_conv_configs():
+// the host may time the candidates once per layer shape, which is what the reference does through
+// cudnn.benchmark = True (main.py:187).
+struct Cfg {
+  int mt, nt, sp;
+};
+static bool tile_ok(int mt, int nt) {
+  return ((mt == 4 || mt == 8 || mt == 9) && (nt == 1 || nt == 2)) || (mt == 15 && nt == 1);
+}
+static int32_t pack_cfg(int mt, int nt, int sp) { return mt | (nt << 8) | (sp << 16); }
+static int unpack_cfg(int32_t cfg, Cfg& c) {
+  c.mt = cfg & 255; c.nt = (cfg >> 8) & 255; c.sp = (cfg >> 16) & 0x7FFF;
+  return (tile_ok(c.mt, c.nt) && c.sp >= 1) ? 0 : -1;
+}
+static int clamp_splits(int sp, long long chunks) {
+  if (sp > chunks) sp = (int)(chunks > 0 ? chunks : 1);
+  if (sp < 1) sp = 1;
+  const long long cps = (chunks + sp - 1) / sp;
+  return cps > 0 ? (int)((chunks + cps - 1) / cps) : 1;   // no empty slices
+}
+static int fwd_cfg(const Geom& g, int32_t cfg, Cfg& c) {
   const long long P = (long long)g.Bn * g.To * g.Ho * g.Wo;
-  int mt, nt;
-  pick_tile(g.Cout, P, &mt, &nt);
-  return (int32_t)((P + nt * 64 - 1) / (nt * 64));
+  const int Kd = g.Cin * g.kt * g.kh * g.kw;
+  if (cfg == 0) { plan_conv(g.Cout, P, Kd, &c.mt, &c.nt, &c.sp); return 0; }
+  if (unpack_cfg(cfg, c) != 0 || c.sp > 64) return -1;
+  c.sp = clamp_splits(c.sp, (Kd + 15) / 16);
+  return 0;
+}
+// backward-data: per parity class tile (heuristic) or one tile for all (cfg); one common slice count
+static int dgrad_cfg(const Geom& g, const Desc* ds, int n, int32_t cfg, Cfg* per_class, int* sp_out) {
+  int sp = 1;
+  if (cfg == 0) {
+    for (int i = 0; i < n; ++i) {
+      plan_conv(ds[i].M, ds[i].Ntot, ds[i].Kd, &per_class[i].mt, &per_class[i].nt, &per_class[i].sp);
+      if (per_class[i].sp > sp) sp = per_class[i].sp;
+    }
+  } else {
+    Cfg c;
+    if (unpack_cfg(cfg, c) != 0 || c.sp > 64) return -1;
+    int maxchunks = 1;
+    for (int i = 0; i < n; ++i) {
+      per_class[i] = c;
+      if ((ds[i].Kd + 15) / 16 > maxchunks) maxchunks = (ds[i].Kd + 15) / 16;
+    }
+    sp = clamp_splits(c.sp, maxchunks);
+  }
+  *sp_out = sp;
+  return 0;
+}
+static int wgrad_cfg(const Geom& g, int32_t cfg, Cfg& c) {
+  const long long chunks = ((long long)g.Bn * g.To * g.Ho * g.Wo + 15) / 16;
+  if (cfg == 0) {
+    c.mt = pick_mt(g.Cout);
+    c.nt = c.mt >= 15 ? 1 : 2;
+    c.sp = wgrad_splits(g, c.mt, c.nt);
+    return 0;
+  }
+  if (unpack_cfg(cfg, c) != 0 || c.sp > 1024) return -1;
+  c.sp = clamp_splits(c.sp, chunks);
+  return 0;
+}
+
+int32_t slv_conv_configs(const int32_t* geom, int op, int32_t* out, int32_t max_out) {
+  Geom g;
+  if (read_geom(geom, g) != 0 || !out || max_out <= 0 || op < 0 || op > 2) return -1;
+  static const int tiles[7][2] = {{9, 2}, {8, 2}, {15, 1}, {4, 2}, {9, 1}, {8, 1}, {4, 1}};
+  const int taps = g.kt * g.kh * g.kw;
+  int M;
+  long long N, chunks;
+  if (op == 0) { M = g.Cout; N = (long long)g.Bn * g.To * g.Ho * g.Wo; chunks = (g.Cin * taps + 15) / 16; }
+  else if (op == 1) {
+    Desc ds[8];
+    const int n = dgrad_descs(g, ds);
+    M = g.Cin; N = 0; chunks = 1;
+    for (int i = 0; i < n; ++i) {
+      if (ds[i].Ntot > N) N = ds[i].Ntot;
+      if ((ds[i].Kd + 15) / 16 > chunks) chunks = (ds[i].Kd + 15) / 16;
+    }
+  } else { M = g.Cout; N = (long long)g.Cin * taps; chunks = ((long long)g.Bn * g.To * g.Ho * g.Wo + 15) / 16; }
+  long long minpad = 1LL << 62;
+  for (const auto& t : tiles) {
+    const long long bm = t[0] * 16, bn = t[1] * 64;
+    const long long pad = ((M + bm - 1) / bm) * bm * (((N + bn - 1) / bn) * bn);
+    if (pad < minpad) minpad = pad;
+  }
+  int cnt = 0;
+  for (const auto& t : tiles) {
+    const long long bm = t[0] * 16, bn = t[1] * 64;
+    const long long nb = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    if ((double)(nb * bm * bn) > 1.35 * (double)minpad) continue;   // too much padded work
+    int cand[12], nc = 0;
+    if (op != 2) {
+      static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+      for (int sp : sps) {
+        if (sp > 1 && (nb >= 1536 || chunks / sp < 8 || nb * sp > 8192)) continue;
+        cand[nc++] = sp;
+      }
+    } else {
+      const int s0 = wgrad_splits(g, t[0], t[1]);
+      const int raw[5] = {s0 / 2, (s0 * 3) / 4, s0, (s0 * 3) / 2, s0 * 2};
+      for (int r : raw) {
+        const int sp = clamp_splits(r, chunks);
+        bool dup = false;
+        for (int j = 0; j < nc; ++j) dup |= cand[j] == sp;
+        if (!dup) cand[nc++] = sp;
+      }
+    }
+    for (int j = 0; j < nc && cnt < max_out; ++j) out[cnt++] = pack_cfg(t[0], t[1], cand[j]);
+  }
+  return cnt;
+}
+
+int32_t slv_conv_fwd_nblk(const int32_t* geom, int32_t cfg) {
+  Geom g;
+  Cfg c;
+  if (read_geom(geom, g) != 0 || fwd_cfg(g, cfg, c) != 0) return -1;
+  const long long P = (long long)g.Bn * g.To * g.Ho * g.Wo;
+  return (int32_t)((P + c.nt * 64 - 1) / (c.nt * 64));
+}
+
+size_t slv_conv_fwd_ws_bytes(const int32_t* geom, int32_t cfg) {
+  Geom g;
+  Cfg c;
+  if (read_geom(geom, g) != 0 || fwd_cfg(g, cfg, c) != 0) return 0;
+  const long long P = (long long)g.Bn * g.To * g.Ho * g.Wo;
+  return c.sp > 1 ? sizeof(float) * (size_t)c.sp * g.Cout * (size_t)P : 0;
 }
 
 int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const int32_t* tab,
                  const float* in_scale_shift, int in_relu, float* y, float* stat_sum, float* stat_sq,
-                 slv_stream_t stream) {
+                 void* ws, size_t ws_bytes, int32_t cfg, slv_stream_t stream) {
   Geom g;
   SLV_CHECK_ARG(read_geom(geom, g) == 0, "invalid geometry");
   SLV_CHECK_ARG(x && w && tab && y, "null pointer");
+  Cfg c;
+  SLV_CHECK_ARG(fwd_cfg(g, cfg, c) == 0, "invalid launch configuration");
   const Desc d = fwd_desc(g);
   IgemmArgs a;
   conv_args(a, g, d, tab);
   a.A = w; a.B = x; a.C = y;
   a.pb = in_scale_shift; a.b_pro = in_scale_shift ? PRO_ACT : PRO_NONE; a.b_relu = in_relu;
   a.stat_sum = stat_sum; a.stat_sq = stat_sq;
-  int mt, nt;
-  pick_tile(a.M, a.Ntot, &mt, &nt);
-  SLV_CHECK_ARG(dispatch<MODE_CONV>(a, mt, nt, 1, (hipStream_t)stream) == 0, "no kernel for tile");
+  const int mt = c.mt, nt = c.nt, sp = c.sp;
+  const size_t total = (size_t)g.Cout * (size_t)a.Ntot;
+  if (sp > 1) {
+    SLV_CHECK_ARG(ws && ws_bytes >= sizeof(float) * total * sp, "workspace too small (slv_conv_fwd_ws_bytes)");
+    a.C = (float*)ws; a.stat_sum = a.stat_sq = nullptr;
+    a.split_stride = (long long)total;
+    const int chunks = (a.Kd + 15) / 16;
+    a.chunks_per_split = (chunks + sp - 1) / sp;
+  }
+  SLV_CHECK_ARG(dispatch<MODE_CONV>(a, mt, nt, sp, (hipStream_t)stream) == 0, "no kernel for tile");
   SLV_LAUNCH_CHECK();
+  if (sp > 1) {
+    if (stat_sum) {
+      const int bn = nt * 64, nblkN = (int)((a.Ntot + bn - 1) / bn);
+      hipLaunchKernelGGL(conv_splitk_reduce_stats_kernel, dim3(nblkN, (g.Cout + 3) / 4), dim3(256), 0,
+                         (hipStream_t)stream, (const float*)ws, y, stat_sum, stat_sq, g.Cout, a.Ntot,
+                         g.To * g.Ho * g.Wo, bn, nblkN, total, sp);
+    } else {
+      hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)),
+                         dim3(256), 0, (hipStream_t)stream, (const float*)ws, (const float*)nullptr, y, total, sp);
+    }
+    SLV_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -328,46 +547,67 @@ int slv_conv_wt_transform(const int32_t* geom, const float* w, float* wt, slv_st
   return 0;
 }
 
-int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* x_out, const float* wt,
-                   const int32_t* tab, const float* bwd5, int relu, float* dx, const float* addend,
-                   slv_stream_t stream) {
+size_t slv_conv_dgrad_ws_bytes(const int32_t* geom, int32_t cfg) {
+  Geom g;
+  if (read_geom(geom, g) != 0) return 0;
+  Desc ds[8];
+  Cfg pc[8];
+  int sp;
+  const int n = dgrad_descs(g, ds);
+  if (dgrad_cfg(g, ds, n, cfg, pc, &sp) != 0) return 0;
+  return sp > 1 ? sizeof(float) * (size_t)sp * g.Bn * g.Cin * g.Ti * g.Hi * g.Wi : 0;
+}
+
+int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* wt, const int32_t* tab, float* dx,
+                   const float* addend, void* ws, size_t ws_bytes, int32_t cfg, slv_stream_t stream) {
   Geom g;
   SLV_CHECK_ARG(read_geom(geom, g) == 0, "invalid geometry");
   SLV_CHECK_ARG(dy && wt && tab && dx, "null pointer");
-  SLV_CHECK_ARG(!bwd5 && !x_out, "the on-load BN-backward prologue was removed: materialise dXout with slv_bn_bwd_apply");
-  (void)relu;
   Desc ds[8];
+  Cfg pc[8];
+  int sp;
   const int n = dgrad_descs(g, ds);
+  SLV_CHECK_ARG(dgrad_cfg(g, ds, n, cfg, pc, &sp) == 0, "invalid launch configuration");
+  const size_t total = (size_t)g.Bn * g.Cin * g.Ti * g.Hi * g.Wi;
+  if (sp > 1) SLV_CHECK_ARG(ws && ws_bytes >= sizeof(float) * total * sp, "workspace too small (slv_conv_dgrad_ws_bytes)");
   for (int i = 0; i < n; ++i) {
     const Desc& d = ds[i];
     IgemmArgs a;
     conv_args(a, g, d, tab);
-    a.A = wt + d.wt_off; a.B = dy; a.B2 = x_out; a.C = dx; a.E = addend;
+    a.A = wt + d.wt_off; a.B = dy; a.C = dx; a.E = addend;
     a.b_pro = PRO_NONE;
-    int mt, nt;
-    pick_tile(a.M, a.Ntot, &mt, &nt);
-    SLV_CHECK_ARG(dispatch<MODE_CONV>(a, mt, nt, 1, (hipStream_t)stream) == 0, "no kernel for tile");
+    if (sp > 1) {
+      a.C = (float*)ws; a.E = nullptr;
+      a.split_stride = (long long)total;
+      const int chunks = (a.Kd + 15) / 16;
+      a.chunks_per_split = chunks > 0 ? (chunks + sp - 1) / sp : 1;
+    }
+    SLV_CHECK_ARG(dispatch<MODE_CONV>(a, pc[i].mt, pc[i].nt, sp, (hipStream_t)stream) == 0, "no kernel for tile");
+    SLV_LAUNCH_CHECK();
+  }
+  if (sp > 1) {
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)),
+                       dim3(256), 0, (hipStream_t)stream, (const float*)ws, addend, dx, total, sp);
     SLV_LAUNCH_CHECK();
   }
   return 0;
 }
 
-size_t slv_conv_wgrad_ws_bytes(const int32_t* geom) {
+size_t slv_conv_wgrad_ws_bytes(const int32_t* geom, int32_t cfg) {
   Geom g;
-  if (read_geom(geom, g) != 0) return 0;
-  const int mt = pick_mt(g.Cout);
-  const int s = wgrad_splits(g, mt, mt >= 15 ? 1 : 2);
-  return s > 1 ? sizeof(float) * (size_t)s * g.Cout * g.Cin * g.kt * g.kh * g.kw : 0;
+  Cfg c;
+  if (read_geom(geom, g) != 0 || wgrad_cfg(g, cfg, c) != 0) return 0;
+  return c.sp > 1 ? sizeof(float) * (size_t)c.sp * g.Cout * g.Cin * g.kt * g.kh * g.kw : 0;
 }
 
-int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_out, const float* bwd5, int a_relu,
-                   const float* x_in, const float* in_scale_shift, int in_relu, const int32_t* tab,
-                   float* dw, void* ws, size_t ws_bytes, slv_stream_t stream) {
+int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_in, const float* in_scale_shift,
+                   int in_relu, const int32_t* tab, float* dw, void* ws, size_t ws_bytes, int32_t cfg,
+                   slv_stream_t stream) {
   Geom g;
   SLV_CHECK_ARG(read_geom(geom, g) == 0, "invalid geometry");
   SLV_CHECK_ARG(dy && x_in && tab && dw, "null pointer");
-  SLV_CHECK_ARG(!bwd5 && !x_out, "the on-load BN-backward prologue was removed: materialise dXout with slv_bn_bwd_apply");
-  (void)a_relu;
+  Cfg c;
+  SLV_CHECK_ARG(wgrad_cfg(g, cfg, c) == 0, "invalid launch configuration");
   const Desc d = fwd_desc(g);
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
@@ -386,9 +626,7 @@ int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_out, con
   a.dPout = make_fastdiv((unsigned)(g.To * g.Ho * g.Wo));
   a.dHoWo = make_fastdiv((unsigned)(g.Ho * g.Wo));
   a.dWo = make_fastdiv((unsigned)g.Wo);
-  const int mt = pick_mt(a.M);
-  const int nt = mt >= 15 ? 1 : 2;
-  const int splits = wgrad_splits(g, mt, nt);
+  const int mt = c.mt, nt = c.nt, splits = c.sp;
   const long long chunks = (a.Ptot + 15) / 16;
   a.chunks_per_split = (int)((chunks + splits - 1) / splits);
   const size_t nel = (size_t)g.Cout * g.Cin * taps;

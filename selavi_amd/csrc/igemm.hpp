@@ -91,7 +91,8 @@ struct IgemmArgs {
   int a_pro, b_pro, a_relu, b_relu;
   // WGRAD geometry
   int Cin, Ti, Hi, Wi, Cout, To, Ho, Wo, st, sh, sw, pt, ph, pw;
-  int chunks_per_split;
+  int chunks_per_split;   // WGRAD: always; CONV: > 0 selects split-K (partials to C + split*split_stride)
+  long long split_stride; // CONV split-K: elements between the partial outputs of consecutive K-slices
   long long Ptot;
   int ldc;
   FastDiv dPout, dHoWo, dWo;
@@ -199,6 +200,16 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
   } else {
     nchunks = (g.Kd + 15) / 16;
   }
+  int kbase = 0;  // CONV split-K: first k of this block's K-slice
+  if constexpr (MODE == MODE_CONV) {
+    if (g.chunks_per_split > 0) {
+      const int c0 = split * g.chunks_per_split;
+      int c1 = c0 + g.chunks_per_split;
+      if (c1 > nchunks) c1 = nchunks;
+      nchunks = c1 > c0 ? c1 - c0 : 0;
+      kbase = c0 * 16;
+    }
+  }
 
   // staging registers hold RAW loaded values; masking + prologue math run in store_chunk
   float ra[VA ? 1 : MT];
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
   // reference and drags the accumulators into scratch memory.
   // ---------------------------------------------------------------- global -> registers (raw, branch-free)
   auto load_chunk = [&](int c) __attribute__((always_inline)) {
-    const int k0 = c * 16;
+    const int k0 = kbase + c * 16;
     if constexpr (MODE != MODE_WGRAD) {
       // A: dense [M][Kd]; rows >= M fall outside the buffer (-> 0), the k tail is neutralised by B == 0
       if constexpr (VA) {
@@ -449,6 +460,7 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
   // accumulator layout: row = i*16 + fk*4 + r, col = (wave*NT + j)*16 + fi
   if constexpr (MODE == MODE_CONV) {
     const int dP = g.D0 * g.D1 * g.D2;
+    float* Cp = g.C + (size_t)split * (size_t)g.split_stride;  // split-K: slice-private partial output
     size_t obase[NT];
     bool cok[NT];
     const int NQ = g.Q0 * g.Q1 * g.Q2, Q12 = g.Q1 * g.Q2;
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
                 const size_t ad = obase[j] + (size_t)(m0 + m) * dP;
                 float v = acc[i][j][r];
                 if (g.E) v += g.E[ad];
-                g.C[ad] = v;
+                Cp[ad] = v;
               }
             }
           }

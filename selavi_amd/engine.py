@@ -5,8 +5,9 @@ Every conv of R(2+1)D-18 / ResNet-9 is followed by a BatchNorm (torchvision nets
 /root/reference/model.py:95,114).  The engine keeps only the RAW conv outputs in HBM; BN(+ReLU) is
 applied when the consumer loads the tensor (PRO_ACT), batch statistics come out of the producing
 conv's epilogue, and in the backward pass BN-backward is folded into per-channel coefficients
-(bwd5) applied when dgrad/wgrad load the gradient (PRO_BWD).  Only block outputs (two consumers)
-are materialised.  See csrc/igemm.hpp.
+(bwd5) with which the conv-output gradient is materialised ONCE per layer (slv_bn_bwd_apply) and then
+read by both dgrad and wgrad.  In the forward pass only block outputs (two consumers) are
+materialised.  See csrc/igemm.hpp.
 """
 import torch
 

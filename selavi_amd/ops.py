@@ -1,6 +1,7 @@
 """Thin Python wrappers over the C ABI (include/selavi_hip.h).  torch is used only to own device
 memory and streams; every numeric op below is a hand-written HIP kernel in libselavi_hip.so."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -39,11 +40,27 @@ class ConvPlan:
         C.slv_conv_table(self.gp, 1, td.ctypes.data)
         self.tab_fwd = torch.from_numpy(tf).to(device)
         self.tab_dgrad = torch.from_numpy(td).to(device)
-        self.nblk = C.slv_conv_fwd_nblk(self.gp)
-        self.ws_bytes = C.slv_conv_wgrad_ws_bytes(self.gp)
         self.count = float(Bn * To * Ho * Wo)          # elements per channel of the output
         self.P_out = To * Ho * Wo
         self.P_in = Ti * Hi * Wi
+        self.set_configs(0, 0, 0)
+        if benchmark:
+            _autotune(self)
+
+    def set_configs(self, cfg_fwd, cfg_dgrad, cfg_wgrad):
+        """Launch configurations (0 = built-in heuristic) and the scratch sizes that follow from them."""
+        self.cfg_fwd, self.cfg_dgrad, self.cfg_wgrad = int(cfg_fwd), int(cfg_dgrad), int(cfg_wgrad)
+        self.nblk = C.slv_conv_fwd_nblk(self.gp, self.cfg_fwd)
+        if self.nblk <= 0:
+            raise ValueError(f"invalid forward launch configuration {self.cfg_fwd:#x}")
+        self.ws_fwd = C.slv_conv_fwd_ws_bytes(self.gp, self.cfg_fwd)       # split-K scratch, 0 if unsplit
+        self.ws_dgrad = C.slv_conv_dgrad_ws_bytes(self.gp, self.cfg_dgrad)
+        self.ws_bytes = C.slv_conv_wgrad_ws_bytes(self.gp, self.cfg_wgrad)
+
+    def candidates(self, op):
+        buf = np.empty(128, dtype=np.int32)
+        n = C.slv_conv_configs(self.gp, op, buf.ctypes.data, buf.size)
+        return [int(v) for v in buf[:n]]
 
     @classmethod
     def get(cls, in_shape, Cout, k, stride, pad, device):
@@ -54,11 +71,69 @@ class ConvPlan:
         return p
 
 
+# Per-layer-shape timing of the launch configurations at plan creation -- the counterpart of
+# `cudnn.benchmark = True` (/root/reference/main.py:187).  Off by default (deterministic heuristics);
+# selavi_amd.train / bench.py switch it on.  SELAVI_BENCHMARK=0/1 overrides.
+benchmark = os.environ.get("SELAVI_BENCHMARK", "0") == "1"
+_tune_log = []
+
+
+def set_benchmark(flag):
+    global benchmark
+    if "SELAVI_BENCHMARK" not in os.environ:
+        benchmark = bool(flag)
+
+
+def _time_call(fn, reps=3):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _autotune(plan):
+    """Time every candidate configuration of the three GEMMs of this layer on scratch tensors and keep
+    the fastest.  Summation order inside a K-split differs between configurations, so results are
+    reproducible only for a fixed choice -- same caveat as cudnn.benchmark."""
+    dev = plan.device
+    x = torch.randn(plan.in_shape, device=dev)
+    w = torch.randn(plan.Cout, plan.Cin * plan.taps, device=dev) * 0.05
+    ss = torch.stack([torch.rand(plan.Cin, device=dev) + 0.5, torch.randn(plan.Cin, device=dev) * 0.1]).contiguous()
+    dy = torch.randn(plan.out_shape, device=dev)
+    wt = conv_wt_transform(plan, w)
+    best = [0, 0, 0]
+    times = [None, None, None]   # (best ms, heuristic ms)
+    for op in range(3):
+        for cfg in [0] + plan.candidates(op):
+            cfgs = [plan.cfg_fwd, plan.cfg_dgrad, plan.cfg_wgrad]
+            cfgs[op] = cfg
+            plan.set_configs(*cfgs)
+            if op == 0:
+                t = _time_call(lambda: conv_fwd(plan, x, w, in_ss=ss, in_relu=True))
+            elif op == 1:
+                t = _time_call(lambda: conv_dgrad(plan, dy, wt))
+            else:
+                t = _time_call(lambda: conv_wgrad(plan, dy, x, in_ss=ss, in_relu=True))
+            if times[op] is None:
+                times[op] = (t, t)
+            elif t < times[op][0] * 0.97:       # 3 % hysteresis in favour of the earlier candidate
+                times[op] = (t, times[op][1])
+                best[op] = cfg
+        cfgs = [plan.cfg_fwd, plan.cfg_dgrad, plan.cfg_wgrad]
+        cfgs[op] = best[op]
+        plan.set_configs(*cfgs)
+    _tune_log.append((plan.in_shape, plan.Cout, tuple(best), tuple((round(a, 4), round(b, 4)) for a, b in times)))
+
+
 _ws_cache = {}
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer shared by all wgrad calls on a device (stream ordered)."""
+    """Grow-only scratch buffer shared by all split-K conv calls on a device (stream ordered)."""
     key = str(device)
     t = _ws_cache.get(key)
     if t is None or t.numel() * 4 < nbytes:
@@ -73,8 +148,9 @@ def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True):
     if want_stats:
         ssum = _f32(plan.Cout, plan.nblk, device=x.device)
         ssq = _f32(plan.Cout, plan.nblk, device=x.device)
+    ws = workspace(plan.ws_fwd, x.device) if plan.ws_fwd else None
     C.slv_conv_fwd(plan.gp, ptr(x), ptr(w), ptr(plan.tab_fwd), ptr(in_ss), int(in_relu), ptr(y), ptr(ssum),
-                   ptr(ssq), stream())
+                   ptr(ssq), ptr(ws), plan.ws_fwd, plan.cfg_fwd, stream())
     return y, ssum, ssq
 
 
@@ -88,7 +164,9 @@ def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out
     dx = out if out is not None else _f32(*plan.in_shape, device=dy.device)
     if bwd5 is not None:     # BN backward of the conv's own output: materialised, then a plain dgrad
         dy = bn_bwd_apply(dy, x_out, bwd5, relu, out=torch.empty_like(dy))
-    C.slv_conv_dgrad(plan.gp, ptr(dy), 0, ptr(wt), ptr(plan.tab_dgrad), 0, 0, ptr(dx), ptr(addend), stream())
+    ws = workspace(plan.ws_dgrad, dy.device) if plan.ws_dgrad else None
+    C.slv_conv_dgrad(plan.gp, ptr(dy), ptr(wt), ptr(plan.tab_dgrad), ptr(dx), ptr(addend), ptr(ws), plan.ws_dgrad,
+                     plan.cfg_dgrad, stream())
     return dx
 
 
@@ -97,8 +175,8 @@ def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, 
     ws = workspace(plan.ws_bytes, dy.device) if plan.ws_bytes else None
     if bwd5 is not None:
         dy = bn_bwd_apply(dy, x_out, bwd5, a_relu, out=torch.empty_like(dy))
-    C.slv_conv_wgrad(plan.gp, ptr(dy), 0, 0, 0, ptr(x_in), ptr(in_ss), int(in_relu), ptr(plan.tab_fwd), ptr(dw),
-                     ptr(ws), plan.ws_bytes, stream())
+    C.slv_conv_wgrad(plan.gp, ptr(dy), ptr(x_in), ptr(in_ss), int(in_relu), ptr(plan.tab_fwd), ptr(dw),
+                     ptr(ws), plan.ws_bytes, plan.cfg_wgrad, stream())
     return dw
 
 

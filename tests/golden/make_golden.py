@@ -90,15 +90,18 @@ def label_digest(L):
     return hashlib.sha256(np.ascontiguousarray(L.astype(np.int32)).tobytes()).hexdigest()
 
 
-def grad_fixture(ref_model, ref_utils):
+def grad_fixture(ref_model, ref_utils, fname="grads_hc1_k28.npz", B=4, T=4, S=32, FA=40, TA=36):
     """All-parameter gradient fixture: fp64 run of the reference model (truth), fp32 run (the
-    reference's own arithmetic noise), first 256 elements + norm of every parameter gradient."""
-    hc, K, B, T, S = 1, 28, 4, 4, 32
+    reference's own arithmetic noise), first 256 elements + norm of every parameter gradient.
+    The default (tiny) shapes leave 16 elements per channel in layer4's BatchNorms: gradients there are
+    ill-conditioned (1e-7 perturbations show up as 1e-2).  The "wide" variant (B=6, T=8, S=64, 96x96
+    audio) keeps >= 54 elements per channel and is the tight parity fixture."""
+    hc, K = 1, 28
     video = portable_fill_(torch.empty(B, 3, T, S, S), 5, kind="normal")
-    audio = portable_fill_(torch.empty(B, 1, 40, 36), 6, kind="normal")
+    audio = portable_fill_(torch.empty(B, 1, FA, TA), 6, kind="normal")
     N = 64
     selflabels = torch.from_numpy((np.arange(N * hc).reshape(N, hc) * 7919 % K).astype(np.int64))
-    selected = torch.tensor([3, 17, 42, 63])
+    selected = torch.tensor([3, 17, 42, 63, 8, 29][:B])
     res = {}
     for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
         m = ref_model.load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', use_mlp=True,
@@ -124,8 +127,9 @@ def grad_fixture(ref_model, ref_utils):
         heads[i, :n] = g64[:n].numpy()
         norms[i] = g64.norm().item()
         e_cpu[i] = (g32 - g64).norm().item() / (norms[i] + 1e-300)
-    np.savez_compressed(os.path.join(OUT, "grads_hc1_k28.npz"), names=np.array(names), heads=heads, norms=norms,
+    np.savez_compressed(os.path.join(OUT, fname), names=np.array(names), heads=heads, norms=norms,
                         e_cpu=e_cpu, loss64=res["f64_loss"], loss32=res["f32_loss"], hc=hc, K=K, B=B, T=T, S=S,
+                        FA=FA, TA=TA,
                         selflabels=selflabels.numpy(), selected=selected.numpy())
     print("grad fixture: median fp32 noise %.2e max %.2e" % (np.median(e_cpu), e_cpu.max()))
 
@@ -135,6 +139,7 @@ def main():
         ref_model, ref_utils, ref_sk = import_reference()
         torch.set_num_threads(os.cpu_count())
         grad_fixture(ref_model, ref_utils)
+        grad_fixture(ref_model, ref_utils, "grads_hc1_k28_wide.npz", B=6, T=8, S=64, FA=96, TA=96)
         return
     torch.manual_seed(0)
     np.random.seed(0)

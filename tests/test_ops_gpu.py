@@ -81,6 +81,51 @@ def test_conv_forward_dgrad_wgrad(geo):
     _close(acc, xr.grad + add)
 
 
+@pytest.mark.parametrize("geo", [GEOMS[4], GEOMS[7], GEOMS[8], GEOMS[9], GEOMS[14]])
+def test_conv_every_launch_configuration(geo):
+    """Every (tile, K-split) candidate the benchmark mode may pick (the cudnn.benchmark counterpart,
+    main.py:187) computes the same convolution, in-place residual add and BN statistics."""
+    from selavi_amd import ops
+    Bn, Cin, T, H, W, Cout, k, st, pd = geo
+    dev = torch.device("cuda")
+    x = _mk((Bn, Cin, T, H, W), 11)
+    w = _mk((Cout, Cin) + k, 12, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, stride=st, padding=pd)
+    dy = _mk(tuple(y_ref.shape), 13)
+    y_ref.backward(dy)
+    add = _mk(tuple(x.shape), 14)
+    plan = ops.ConvPlan(Bn, Cin, T, H, W, Cout, k, st, pd, dev)     # private plan: configs are mutated
+    xg, wg, dyg = x.to(dev), w.to(dev), dy.to(dev)
+    wt = ops.conv_wt_transform(plan, wg)
+    ncfg = 0
+    for op in range(3):
+        cands = plan.candidates(op)
+        assert cands, "no launch configuration offered"
+        for cfg in cands:
+            cfgs = [0, 0, 0]
+            cfgs[op] = cfg
+            plan.set_configs(*cfgs)
+            ncfg += 1
+            if op == 0:
+                y, ssum, ssq = ops.conv_fwd(plan, xg, wg)
+                _close(y, y_ref)
+                _close(ssum.sum(1), y_ref.sum((0, 2, 3, 4)), rtol=1e-3)
+                _close(ssq.sum(1), (y_ref ** 2).sum((0, 2, 3, 4)), rtol=1e-3)
+                y2, _, _ = ops.conv_fwd(plan, xg, wg, want_stats=False)
+                assert torch.equal(y, y2)
+            elif op == 1:
+                acc = add.to(dev).clone()
+                ops.conv_dgrad(plan, dyg, wt, addend=acc, out=acc)
+                _close(acc, xr.grad + add)
+            else:
+                _close(ops.conv_wgrad(plan, dyg, xg).view_as(w), wr.grad)
+    assert ncfg >= 3
+    with pytest.raises(Exception):
+        plan.set_configs(3 | (2 << 8) | (1 << 16), 0, 0)        # 48-row tile does not exist
+        ops.conv_fwd(plan, xg, wg)
+
+
 @pytest.mark.parametrize("geo", [GEOMS[2], GEOMS[4], GEOMS[5], GEOMS[8], GEOMS[11]])
 def test_conv_fused_bn_prologues(geo):
     """Consumer-side BN+ReLU on load (forward / wgrad B operand) and BN-backward on load

@@ -15,12 +15,20 @@ LAYERS = [  # name, Cin, T, H, W, Cout, k, stride, pad
     ("l2.0.tm_s2", 230, 16, 28, 28, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0)),
     ("l2.1.spatial", 128, 8, 28, 28, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("l2.1.temporal", 288, 8, 28, 28, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("l2.0.ds", 64, 16, 56, 56, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
+    ("l3.0.sp_s2", 128, 8, 28, 28, 460, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("l3.0.tm_s2", 460, 8, 14, 14, 256, (3, 1, 1), (2, 1, 1), (1, 0, 0)),
+    ("l3.0.ds", 128, 8, 28, 28, 256, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
     ("l3.1.spatial", 256, 4, 14, 14, 576, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("l3.1.temporal", 576, 4, 14, 14, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     ("l4.0.sp_s2", 256, 4, 14, 14, 921, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("l4.0.tm_s2", 921, 4, 7, 7, 512, (3, 1, 1), (2, 1, 1), (1, 0, 0)),
+    ("l4.0.ds", 256, 4, 14, 14, 512, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
     ("l4.1.spatial", 512, 2, 7, 7, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("l4.1.temporal", 1152, 2, 7, 7, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
 ]
+if os.environ.get("TUNE", "0") == "1":      # time with the benchmark-mode (autotuned) configurations
+    ops.benchmark = True
 sel = sys.argv[1] if len(sys.argv) > 1 else ""
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda")
@@ -47,13 +55,10 @@ for name, Cin, T, H, W, Cout, k, st, pd in LAYERS:
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
     tf = timeit(lambda: ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True))
-    if os.environ.get("SELAVI_FUSE_BN_BWD", "0") == "1":
-        ta = 0.0
-        td = timeit(lambda: ops.conv_dgrad(plan, dy, wt, x_out=y, bwd5=b5, relu=True))
-        tw = timeit(lambda: ops.conv_wgrad(plan, dy, x, x_out=y, bwd5=b5, a_relu=True, in_ss=ss, in_relu=True))
-    else:
-        dxo = torch.empty_like(dy)
-        ta = timeit(lambda: ops.bn_bwd_apply(dy, y, b5, True, out=dxo))
-        td = timeit(lambda: ops.conv_dgrad(plan, dxo, wt))
-        tw = timeit(lambda: ops.conv_wgrad(plan, dxo, x, in_ss=ss, in_relu=True))
+    dxo = torch.empty_like(dy)
+    ta = timeit(lambda: ops.bn_bwd_apply(dy, y, b5, True, out=dxo))
+    td = timeit(lambda: ops.conv_dgrad(plan, dxo, wt))
+    tw = timeit(lambda: ops.conv_wgrad(plan, dxo, x, in_ss=ss, in_relu=True))
+    if ops.benchmark:
+        print("   tuned:", ops._tune_log[-1][2:])
     print(f"{name:14s} {flop/1e9:8.1f} | {tf:8.3f} {flop/tf/1e9:6.1f} | {td:8.3f} {flop/td/1e9:6.1f} | {tw:8.3f} {flop/tw/1e9:6.1f} | apply {ta:6.3f}")
