@@ -45,7 +45,14 @@ class ConvPlan:
         self.P_in = Ti * Hi * Wi
         self.set_configs(0, 0, 0)
         if benchmark:
-            _autotune(self)
+            key = ",".join(str(int(v)) for v in self.geom)
+            hit = _tune_cache().get(key)
+            if hit is not None:
+                self.set_configs(*hit)
+            else:
+                _autotune(self)
+                _tune_cache()[key] = [self.cfg_fwd, self.cfg_dgrad, self.cfg_wgrad]
+                _tune_cache_save()
 
     def set_configs(self, cfg_fwd, cfg_dgrad, cfg_wgrad):
         """Launch configurations (0 = built-in heuristic) and the scratch sizes that follow from them."""
@@ -82,6 +89,34 @@ def set_benchmark(flag):
     global benchmark
     if "SELAVI_BENCHMARK" not in os.environ:
         benchmark = bool(flag)
+
+
+# Optional persistence of the tuned configurations (SELAVI_TUNE_CACHE=<json path>): a restarted job
+# skips the timing pass and -- since the K-split choice fixes the summation order -- reproduces the
+# previous run's arithmetic exactly.
+_tune_cache_dict = None
+
+
+def _tune_cache():
+    global _tune_cache_dict
+    if _tune_cache_dict is None:
+        _tune_cache_dict = {}
+        path = os.environ.get("SELAVI_TUNE_CACHE")
+        if path and os.path.exists(path):
+            import json
+            with open(path) as f:
+                _tune_cache_dict = {k: [int(x) for x in v] for k, v in json.load(f).items()}
+    return _tune_cache_dict
+
+
+def _tune_cache_save():
+    path = os.environ.get("SELAVI_TUNE_CACHE")
+    if path:
+        import json
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump(_tune_cache_dict, f, indent=0, sort_keys=True)
+        os.replace(tmp, path)
 
 
 def _time_call(fn, reps=3):
