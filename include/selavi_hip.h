@@ -113,14 +113,23 @@ int32_t slv_conv_configs(const int32_t* geom, int op, int32_t* cfg_out, int32_t 
 int32_t slv_conv_fwd_nblk(const int32_t* geom, int32_t cfg);
 /* split-K scratch (late layers: few columns, deep K): 0 when the layer runs unsplit */
 size_t slv_conv_fwd_ws_bytes(const int32_t* geom, int32_t cfg);
-int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const int32_t* tab,
+/* Weight layouts.  Layers whose channel count pads to a multiple of 16 with <= 10 % waste run with a
+ * TAP-MAJOR K order (k = tap*Cpad + c: every 16-deep K chunk has one tap, so padding validity and
+ * address math are per chunk, not per element); they read re-laid-out copies of the weights made
+ * once per step by slv_conv_w_transform (one read of w):
+ *   wf  forward weights   [Cout][tap*CinPad + ci]               slv_conv_wf_elems() floats, 0 = the forward
+ *                                                               conv reads w itself (channel-major)
+ *   wt  backward-data weights, per stride-parity class c:       slv_conv_wt_elems() floats
+ *       [ci][j*CoutPad + co] (tap-major) or [ci][co*ntaps_c + j] (channel-major), classes concatenated */
+size_t slv_conv_wf_elems(const int32_t* geom);
+size_t slv_conv_wt_elems(const int32_t* geom);
+int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf /* nullable */, float* wt /* nullable */,
+                         slv_stream_t stream);
+int slv_conv_fwd(const int32_t* geom, const float* x, const float* w /* nullable if wf is used */,
+                 const float* wf /* nullable if slv_conv_wf_elems() == 0 */, const int32_t* tab,
                  const float* in_scale_shift /* nullable */, int in_relu, float* y,
                  float* stat_sum /* nullable */, float* stat_sq, void* ws /* nullable if 0 bytes */,
                  size_t ws_bytes, int32_t cfg, slv_stream_t stream);
-/* backward-data weights: per stride-parity class c a K-contiguous matrix wt_c[ci][co*ntaps_c + j] =
- * w[co][ci][tap_j], classes concatenated (same element count as w) */
-int slv_conv_wt_transform(const int32_t* geom, const float* w, float* wt, slv_stream_t stream);
-/* dx = conv_transpose(dy) (+ addend);  dy = gradient w.r.t. the raw conv output.  tab = dgrad table */
 size_t slv_conv_dgrad_ws_bytes(const int32_t* geom, int32_t cfg);
 int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* wt, const int32_t* tab,
                    float* dx, const float* addend /* nullable, may alias dx */, void* ws /* nullable if 0 bytes */,

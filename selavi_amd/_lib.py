@@ -10,7 +10,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "selavi_hip.h")
-LIBPATH = os.path.join(HERE, "libselavi_hip.so")
+LIBPATH = os.environ.get("SELAVI_HIP_LIB") or os.path.join(HERE, "libselavi_hip.so")   # override: A/B builds
 
 
 class SelaviHipError(RuntimeError):

@@ -32,7 +32,8 @@ static int read_geom(const int32_t* p, Geom& g) {
 
 // One MODE_CONV launch: the forward conv, or one stride-parity class of the backward-data conv.
 struct Desc {
-  int M, C, Kd, ntaps;
+  int M, C, Kd, ntaps;     // Kd: K extent of the launch (C*ntaps, or ntaps*Cp with tap-major K)
+  int kord, Cp;            // K ordering (igemm.hpp) and padded channel count of the tap-major layout
   int taps[64];            // linear tap ids (kt,kh,kw order) in this launch's k order
   int delta[64][3];        // source-coordinate delta of each tap
   int Q[3], mul[3], S[3];  // lattice dims, source multipliers, source dims
@@ -40,16 +41,34 @@ struct Desc {
   long long Ntot;
   size_t tab_words;        // int32 words of this launch's table block
   size_t tab_off;          // word offset inside the layer's table buffer
+  size_t gen_words;        // forward only: words of the channel-major table that precedes a tap-major one
+                           // (the weight-gradient kernel always reads the channel-major table)
   size_t wt_off;           // backward-data: float offset of this class' weight matrix
 };
 
 // the loader waves run two chunks past the end (branch-free schedule): 48 invalid pad entries
 static int kpad(int Kd) { return ((Kd + 15) / 16) * 16 + 48; }
 
-static void finish(Desc& d, const Geom& g) {
-  d.Kd = d.C * d.ntaps;
+static bool want_tap_major(int C) {
+  static const int off = getenv("SLV_KORD_CHAN") ? 1 : 0;   // A/B switch: force the channel-major path
+  const int cp = (C + 15) / 16 * 16;
+  return !off && C >= 16 && cp * 10 <= C * 11;              // at most 10 % zero padding of K
+}
+static size_t tap_table_words(int nchunks) { return (size_t)2 * (nchunks + 4) + 64; }
+static void finish(Desc& d, const Geom& g, bool with_generic) {
   d.Ntot = (long long)g.Bn * d.Q[0] * d.Q[1] * d.Q[2];
-  d.tab_words = (size_t)2 * kpad(d.Kd) + 64;
+  d.Cp = (d.C + 15) / 16 * 16;
+  d.kord = want_tap_major(d.C) ? KORD_TAP : KORD_CHAN;
+  const size_t gen = (size_t)2 * kpad(d.C * d.ntaps) + 64;
+  if (d.kord == KORD_TAP) {
+    d.Kd = d.ntaps * d.Cp;
+    d.gen_words = with_generic ? gen : 0;
+    d.tab_words = d.gen_words + tap_table_words(d.Kd / 16);
+  } else {
+    d.Kd = d.C * d.ntaps;
+    d.gen_words = 0;
+    d.tab_words = gen;
+  }
 }
 
 static Desc fwd_desc(const Geom& g) {
@@ -72,7 +91,7 @@ static Desc fwd_desc(const Geom& g) {
     d.Q[i] = out[i]; d.mul[i] = s[i]; d.S[i] = in[i];
     d.dmul[i] = 1; d.dorg[i] = 0; d.D[i] = out[i];
   }
-  finish(d, g);
+  finish(d, g, true);
   return d;
 }
 
@@ -114,7 +133,7 @@ static int dgrad_descs(const Geom& g, Desc* out8) {
               d.taps[j] = (a * k[1] + b) * k[2] + c;
               for (int i = 0; i < 3; ++i) d.delta[j][i] = dl[i];
             }
-        finish(d, g);
+        finish(d, g, false);
         d.tab_off = tab_off;
         d.wt_off = wt_off;
         tab_off += d.tab_words;
@@ -124,22 +143,48 @@ static int dgrad_descs(const Geom& g, Desc* out8) {
   return n;
 }
 
-static void fill_table(const Desc& d, int32_t* w) {
+static void fill_tapd(const Desc& d, int32_t* td) {
+  for (int j = 0; j < 64; ++j)
+    td[j] = j < d.ntaps ? ((d.delta[j][0] + 64) | ((d.delta[j][1] + 64) << 8) | ((d.delta[j][2] + 64) << 16)) : 0;
+}
+// channel-major table: one {offset, tap | chan << 8} entry per k = c*ntaps + j
+static void fill_table_generic(const Desc& d, int32_t* w) {
   const int Sprod = d.S[0] * d.S[1] * d.S[2];
-  const int KP = kpad(d.Kd);
+  const int Kg = d.C * d.ntaps, KP = kpad(Kg);
   for (int c = 0; c < d.C; ++c)
     for (int j = 0; j < d.ntaps; ++j) {
       const int kidx = c * d.ntaps + j;
       w[2 * kidx] = c * Sprod + d.delta[j][0] * d.S[1] * d.S[2] + d.delta[j][1] * d.S[2] + d.delta[j][2];
       w[2 * kidx + 1] = j | (c << 8);
     }
-  for (int kidx = d.Kd; kidx < KP; ++kidx) {
+  for (int kidx = Kg; kidx < KP; ++kidx) {
     w[2 * kidx] = 0;
     w[2 * kidx + 1] = 63;  // tap 63 is never valid
   }
-  int32_t* td = w + 2 * KP;
-  for (int j = 0; j < 64; ++j)
-    td[j] = j < d.ntaps ? ((d.delta[j][0] + 64) | ((d.delta[j][1] + 64) << 8) | ((d.delta[j][2] + 64) << 16)) : 0;
+  fill_tapd(d, w + 2 * KP);
+}
+// tap-major table: one entry per 16-deep chunk (k = j*Cp + c): {offset of (tap j, channel c0), j | c0 << 8}
+static void fill_table_tap(const Desc& d, int32_t* w) {
+  const int Sprod = d.S[0] * d.S[1] * d.S[2];
+  const int nch = d.Kd / 16, cpc = d.Cp / 16;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int j = ch / cpc, c0 = (ch % cpc) * 16;
+    w[2 * ch] = c0 * Sprod + d.delta[j][0] * d.S[1] * d.S[2] + d.delta[j][1] * d.S[2] + d.delta[j][2];
+    w[2 * ch + 1] = j | (c0 << 8);
+  }
+  for (int ch = nch; ch < nch + 4; ++ch) {
+    w[2 * ch] = 0;
+    w[2 * ch + 1] = 63;
+  }
+  fill_tapd(d, w + 2 * (nch + 4));
+}
+static void fill_table(const Desc& d, int32_t* w) {
+  if (d.kord == KORD_TAP) {
+    if (d.gen_words) fill_table_generic(d, w);
+    fill_table_tap(d, w + d.gen_words);
+  } else {
+    fill_table_generic(d, w);
+  }
 }
 
 // Tile choice for the M x ncols output: minimise  padded work / (tile efficiency * chip fill).
@@ -269,8 +314,11 @@ static int dispatch(const IgemmArgs& a0, int mt, int nt, int splits, hipStream_t
 static void conv_args(IgemmArgs& a, const Geom& g, const Desc& d, const int32_t* tab_dev) {
   memset(&a, 0, sizeof(a));
   a.M = d.M; a.Kd = d.Kd; a.Ntot = d.Ntot; a.Cb = d.C; a.ntaps = d.ntaps;
-  a.tab = (const int2*)(tab_dev + d.tab_off);
-  a.tapd = (const int*)(tab_dev + d.tab_off + 2 * kpad(d.Kd));
+  a.kord = d.kord;
+  a.sprod4 = (unsigned)(d.S[0] * d.S[1] * d.S[2]) * 4u;
+  const int32_t* t = tab_dev + d.tab_off + d.gen_words;
+  a.tab = (const int2*)t;
+  a.tapd = (const int*)(t + (d.kord == KORD_TAP ? 2 * (d.Kd / 16 + 4) : 2 * kpad(d.Kd)));
   a.Q0 = d.Q[0]; a.Q1 = d.Q[1]; a.Q2 = d.Q[2];
   a.mul0 = d.mul[0]; a.mul1 = d.mul[1]; a.mul2 = d.mul[2];
   a.S0 = d.S[0]; a.S1 = d.S[1]; a.S2 = d.S[2];
@@ -286,26 +334,69 @@ static void conv_args(IgemmArgs& a, const Geom& g, const Desc& d, const int32_t*
 struct TapMap {
   int off[64], nt[64], j[64];
 };
-// wt[class][ci][co*nt + j] = w[co][ci][tap]
-__global__ void wt_transform_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin,
-                                    int taps, const TapMap tm) {
+// Per-step weight re-layouts (one read of w):
+//   wf (forward, tap-major layers only)  wf[co][tap*CpIn + ci]                 = w[co][ci][tap]
+//   wt (backward-data), per parity class  channel-major: wt_c[ci][co*nt_c + j]  = w[co][ci][tap_j]
+//                                         tap-major:     wt_c[ci][j*CpOut + co] = w[co][ci][tap_j]
+// Padding channels (ci >= Cin resp. co >= Cout) stay zero (buffers are cleared first when padded).
+__global__ void w_transform_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wt,
+                                   int Cout, int Cin, int taps, const TapMap tm, int CpIn, int CpOut) {
   const size_t n = (size_t)Cout * Cin * taps;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int tap = (int)(i % taps);
-    if (tm.nt[tap] == 0) continue;
     const size_t r = i / taps;
     const int ci = (int)(r % Cin), co = (int)(r / Cin);
-    wt[(size_t)tm.off[tap] + ((size_t)ci * Cout + co) * tm.nt[tap] + tm.j[tap]] = w[i];
+    const float v = w[i];
+    if (wf) wf[((size_t)co * taps + tap) * CpIn + ci] = v;
+    if (wt && tm.nt[tap] != 0) {
+      if (CpOut) wt[(size_t)tm.off[tap] + ((size_t)ci * tm.nt[tap] + tm.j[tap]) * CpOut + co] = v;
+      else wt[(size_t)tm.off[tap] + ((size_t)ci * Cout + co) * tm.nt[tap] + tm.j[tap]] = v;
+    }
   }
 }
 
-// dW[i] = sum_s partial[s][i]   (fixed order)
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n,
-                                     int splits) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += part[(size_t)s * n + i];
-    out[i] = v;
+// dW[i] = sum_s partial[s][i], fixed order.  The weight gradients have few elements (83 k for layer1)
+// but up to hundreds of K-slices, so the slice loop is spread over G waves per element group and
+// unrolled 8-fold (independent loads in flight); partial sums are combined in a fixed tree.
+template <int G>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            size_t n, int splits) {
+  constexpr int EPB = 256 / G;   // elements per block
+  __shared__ float red[256];
+  const int e = threadIdx.x % EPB, grp = threadIdx.x / EPB;
+  const size_t i = (size_t)blockIdx.x * EPB + e;
+  const int per = (splits + G - 1) / G;
+  const int s0 = grp * per, s1 = (s0 + per < splits) ? s0 + per : splits;
+  float v = 0.f;
+  if (i < n) {
+    const float* p = part + i;
+    int s = s0;
+    for (; s + 8 <= s1; s += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(s + u) * n];
+      v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    for (; s < s1; ++s) v += p[(size_t)s * n];
+  }
+  if constexpr (G == 1) {
+    if (i < n) out[i] = v;
+  } else {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+      float r = red[e];
+#pragma unroll
+      for (int g2 = 1; g2 < G; ++g2) r += red[g2 * EPB + e];
+      out[i] = r;
+    }
+  }
+}
+static void launch_splitk_reduce(const float* ws, float* out, size_t nel, int splits, hipStream_t st) {
+  if (splits >= 16) {
+    hipLaunchKernelGGL((splitk_reduce_kernel<4>), dim3((unsigned)((nel + 63) / 64)), dim3(256), 0, st, ws, out, nel, splits);
+  } else {
+    hipLaunchKernelGGL((splitk_reduce_kernel<1>), dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, ws, out, nel, splits);
   }
 }
 
@@ -482,18 +573,20 @@ size_t slv_conv_fwd_ws_bytes(const int32_t* geom, int32_t cfg) {
   return c.sp > 1 ? sizeof(float) * (size_t)c.sp * g.Cout * (size_t)P : 0;
 }
 
-int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const int32_t* tab,
+int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const float* wf, const int32_t* tab,
                  const float* in_scale_shift, int in_relu, float* y, float* stat_sum, float* stat_sq,
                  void* ws, size_t ws_bytes, int32_t cfg, slv_stream_t stream) {
   Geom g;
   SLV_CHECK_ARG(read_geom(geom, g) == 0, "invalid geometry");
-  SLV_CHECK_ARG(x && w && tab && y, "null pointer");
+  SLV_CHECK_ARG(x && tab && y, "null pointer");
   Cfg c;
   SLV_CHECK_ARG(fwd_cfg(g, cfg, c) == 0, "invalid launch configuration");
   const Desc d = fwd_desc(g);
   IgemmArgs a;
   conv_args(a, g, d, tab);
-  a.A = w; a.B = x; a.C = y;
+  if (d.kord == KORD_TAP) SLV_CHECK_ARG(wf, "this layer reads the tap-major weights: pass wf (slv_conv_w_transform)");
+  else SLV_CHECK_ARG(w, "null weight pointer");
+  a.A = d.kord == KORD_TAP ? wf : w; a.B = x; a.C = y;
   a.pb = in_scale_shift; a.b_pro = in_scale_shift ? PRO_ACT : PRO_NONE; a.b_relu = in_relu;
   a.stat_sum = stat_sum; a.stat_sq = stat_sq;
   const int mt = c.mt, nt = c.nt, sp = c.sp;
@@ -522,27 +615,53 @@ int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const int3
   return 0;
 }
 
-/* wt: per stride-parity class c a [Cin][Cout*ntaps_c] matrix, classes concatenated (same total size as w) */
-int slv_conv_wt_transform(const int32_t* geom, const float* w, float* wt, slv_stream_t stream) {
+size_t slv_conv_wf_elems(const int32_t* geom) {
   Geom g;
-  SLV_CHECK_ARG(read_geom(geom, g) == 0 && w && wt, "invalid geometry or null pointer");
+  if (read_geom(geom, g) != 0) return 0;
+  const Desc d = fwd_desc(g);
+  return d.kord == KORD_TAP ? (size_t)d.M * d.Kd : 0;
+}
+
+size_t slv_conv_wt_elems(const int32_t* geom) {
+  Geom g;
+  if (read_geom(geom, g) != 0) return 0;
+  Desc ds[8];
+  const int n = dgrad_descs(g, ds);
+  size_t t = 0;
+  for (int i = 0; i < n; ++i) t += (size_t)g.Cin * ds[i].Kd;
+  return t > 0 ? t : 1;
+}
+
+int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf, float* wt, slv_stream_t stream) {
+  Geom g;
+  SLV_CHECK_ARG(read_geom(geom, g) == 0 && w && (wf || wt), "invalid geometry or null pointer");
+  const Desc df = fwd_desc(g);
+  if (df.kord != KORD_TAP) wf = nullptr;   // the forward conv of this layer reads w directly
   Desc ds[8];
   const int n = dgrad_descs(g, ds);
   TapMap tm;
   memset(&tm, 0, sizeof(tm));
   const int taps = g.kt * g.kh * g.kw;
-  for (int i = 0; i < n; ++i)
+  int cp_out = 0;
+  size_t wt_elems = 0;
+  for (int i = 0; i < n; ++i) {
+    wt_elems += (size_t)g.Cin * ds[i].Kd;
+    if (ds[i].kord == KORD_TAP) cp_out = ds[i].Cp;
     for (int j = 0; j < ds[i].ntaps; ++j) {
       const int t = ds[i].taps[j];
       tm.off[t] = (int)ds[i].wt_off;
       tm.nt[t] = ds[i].ntaps;
       tm.j[t] = j;
     }
+  }
   // taps whose parity class has an empty lattice (input extent smaller than the stride) keep nt = 0:
   // no input position ever sees them, the kernel skips them
+  hipStream_t st = (hipStream_t)stream;
+  if (wf && df.Cp != g.Cin) SLV_HIP(hipMemsetAsync(wf, 0, sizeof(float) * (size_t)df.M * df.Kd, st));
+  if (wt && cp_out && cp_out != g.Cout) SLV_HIP(hipMemsetAsync(wt, 0, sizeof(float) * wt_elems, st));
   const size_t nel = (size_t)g.Cout * g.Cin * taps;
-  hipLaunchKernelGGL(wt_transform_kernel, dim3((unsigned)((nel + 255) / 256 < 4096 ? (nel + 255) / 256 : 4096)),
-                     dim3(256), 0, (hipStream_t)stream, w, wt, g.Cout, g.Cin, taps, tm);
+  hipLaunchKernelGGL(w_transform_kernel, dim3((unsigned)((nel + 255) / 256 < 4096 ? (nel + 255) / 256 : 4096)),
+                     dim3(256), 0, st, w, wf, wt, g.Cout, g.Cin, taps, tm, df.Cp, cp_out);
   SLV_LAUNCH_CHECK();
   return 0;
 }
@@ -612,8 +731,8 @@ int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_in, cons
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
   const int taps = g.kt * g.kh * g.kw;
-  a.tab = (const int2*)tab;
-  a.tapd = (const int*)(tab + 2 * kpad(d.Kd));
+  a.tab = (const int2*)tab;                                  // channel-major table (first block of the forward table)
+  a.tapd = (const int*)(tab + 2 * kpad(g.Cin * taps));
   a.Cin = g.Cin; a.Ti = g.Ti; a.Hi = g.Hi; a.Wi = g.Wi; a.Cout = g.Cout; a.To = g.To; a.Ho = g.Ho; a.Wo = g.Wo;
   a.st = g.st; a.sh = g.sh; a.sw = g.sw; a.pt = g.pt; a.ph = g.ph; a.pw = g.pw;
   a.A = dy; a.a_pro = PRO_NONE;
@@ -639,8 +758,7 @@ int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_in, cons
   SLV_CHECK_ARG(dispatch<MODE_WGRAD>(a, mt, nt, splits, (hipStream_t)stream) == 0, "no kernel for tile");
   SLV_LAUNCH_CHECK();
   if (splits > 1) {
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nel + 255) / 256 < 2048 ? (nel + 255) / 256 : 2048)),
-                       dim3(256), 0, (hipStream_t)stream, (const float*)ws, dw, nel, splits);
+    launch_splitk_reduce((const float*)ws, dw, nel, splits, (hipStream_t)stream);
     SLV_LAUNCH_CHECK();
   }
   return 0;

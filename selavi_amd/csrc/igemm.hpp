@@ -40,6 +40,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { MODE_CONV = 0, MODE_WGRAD = 2, MODE_GEMM = 3 };
 enum { PRO_NONE = 0, PRO_ACT = 1, PRO_BWD = 2 };
+// K ordering of MODE_CONV: channel-major (k = c*ntaps + tap, the nn.Conv weight layout, per-k table) or
+// tap-major (k = tap*Cpad + c with Cpad = round16(C), transformed weights): every 16-deep chunk then has
+// ONE tap, so padding validity / address math is per chunk instead of per element.
+enum { KORD_CHAN = 0, KORD_TAP = 1 };
 
 // exact unsigned division by a runtime constant (Granlund-Montgomery round-up form)
 struct FastDiv {
@@ -71,7 +75,11 @@ struct IgemmArgs {
   const float* pa;   // WGRAD A prologue params [5][Cout] = s, h, A1, A2, A3
   const float* pb;   // B prologue params: PRO_ACT [2][Cb] = s, h ; PRO_BWD [5][Cb]
   const int2* tab;   // per-k (CONV) / per-column (WGRAD) entries {element offset, tap | chan << 8}; padded with
-                     // invalid entries {0, 63} to a multiple of 16 (+16)
+                     // invalid entries {0, 63} to a multiple of 16 (+16).
+                     // CONV with KORD_TAP: one entry per 16-deep CHUNK {element offset of (tap, first channel),
+                     // tap | first channel << 8}
+  int kord;          // CONV: KORD_CHAN / KORD_TAP
+  unsigned sprod4;   // KORD_TAP: bytes between consecutive channels of the gathered tensor (S0*S1*S2*4)
   const int* tapd;   // per-tap packed deltas: (d0+64) | (d1+64)<<8 | (d2+64)<<16, 64 entries
   float* C;          // output
   const float* E;    // optional epilogue addend, same indexing as C
@@ -110,6 +118,9 @@ __device__ __forceinline__ float apply_bwd(float g, float x, float s, float h, f
 __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
+__device__ __forceinline__ float bload_s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {  // soff: SGPR
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {  // 16-byte aligned offset
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
@@ -118,7 +129,7 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 // preconditions: CONV/GEMM Kd % 4 == 0; WGRAD To*Ho*Wo % 4 == 0 and no A prologue.
 // PRO: prologue of the gathered B operand (PRO_NONE / PRO_ACT) -- a template parameter so that the
 // steady-state loop stays one basic block.
-template <int MODE, int MT, int NT, bool VA, int PRO>
+template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN>
 __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) void igemm_kernel(const IgemmArgs g) {
   constexpr int BM = MT * 16, BN = NT * 64;
   constexpr int AS = 18;
@@ -174,6 +185,7 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
     const int q1 = rem / g.Q2, q2 = rem - q1 * g.Q2;
     const int c0 = q0 * g.mul0, c1 = q1 * g.mul1, c2 = q2 * g.mul2;
     lbase = (unsigned)((long long)b * g.sbatch + (long long)c0 * (g.S1 * g.S2) + c1 * g.S2 + c2);
+    if constexpr (KORD == KORD_TAP) lbase += (unsigned)(kg * BROWS) * (g.sprod4 >> 2);  // this thread's first channel row
     if (nvalid) {
       for (int t = 0; t < g.ntaps; ++t) {
         const int d = g.tapd[t];
@@ -277,7 +289,25 @@ __global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) vo
         rb[i] = bload(rB, (n < g.Ntot && k < g.Kd) ? (unsigned)((n * g.Kd + k) * 4) : OOB);
       }
     }
-    if constexpr (MODE == MODE_CONV) {
+    if constexpr (MODE == MODE_CONV && KORD == KORD_TAP) {
+      const int2 e = g.tab[k0 >> 4];  // one entry per chunk (scalar load)
+      const int tap = e.y & 63;
+      const unsigned half = tap < 32 ? mlo : mhi;
+      const bool ok = (half >> (tap & 31)) & 1u;
+      const unsigned voff = ok ? ((lbase + (unsigned)e.x) << 2) : OOB;
+      okB = ok ? ~0u : 0u;
+      const int cb = (e.y >> 8) + kg * BROWS;
+#pragma unroll
+      for (int q = 0; q < BROWS; ++q) {
+        rb[q] = bload_s(rB, voff, (unsigned)q * g.sprod4);  // channels beyond C meet zero weights
+        if constexpr (PRO == PRO_ACT) {
+          const int ci = (cb + q < g.Cb) ? cb + q : g.Cb - 1;
+          sp0[q] = g.pb[ci];
+          sp1[q] = g.pb[g.Cb + ci];
+        }
+      }
+    }
+    if constexpr (MODE == MODE_CONV && KORD == KORD_CHAN) {
       okB = 0;
 #pragma unroll
       for (int q = 0; q < BROWS; ++q) {
@@ -566,6 +596,13 @@ inline void launch_igemm(const IgemmArgs& a, int splits, bool vec_a, hipStream_t
   dim3 grid(a.nblkM * a.nblkN * splits, 1, 1);
   const bool act = (MODE != MODE_GEMM) && a.b_pro == PRO_ACT;
 #define SLV_L(VA_, PRO_) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, VA_, PRO_>), grid, dim3(256), 0, st, a)
+  if constexpr (MODE == MODE_CONV) {
+    if (a.kord == KORD_TAP) {  // tap-major K: Kd is a multiple of 16 and A is 64-byte aligned -> always vector A loads
+      if (act) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_ACT, KORD_TAP>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_TAP>), grid, dim3(256), 0, st, a);
+      return;
+    }
+  }
   if constexpr (MODE == MODE_GEMM) {
     if (vec_a) SLV_L(true, PRO_NONE); else SLV_L(false, PRO_NONE);
   } else {

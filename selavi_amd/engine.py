@@ -16,10 +16,11 @@ from . import ops
 
 class Raw:
     """A raw conv output with its (pending) BatchNorm."""
-    __slots__ = ("y", "ss", "mi", "plan", "conv", "bn", "src")
+    __slots__ = ("y", "ss", "mi", "plan", "conv", "bn", "src", "wt")
 
-    def __init__(self, y, ss, mi, plan, conv, bn, src):
+    def __init__(self, y, ss, mi, plan, conv, bn, src, wt=None):
         self.y, self.ss, self.mi, self.plan, self.conv, self.bn, self.src = y, ss, mi, plan, conv, bn, src
+        self.wt = wt                # backward-data weights made together with the forward ones
 
 
 class Ctx:
@@ -42,15 +43,17 @@ def conv_bn(ctx, x, conv, bn):
     else:
         xin, in_ss = x, None
     plan = ops.ConvPlan.get(tuple(xin.shape), conv.out_channels, conv.kernel3, conv.stride3, conv.padding3, xin.device)
+    # one pass over the weights makes the forward (tap-major) and backward-data layouts of this step
+    wf, wt = ops.conv_w_transform(plan, conv.weight, need_wt=ctx.training)
     y, ssum, ssq = ops.conv_fwd(plan, xin, conv.weight, in_ss=in_ss, in_relu=in_ss is not None,
-                                want_stats=ctx.training)
+                                want_stats=ctx.training, wf=wf)
     if ctx.training:
         mi, ss = ops.bn_train_finalize(ssum, ssq, plan.count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                        bn.momentum, bn.eps, sync=ctx.sync)
         bn.note_batch()
     else:
         mi, ss = ops.bn_eval_params(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-    return Raw(y, ss, mi, plan, conv, bn, x)
+    return Raw(y, ss, mi, plan, conv, bn, x, wt)
 
 
 def tail(ctx, r, res=None, res_raw=None, relu=True):
@@ -58,10 +61,6 @@ def tail(ctx, r, res=None, res_raw=None, relu=True):
     if res_raw is not None:
         return ops.bn_act(r.y, r.ss, res=res_raw.y, res_ss=res_raw.ss, relu=relu)
     return ops.bn_act(r.y, r.ss, res=res, relu=relu)
-
-
-def _wt(r):
-    return ops.conv_wt_transform(r.plan, r.conv.weight)
 
 
 def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, keep_g=False):
@@ -82,7 +81,8 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
     ctx.grads[id(r.conv.weight)] = dw.view_as(r.conv.weight)
     if not need_dx:
         return None
-    return ops.conv_dgrad(r.plan, dxo, _wt(r), addend=addend, out=out)
+    wt = r.wt if r.wt is not None else ops.conv_wt_transform(r.plan, r.conv.weight)
+    return ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out)
 
 
 def bn_bwd_own(ctx, r, g):

@@ -40,6 +40,8 @@ class ConvPlan:
         C.slv_conv_table(self.gp, 1, td.ctypes.data)
         self.tab_fwd = torch.from_numpy(tf).to(device)
         self.tab_dgrad = torch.from_numpy(td).to(device)
+        self.wf_elems = C.slv_conv_wf_elems(self.gp)   # > 0: the forward conv reads tap-major weights
+        self.wt_elems = C.slv_conv_wt_elems(self.gp)
         self.count = float(Bn * To * Ho * Wo)          # elements per channel of the output
         self.P_out = To * Ho * Wo
         self.P_in = Ti * Hi * Wi
@@ -139,7 +141,7 @@ def _autotune(plan):
     w = torch.randn(plan.Cout, plan.Cin * plan.taps, device=dev) * 0.05
     ss = torch.stack([torch.rand(plan.Cin, device=dev) + 0.5, torch.randn(plan.Cin, device=dev) * 0.1]).contiguous()
     dy = torch.randn(plan.out_shape, device=dev)
-    wt = conv_wt_transform(plan, w)
+    wf, wt = conv_w_transform(plan, w)
     best = [0, 0, 0]
     times = [None, None, None]   # (best ms, heuristic ms)
     for op in range(3):
@@ -148,7 +150,7 @@ def _autotune(plan):
             cfgs[op] = cfg
             plan.set_configs(*cfgs)
             if op == 0:
-                t = _time_call(lambda: conv_fwd(plan, x, w, in_ss=ss, in_relu=True))
+                t = _time_call(lambda: conv_fwd(plan, x, w, in_ss=ss, in_relu=True, wf=wf))
             elif op == 1:
                 t = _time_call(lambda: conv_dgrad(plan, dy, wt))
             else:
@@ -176,23 +178,33 @@ def workspace(nbytes, device):
     return t
 
 
-def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True):
-    """y = conv(relu?(x*s+h)); returns (y, stat_sum, stat_sq) with stats [Cout][nblk] partials."""
+def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True, wf=None):
+    """y = conv(relu?(x*s+h)); returns (y, stat_sum, stat_sq) with stats [Cout][nblk] partials.
+    wf: tap-major forward weights from conv_w_transform (made on the fly when the layer needs them)."""
+    if plan.wf_elems and wf is None:
+        wf, _ = conv_w_transform(plan, w, need_wt=False)
     y = _f32(*plan.out_shape, device=x.device)
     ssum = ssq = None
     if want_stats:
         ssum = _f32(plan.Cout, plan.nblk, device=x.device)
         ssq = _f32(plan.Cout, plan.nblk, device=x.device)
     ws = workspace(plan.ws_fwd, x.device) if plan.ws_fwd else None
-    C.slv_conv_fwd(plan.gp, ptr(x), ptr(w), ptr(plan.tab_fwd), ptr(in_ss), int(in_relu), ptr(y), ptr(ssum),
+    C.slv_conv_fwd(plan.gp, ptr(x), ptr(w), ptr(wf), ptr(plan.tab_fwd), ptr(in_ss), int(in_relu), ptr(y), ptr(ssum),
                    ptr(ssq), ptr(ws), plan.ws_fwd, plan.cfg_fwd, stream())
     return y, ssum, ssq
 
 
-def conv_wt_transform(plan, w, out=None):
-    wt = out if out is not None else torch.empty_like(w)
-    C.slv_conv_wt_transform(plan.gp, ptr(w), ptr(wt), stream())
-    return wt
+def conv_w_transform(plan, w, need_wf=True, need_wt=True):
+    """Per-step re-layouts of the weights (one read of w): (wf, wt) -- see include/selavi_hip.h."""
+    wf = _f32(plan.wf_elems, device=w.device) if (need_wf and plan.wf_elems) else None
+    wt = _f32(plan.wt_elems, device=w.device) if need_wt else None
+    if wf is not None or wt is not None:
+        C.slv_conv_w_transform(plan.gp, ptr(w), ptr(wf), ptr(wt), stream())
+    return wf, wt
+
+
+def conv_wt_transform(plan, w):
+    return conv_w_transform(plan, w, need_wf=False)[1]
 
 
 def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out=None):

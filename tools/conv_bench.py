@@ -44,7 +44,7 @@ for name, Cin, T, H, W, Cout, k, st, pd in LAYERS:
     y, _, _ = ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True)
     dy = torch.randn_like(y)
     b5 = torch.randn(5, Cout, device=dev, generator=g) * 0.1
-    wt = ops.conv_wt_transform(plan, w)
+    wf, wt = ops.conv_w_transform(plan, w)
     flop = 2.0 * y.numel() * Cin * k[0] * k[1] * k[2]
     def timeit(fn):
         fn(); torch.cuda.synchronize()
@@ -54,7 +54,7 @@ for name, Cin, T, H, W, Cout, k, st, pd in LAYERS:
             fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
-    tf = timeit(lambda: ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True))
+    tf = timeit(lambda: ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True, wf=wf))
     dxo = torch.empty_like(dy)
     ta = timeit(lambda: ops.bn_bwd_apply(dy, y, b5, True, out=dxo))
     td = timeit(lambda: ops.conv_dgrad(plan, dxo, wt))
