@@ -70,4 +70,24 @@ __device__ __forceinline__ float wave_max(float v) {
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// exact unsigned division by a runtime constant (Granlund-Montgomery round-up form)
+struct FastDiv {
+  unsigned m, s1, s2, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s1 = l > 1 ? 1 : l;
+  f.s2 = l > 0 ? l - 1 : 0;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
+
 }  // namespace slv

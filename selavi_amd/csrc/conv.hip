@@ -405,7 +405,7 @@ static int wgrad_splits(const Geom& g, int mt, int nt) {
   const long long chunks = (Ptot + 15) / 16;
   const int taps = g.kt * g.kh * g.kw;
   const long long tiles = (long long)((g.Cout + mt * 16 - 1) / (mt * 16)) * ((g.Cin * taps + nt * 64 - 1) / (nt * 64));
-  long long s = (1024 + tiles - 1) / tiles;      // aim at ~1024 workgroups
+  long long s = 768 / tiles;                     // one full round of 3 workgroups per CU (measured best: 765 of 768)
   const long long maxs = (chunks + 15) / 16;     // at least 16 chunks (256 positions) per slice
   if (s > maxs) s = maxs;
   if (s > 512) s = 512;

@@ -77,15 +77,36 @@ __global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const flo
 
 // ------------------------------------------------------------------ block tail (forward)
 // out = relu?( x*s + h  +  (res ? (rss ? res*rs + rh : res) : 0) ),  tensors [Bn][C][P]
+// V = 4: P % 4 == 0 and 16-byte aligned tensors -> float4 accesses (4 consecutive elements share a channel).
+// 32-bit exact division by P and C (FastDiv): the flat index stays below 2^32 (checked by the entry point).
+template <int V>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ ss,
                                                     const float* __restrict__ res, const float* __restrict__ rss,
-                                                    int relu, float* __restrict__ out, int C, int P,
-                                                    size_t total) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)((i / P) % C);
-    float v = x[i] * ss[c] + ss[C + c];
-    if (res) v += rss ? (res[i] * rss[c] + rss[C + c]) : res[i];
-    out[i] = relu ? fmaxf(v, 0.f) : v;
+                                                    int relu, float* __restrict__ out, int C, const FastDiv dP,
+                                                    const FastDiv dC, unsigned units) {
+  for (unsigned u = blockIdx.x * 256u + threadIdx.x; u < units; u += gridDim.x * 256u) {
+    const unsigned i = u * V;
+    const unsigned row = fdiv(i, dP);
+    const unsigned c = row - fdiv(row, dC) * (unsigned)C;
+    const float s = ss[c], h = ss[C + c];
+    float rs = 1.f, rh = 0.f;
+    if (res && rss) { rs = rss[c]; rh = rss[C + c]; }
+    float xv[V], rv[V], ov[V];
+    if constexpr (V == 4) {
+      *(float4*)xv = *(const float4*)(x + i);
+      if (res) *(float4*)rv = *(const float4*)(res + i);
+    } else {
+      xv[0] = x[i];
+      if (res) rv[0] = res[i];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float v = xv[j] * s + h;
+      if (res) v += rss ? (rv[j] * rs + rh) : rv[j];
+      ov[j] = relu ? fmaxf(v, 0.f) : v;
+    }
+    if constexpr (V == 4) *(float4*)(out + i) = *(float4*)ov;
+    else out[i] = ov[0];
   }
 }
 
@@ -93,7 +114,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
 // For channel c (blockIdx.x) and slice blockIdx.y of the (b,p) space:
 //   g' = mask * g ;  partial = { sum g', sum g' * xhat(x) [, sum g' * xhat2(x2)] }
 // MASK 0: none; 1: own BN output > 0 (s*x+h); 2: external tensor v > 0 (and g' is written to gout)
-template <int MASK, bool TWO>
+template <int MASK, bool TWO, int V>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ gin,
                                                            const float* __restrict__ x,
                                                            const float* __restrict__ mi,  // mean,invstd [2C]
@@ -101,31 +122,43 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                            const float* __restrict__ v,   // MASK 2
                                                            const float* __restrict__ x2, const float* __restrict__ mi2,
                                                            float* __restrict__ gout, float* __restrict__ part,
-                                                           float* __restrict__ part2, int Bn, int C, int P,
-                                                           int nsplit) {
+                                                           float* __restrict__ part2, int C, unsigned P,
+                                                           const FastDiv dP, unsigned tot, unsigned per, int nsplit) {
   __shared__ float sh[3][256];
   const int c = blockIdx.x, sp = blockIdx.y;
-  const long long tot = (long long)Bn * P;
-  const long long per = (tot + nsplit - 1) / nsplit;
-  const long long e0 = sp * per, e1 = (e0 + per < tot) ? e0 + per : tot;
+  const unsigned e0 = sp * per, e1 = (e0 + per < tot) ? e0 + per : tot;   // slice of the (b,p) space; per % V == 0
   const float mean = mi[c], invstd = mi[C + c];
   float mean2 = 0.f, invstd2 = 0.f, s_ = 0.f, h_ = 0.f;
   if (TWO) { mean2 = mi2[c]; invstd2 = mi2[C + c]; }
   if (MASK == 1) { s_ = ss[c]; h_ = ss[C + c]; }
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-  for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
-    const long long b = e / P;
+  for (unsigned e = e0 + threadIdx.x * V; e < e1; e += 256 * V) {
+    const unsigned b = fdiv(e, dP);
     const size_t ad = ((size_t)b * C + c) * P + (size_t)(e - b * P);
-    float g = gin[ad];
-    const float xv = x[ad];
-    if (MASK == 1) g = (xv * s_ + h_ > 0.f) ? g : 0.f;
-    if (MASK == 2) {
-      g = (v[ad] > 0.f) ? g : 0.f;
-      gout[ad] = g;
+    float g[V], xv[V], vv[V], x2v[V];
+    if constexpr (V == 4) {
+      *(float4*)g = *(const float4*)(gin + ad);
+      *(float4*)xv = *(const float4*)(x + ad);
+      if (MASK == 2) *(float4*)vv = *(const float4*)(v + ad);
+      if (TWO) *(float4*)x2v = *(const float4*)(x2 + ad);
+    } else {
+      g[0] = gin[ad];
+      xv[0] = x[ad];
+      if (MASK == 2) vv[0] = v[ad];
+      if (TWO) x2v[0] = x2[ad];
     }
-    a0 += g;
-    a1 += g * ((xv - mean) * invstd);
-    if (TWO) a2 += g * ((x2[ad] - mean2) * invstd2);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      if (MASK == 1) g[j] = (xv[j] * s_ + h_ > 0.f) ? g[j] : 0.f;
+      if (MASK == 2) g[j] = (vv[j] > 0.f) ? g[j] : 0.f;
+      a0 += g[j];
+      a1 += g[j] * ((xv[j] - mean) * invstd);
+      if (TWO) a2 += g[j] * ((x2v[j] - mean2) * invstd2);
+    }
+    if (MASK == 2) {
+      if constexpr (V == 4) *(float4*)(gout + ad) = *(float4*)g;
+      else gout[ad] = g[0];
+    }
   }
   sh[0][threadIdx.x] = a0;
   sh[1][threadIdx.x] = a1;
@@ -193,15 +226,31 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
 }
 
 // materialise the gradient w.r.t. a raw conv output: out = A1*mask*g + A2 + A3*x  (bwd5 = s,h,A1,A2,A3)
+template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ b5, int relu,
-                                                          float* __restrict__ out, int C, int P, size_t total) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)((i / P) % C);
-    const float xv = x[i];
-    float gv = g[i];
-    if (relu && !(xv * b5[c] + b5[C + c] > 0.f)) gv = 0.f;
-    out[i] = b5[2 * C + c] * gv + b5[3 * C + c] + b5[4 * C + c] * xv;
+                                                          float* __restrict__ out, int C, const FastDiv dP,
+                                                          const FastDiv dC, unsigned units) {
+  for (unsigned u = blockIdx.x * 256u + threadIdx.x; u < units; u += gridDim.x * 256u) {
+    const unsigned i = u * V;
+    const unsigned row = fdiv(i, dP);
+    const unsigned c = row - fdiv(row, dC) * (unsigned)C;
+    const float s = b5[c], h = b5[C + c], a1 = b5[2 * C + c], a2 = b5[3 * C + c], a3 = b5[4 * C + c];
+    float xv[V], gv[V], ov[V];
+    if constexpr (V == 4) {
+      *(float4*)xv = *(const float4*)(x + i);
+      *(float4*)gv = *(const float4*)(g + i);
+    } else {
+      xv[0] = x[i];
+      gv[0] = g[i];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float gm = (relu && !(xv[j] * s + h > 0.f)) ? 0.f : gv[j];
+      ov[j] = a1 * gm + a2 + a3 * xv[j];
+    }
+    if constexpr (V == 4) *(float4*)(out + i) = *(float4*)ov;
+    else out[i] = ov[0];
   }
 }
 
@@ -322,6 +371,7 @@ __global__ void fill_kernel(float* __restrict__ p, float v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+static inline bool aligned16(const void* p) { return ((size_t)p & 15) == 0; }   // null counts as aligned
 static inline unsigned grid_for(size_t n, int cap = 4096) {
   size_t b = (n + 255) / 256;
   if (b > (size_t)cap) b = cap;
@@ -367,8 +417,14 @@ int slv_bn_act(const float* x, const float* scale_shift, const float* res, const
                float* out, int Bn, int C, int64_t P, slv_stream_t stream) {
   SLV_CHECK_ARG(x && scale_shift && out && Bn > 0 && C > 0 && P > 0, "bad argument");
   const size_t total = (size_t)Bn * C * P;
-  hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, scale_shift,
-                     res, res_scale_shift, relu, out, C, (int)P, total);
+  SLV_CHECK_ARG(total < (1ull << 32), "more than 2^32 elements");
+  const FastDiv dP = make_fastdiv((unsigned)P), dC = make_fastdiv((unsigned)C);
+  if (P % 4 == 0 && aligned16(x) && aligned16(out) && aligned16(res))
+    hipLaunchKernelGGL((bn_act_kernel<4>), dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                       scale_shift, res, res_scale_shift, relu, out, C, dP, dC, (unsigned)(total / 4));
+  else
+    hipLaunchKernelGGL((bn_act_kernel<1>), dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                       scale_shift, res, res_scale_shift, relu, out, C, dP, dC, (unsigned)total);
   SLV_LAUNCH_CHECK();
   return 0;
 }
@@ -391,9 +447,18 @@ int slv_bn_bwd_reduce(const float* g, const float* x, const float* mean_invstd, 
   SLV_CHECK_ARG(!x2 || (mean_invstd2 && partial2), "second BN needs its stats and partial buffer");
   dim3 grid(C, nsplit);
   hipStream_t st = (hipStream_t)stream;
-#define SLV_RED(MASK, TWO)                                                                                   \
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<MASK, TWO>), grid, dim3(256), 0, st, g, x, mean_invstd,            \
-                     scale_shift_mask, v_mask, x2, mean_invstd2, g_out, partial, partial2, Bn, C, (int)P, nsplit)
+  const unsigned long long tot64 = (unsigned long long)Bn * (unsigned long long)P;
+  SLV_CHECK_ARG(tot64 < (1ull << 31), "more than 2^31 elements per channel");
+  const unsigned tot = (unsigned)tot64;
+  const bool vec = (P % 4 == 0) && aligned16(g) && aligned16(x) && aligned16(v_mask) && aligned16(x2) && aligned16(g_out);
+  unsigned per = (tot + nsplit - 1) / nsplit;
+  per = (per + 3u) & ~3u;                       // slices start on 4-element boundaries
+  const FastDiv dP = make_fastdiv((unsigned)P);
+#define SLV_RED2(MASK, TWO, V)                                                                               \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<MASK, TWO, V>), grid, dim3(256), 0, st, g, x, mean_invstd,         \
+                     scale_shift_mask, v_mask, x2, mean_invstd2, g_out, partial, partial2, C, (unsigned)P, dP, tot, \
+                     per, nsplit)
+#define SLV_RED(MASK, TWO) do { if (vec) SLV_RED2(MASK, TWO, 4); else SLV_RED2(MASK, TWO, 1); } while (0)
   if (v_mask) {
     if (x2) SLV_RED(2, true); else SLV_RED(2, false);
   } else if (scale_shift_mask) {
@@ -401,6 +466,7 @@ int slv_bn_bwd_reduce(const float* g, const float* x, const float* mean_invstd, 
   } else {
     if (x2) SLV_RED(0, true); else SLV_RED(0, false);
   }
+#undef SLV_RED2
 #undef SLV_RED
   SLV_LAUNCH_CHECK();
   return 0;
@@ -428,8 +494,14 @@ int slv_bn_bwd_apply(const float* g, const float* x, const float* bwd5, int relu
                      int64_t P, slv_stream_t stream) {
   SLV_CHECK_ARG(g && x && bwd5 && out && Bn > 0 && C > 0 && P > 0, "bad argument");
   const size_t total = (size_t)Bn * C * P;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, g, x,
-                     bwd5, relu, out, C, (int)P, total);
+  SLV_CHECK_ARG(total < (1ull << 32), "more than 2^32 elements");
+  const FastDiv dP = make_fastdiv((unsigned)P), dC = make_fastdiv((unsigned)C);
+  if (P % 4 == 0 && aligned16(g) && aligned16(x) && aligned16(out))
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       g, x, bwd5, relu, out, C, dP, dC, (unsigned)(total / 4));
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, g,
+                       x, bwd5, relu, out, C, dP, dC, (unsigned)total);
   SLV_LAUNCH_CHECK();
   return 0;
 }

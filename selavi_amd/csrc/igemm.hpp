@@ -45,25 +45,6 @@ enum { PRO_NONE = 0, PRO_ACT = 1, PRO_BWD = 2 };
 // ONE tap, so padding validity / address math is per chunk instead of per element.
 enum { KORD_CHAN = 0, KORD_TAP = 1 };
 
-// exact unsigned division by a runtime constant (Granlund-Montgomery round-up form)
-struct FastDiv {
-  unsigned m, s1, s2, d;
-};
-inline FastDiv make_fastdiv(unsigned d) {
-  FastDiv f;
-  f.d = d;
-  unsigned l = 0;
-  while ((1ull << l) < d) ++l;
-  f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-  f.s1 = l > 1 ? 1 : l;
-  f.s2 = l > 0 ? l - 1 : 0;
-  return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
-  const unsigned t = __umulhi(f.m, n);
-  return (t + ((n - t) >> f.s1)) >> f.s2;
-}
-
 constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond any buffer -> load returns 0
 
 struct IgemmArgs {
@@ -130,7 +111,13 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 // PRO: prologue of the gathered B operand (PRO_NONE / PRO_ACT) -- a template parameter so that the
 // steady-state loop stays one basic block.
 template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN>
-__global__ __launch_bounds__(256, ((MT >= 15 || MODE == MODE_WGRAD) ? 2 : 3)) void igemm_kernel(const IgemmArgs g) {
+#ifndef SLV_LB_CONV
+#define SLV_LB_CONV 3
+#endif
+#ifndef SLV_LB_WGRAD
+#define SLV_LB_WGRAD 2
+#endif
+__global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_WGRAD : SLV_LB_CONV))) void igemm_kernel(const IgemmArgs g) {
   constexpr int BM = MT * 16, BN = NT * 64;
   constexpr int AS = 18;
   constexpr bool BKF = (MODE == MODE_WGRAD || MODE == MODE_GEMM);  // B tile K-contiguous?
