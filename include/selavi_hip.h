@@ -153,6 +153,11 @@ int slv_bn_finalize(const double* sums, double count, const float* gamma, const 
                     float* running_mean /* nullable: no update */, float* running_var, float momentum,
                     float eps, float* mean_invstd /* [2][C] */, float* scale_shift /* [2][C] */, int C,
                     slv_stream_t stream);
+/* single-process BatchNorm (no SyncBN exchange): the two calls above in one launch */
+int slv_bn_stats_finalize(const float* psum, const float* psq, int nblk, double count, const float* gamma,
+                          const float* beta, float* running_mean /* nullable */, float* running_var,
+                          float momentum, float eps, float* mean_invstd, float* scale_shift, int C,
+                          slv_stream_t stream);
 int slv_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* mean_invstd /* nullable */,
                        float* scale_shift, int C, slv_stream_t stream);
@@ -174,6 +179,11 @@ int slv_bn_bwd_finalize(const double* sums, double count, const float* gamma, co
                         const float* scale_shift /* nullable: no relu mask */, float* bwd5 /* [5][C] */,
                         float* dgamma /* nullable */, float* dbeta, int accumulate, int C,
                         slv_stream_t stream);
+/* single-process: slv_bn_bwd_sums + slv_bn_bwd_finalize in one launch */
+int slv_bn_bwd_sums_finalize(const float* partial, int nsplit, double count, const float* gamma,
+                             const float* mean_invstd, const float* scale_shift /* nullable */,
+                             float* bwd5, float* dgamma /* nullable */, float* dbeta, int accumulate, int C,
+                             slv_stream_t stream);
 /* out = A1*mask*g + A2 + A3*x : the gradient w.r.t. the raw conv output, materialised (may alias g) */
 int slv_bn_bwd_apply(const float* g, const float* x, const float* bwd5, int relu, float* out, int Bn,
                      int C, int64_t P, slv_stream_t stream);

@@ -615,6 +615,43 @@ int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const floa
   return 0;
 }
 
+// LDS-tiled variant for <= 9 taps: a workgroup owns a 32 (co) x 32 (ci) tile; reads are 32*taps-float runs,
+// writes are 128-byte runs in both target layouts; padding channels are written as zeros (no memset).
+__global__ __launch_bounds__(256) void w_transform_tiled_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                                               float* __restrict__ wt, int Cout, int Cin, int taps,
+                                                               const TapMap tm, int CpIn, int CpOut) {
+  __shared__ float t[32][32 * 9 + 1];
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int row = 32 * taps;
+  for (int idx = threadIdx.x; idx < 32 * row; idx += 256) {
+    const int co_l = idx / row, r = idx - co_l * row;
+    const int co = co0 + co_l, ci = ci0 + r / taps;
+    t[co_l][r] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci0) * taps + r] : 0.f;
+  }
+  __syncthreads();
+  if (wf) {
+    for (int idx = threadIdx.x; idx < 32 * row; idx += 256) {
+      const int co_l = idx / row, r2 = idx - co_l * row;
+      const int tap = r2 >> 5, ci_l = r2 & 31;
+      const int co = co0 + co_l, ci = ci0 + ci_l;
+      if (co < Cout && ci < CpIn) wf[((size_t)co * taps + tap) * CpIn + ci] = t[co_l][ci_l * taps + tap];
+    }
+  }
+  if (wt) {
+    const int colim = CpOut ? CpOut : Cout;
+    for (int idx = threadIdx.x; idx < 32 * row; idx += 256) {
+      const int ci_l = idx / row, r2 = idx - ci_l * row;
+      const int tap = r2 >> 5, co_l = r2 & 31;
+      const int co = co0 + co_l, ci = ci0 + ci_l;
+      if (ci < Cin && co < colim && tm.nt[tap] != 0) {
+        const float v = t[co_l][ci_l * taps + tap];
+        if (CpOut) wt[(size_t)tm.off[tap] + ((size_t)ci * tm.nt[tap] + tm.j[tap]) * CpOut + co] = v;
+        else wt[(size_t)tm.off[tap] + ((size_t)ci * Cout + co) * tm.nt[tap] + tm.j[tap]] = v;
+      }
+    }
+  }
+}
+
 size_t slv_conv_wf_elems(const int32_t* geom) {
   Geom g;
   if (read_geom(geom, g) != 0) return 0;
@@ -657,6 +694,13 @@ int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf, float* 
   // taps whose parity class has an empty lattice (input extent smaller than the stride) keep nt = 0:
   // no input position ever sees them, the kernel skips them
   hipStream_t st = (hipStream_t)stream;
+  if (taps <= 9) {
+    const int cin_ext = wf ? df.Cp : g.Cin, cout_ext = cp_out ? cp_out : g.Cout;
+    hipLaunchKernelGGL(w_transform_tiled_kernel, dim3((cin_ext + 31) / 32, (cout_ext + 31) / 32), dim3(256), 0, st, w,
+                       wf, wt, g.Cout, g.Cin, taps, tm, df.Cp, cp_out);
+    SLV_LAUNCH_CHECK();
+    return 0;
+  }
   if (wf && df.Cp != g.Cin) SLV_HIP(hipMemsetAsync(wf, 0, sizeof(float) * (size_t)df.M * df.Kd, st));
   if (wt && cp_out && cp_out != g.Cout) SLV_HIP(hipMemsetAsync(wt, 0, sizeof(float) * wt_elems, st));
   const size_t nel = (size_t)g.Cout * g.Cin * taps;

@@ -37,14 +37,13 @@ __global__ __launch_bounds__(256) void bn_partials_to_sums_kernel(const float* _
 }
 
 // sums -> mean/invstd (saved for backward), scale/shift (consumer prologue), running stats update
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ rmean,
-                                   float* __restrict__ rvar, float momentum, float eps,
-                                   float* __restrict__ mean_invstd, float* __restrict__ scale_shift, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double mean = sums[c] / count;
-  double var = sums[C + c] / count - mean * mean;  // biased
+__device__ __forceinline__ void bn_finalize_one(int c, double sum, double sq, double count,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                                float eps, float* __restrict__ mean_invstd,
+                                                float* __restrict__ scale_shift, int C) {
+  const double mean = sum / count;
+  double var = sq / count - mean * mean;  // biased
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float meanf = (float)mean;
@@ -58,6 +57,42 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
     rmean[c] = (1.f - momentum) * rmean[c] + momentum * meanf;
     rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
   }
+}
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, float momentum, float eps,
+                                   float* __restrict__ mean_invstd, float* __restrict__ scale_shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  bn_finalize_one(c, sums[c], sums[C + c], count, gamma, beta, rmean, rvar, momentum, eps, mean_invstd, scale_shift, C);
+}
+// single-process BatchNorm: partial reduction and finalize in one launch (one workgroup per channel)
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ ps,
+                                                               const float* __restrict__ pq, int nblk, double count,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ rmean,
+                                                               float* __restrict__ rvar, float momentum, float eps,
+                                                               float* __restrict__ mean_invstd,
+                                                               float* __restrict__ scale_shift, int C) {
+  __shared__ double sh[2][256];
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) {
+    s += (double)ps[(size_t)c * nblk + i];
+    q += (double)pq[(size_t)c * nblk + i];
+  }
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    bn_finalize_one(c, sh[0][0], sh[1][0], count, gamma, beta, rmean, rvar, momentum, eps, mean_invstd, scale_shift, C);
 }
 
 __global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -196,14 +231,11 @@ __global__ void bn_bwd_sums_kernel(const float* __restrict__ part, int nsplit, i
 
 // dx = A1*g' + A2 + A3*x  with  A1 = gamma*invstd, A3 = -A1*c2*invstd, A2 = -A1*c1 - A3*mean,
 // c1 = sum g'/n, c2 = sum g' xhat / n.   bwd5 = {s, h, A1, A2, A3} (s,h = forward scale/shift for the mask)
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ mi,
-                                       const float* __restrict__ ss, float* __restrict__ bwd5,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                       int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double sg = sums[c], sgx = sums[C + c];
+__device__ __forceinline__ void bn_bwd_finalize_one(int c, double sg, double sgx, double count,
+                                                    const float* __restrict__ gamma, const float* __restrict__ mi,
+                                                    const float* __restrict__ ss, float* __restrict__ bwd5,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                    int accumulate, int C) {
   const float invstd = mi[C + c], mean = mi[c];
   const float A1 = gamma[c] * invstd;
   const float c1 = (float)(sg / count), c2 = (float)(sgx / count);
@@ -223,6 +255,30 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
       dbeta[c] = (float)sg;
     }
   }
+}
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mi,
+                                       const float* __restrict__ ss, float* __restrict__ bwd5,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                       int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  bn_bwd_finalize_one(c, sums[c], sums[C + c], count, gamma, mi, ss, bwd5, dgamma, dbeta, accumulate, C);
+}
+// single-process: slice partials -> sums -> coefficients in one launch (thread per channel)
+__global__ void bn_bwd_sums_finalize_kernel(const float* __restrict__ part, int nsplit, double count,
+                                            const float* __restrict__ gamma, const float* __restrict__ mi,
+                                            const float* __restrict__ ss, float* __restrict__ bwd5,
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                            int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    a += (double)part[((size_t)c * nsplit + s) * 2];
+    b += (double)part[((size_t)c * nsplit + s) * 2 + 1];
+  }
+  bn_bwd_finalize_one(c, a, b, count, gamma, mi, ss, bwd5, dgamma, dbeta, accumulate, C);
 }
 
 // materialise the gradient w.r.t. a raw conv output: out = A1*mask*g + A2 + A3*x  (bwd5 = s,h,A1,A2,A3)
@@ -404,6 +460,17 @@ int slv_bn_finalize(const double* sums, double count, const float* gamma, const 
   return 0;
 }
 
+int slv_bn_stats_finalize(const float* psum, const float* psq, int nblk, double count, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                          float* mean_invstd, float* scale_shift, int C, slv_stream_t stream) {
+  SLV_CHECK_ARG(psum && psq && nblk > 0 && gamma && beta && mean_invstd && scale_shift && C > 0 && count > 0,
+                "bad argument");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, psum, psq, nblk, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, mean_invstd, scale_shift, C);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
 int slv_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* mean_invstd, float* scale_shift, int C, slv_stream_t stream) {
   SLV_CHECK_ARG(gamma && beta && running_mean && running_var && scale_shift && C > 0, "bad argument");
@@ -486,6 +553,16 @@ int slv_bn_bwd_finalize(const double* sums, double count, const float* gamma, co
   SLV_CHECK_ARG(sums && gamma && mean_invstd && bwd5 && C > 0 && count > 0, "bad argument");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, count,
                      gamma, mean_invstd, scale_shift, bwd5, dgamma, dbeta, accumulate, C);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_bn_bwd_sums_finalize(const float* partial, int nsplit, double count, const float* gamma,
+                             const float* mean_invstd, const float* scale_shift, float* bwd5, float* dgamma,
+                             float* dbeta, int accumulate, int C, slv_stream_t stream) {
+  SLV_CHECK_ARG(partial && nsplit > 0 && gamma && mean_invstd && bwd5 && C > 0 && count > 0, "bad argument");
+  hipLaunchKernelGGL(bn_bwd_sums_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial,
+                     nsplit, count, gamma, mean_invstd, scale_shift, bwd5, dgamma, dbeta, accumulate, C);
   SLV_LAUNCH_CHECK();
   return 0;
 }

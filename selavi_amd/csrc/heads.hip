@@ -154,30 +154,42 @@ __global__ __launch_bounds__(256) void heads_linear_bwd_w_kernel(const float* __
   }
 }
 
-// dx[g][b][k] = (mask ? mask*msc : 1) * sum_n dout[g][b][n] * W[g][n][k]     (thread per k, BB rows at a time)
+// dx[g][b][k] = (mask ? mask*msc : 1) * sum_n dout[g][b][n] * W[g][n][k]
+// Weight-bandwidth bound (20 heads x OUT x IN floats, 16 rows): a workgroup owns 32 consecutive k of one
+// head; its 8 thread groups take n = r, r+8, ... (so 8 weight rows are in flight per step) and are
+// combined through LDS in a fixed order.  BB rows of dout at a time.
 template <bool MASK, int BB>
 __global__ __launch_bounds__(256) void heads_linear_bwd_x_kernel(const float* __restrict__ dout, const PtrTab W,
                                                                 const float* __restrict__ mask, float msc,
                                                                 float* __restrict__ dx, int B, int IN, int OUT) {
+  __shared__ float red[8][BB][33];
   const int g = blockIdx.y, b0 = blockIdx.z * BB;
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= IN) return;
+  const int kl = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + kl;
   const float* __restrict__ w = W.p[g];
   float acc[BB];
 #pragma unroll
   for (int i = 0; i < BB; ++i) acc[i] = 0.f;
-  for (int n = 0; n < OUT; ++n) {
-    const float wv = w[(size_t)n * IN + k];
+  if (k < IN) {
+    for (int n = r; n < OUT; n += 8) {
+      const float wv = w[(size_t)n * IN + k];
 #pragma unroll
-    for (int i = 0; i < BB; ++i) {
-      if (b0 + i < B) acc[i] += dout[((size_t)g * B + b0 + i) * OUT + n] * wv;
+      for (int i = 0; i < BB; ++i) {
+        if (b0 + i < B) acc[i] += dout[((size_t)g * B + b0 + i) * OUT + n] * wv;
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < BB; ++i) {
-    if (b0 + i < B) {
+  for (int i = 0; i < BB; ++i) red[r][i][kl] = acc[i];
+  __syncthreads();
+  // 256 threads finish BB x 32 outputs: thread -> (row i = tid / 32 + 8*j, k = tid % 32)
+  for (int i = r; i < BB; i += 8) {
+    if (b0 + i < B && k < IN) {
+      float v = red[0][i][kl];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) v += red[q][i][kl];
       const size_t ad = ((size_t)g * B + b0 + i) * IN + k;
-      dx[ad] = MASK ? acc[i] * mask[ad] * msc : acc[i];
+      dx[ad] = MASK ? v * mask[ad] * msc : v;
     }
   }
 }
@@ -344,7 +356,7 @@ int slv_heads_linear_bwd_x(const float* dout, const void* const* W, const float*
   PtrTab tw;
   fill_tab(tw, W, G);
   constexpr int BB = 16;
-  dim3 grid((IN + 255) / 256, G, (B + BB - 1) / BB);
+  dim3 grid((IN + 31) / 32, G, (B + BB - 1) / BB);
   if (mask)
     hipLaunchKernelGGL((heads_linear_bwd_x_kernel<true, BB>), grid, dim3(256), 0, (hipStream_t)stream, dout, tw,
                        mask, mask_scale, dx, B, IN, OUT);

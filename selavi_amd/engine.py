@@ -36,15 +36,16 @@ def _as5d(t):
     return t if t.dim() == 5 else t.unsqueeze(2)
 
 
-def conv_bn(ctx, x, conv, bn):
-    """x: materialised tensor or Raw (then relu(bn(x)) is applied on load).  -> Raw"""
+def conv_bn(ctx, x, conv, bn, need_dx=True):
+    """x: materialised tensor or Raw (then relu(bn(x)) is applied on load).  -> Raw
+    need_dx=False: first conv of a trunk (no gradient w.r.t. the network input is ever taken)."""
     if isinstance(x, Raw):
         xin, in_ss = x.y, x.ss
     else:
         xin, in_ss = x, None
     plan = ops.ConvPlan.get(tuple(xin.shape), conv.out_channels, conv.kernel3, conv.stride3, conv.padding3, xin.device)
     # one pass over the weights makes the forward (tap-major) and backward-data layouts of this step
-    wf, wt = ops.conv_w_transform(plan, conv.weight, need_wt=ctx.training)
+    wf, wt = ops.conv_w_transform(plan, conv.weight, need_wt=ctx.training and need_dx)
     y, ssum, ssq = ops.conv_fwd(plan, xin, conv.weight, in_ss=in_ss, in_relu=in_ss is not None,
                                 want_stats=ctx.training, wf=wf)
     if ctx.training:
@@ -150,7 +151,7 @@ def block_bwd(ctx, rec, dv, need_du=True):
 def video_forward(ctx, base, x):
     """R(2+1)D-18 (torchvision VideoResNet).  Returns (feat [B,512], saved record)."""
     st = base.stem
-    r0 = conv_bn(ctx, x, st[0], st[1])
+    r0 = conv_bn(ctx, x, st[0], st[1], need_dx=False)
     r1 = conv_bn(ctx, r0, st[3], st[4])
     u = tail(ctx, r1)
     recs = []
@@ -180,7 +181,7 @@ def video_backward(ctx, saved, dfeat):
 def audio_forward(ctx, base, spec):
     """ResNet-9/18 on 1 x F x T' spectrograms (torchvision ResNet), 2-D = 3-D with T=1."""
     x = _as5d(spec)
-    r0 = conv_bn(ctx, x, base.conv1, base.bn1)
+    r0 = conv_bn(ctx, x, base.conv1, base.bn1, need_dx=False)
     u, idx = ops.bnrelu_maxpool_fwd(r0.y, r0.ss)
     recs = []
     for layer in (base.layer1, base.layer2, base.layer3, base.layer4):

@@ -246,13 +246,16 @@ def bn_train_finalize(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps,
     ``sync`` = (group, world_count): SyncBN -- sums are all-reduced, count is the global count."""
     Cc = gamma.numel()
     dev = gamma.device
-    sums = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
-    C.slv_bn_partials_to_sums(ptr(ssum), ptr(ssq), ssum.shape[1], Cc, ptr(sums), stream())
-    if sync is not None:
-        _allreduce(sums, sync[0])
-        count = count * sync[1]
     mi = _f32(2, Cc, device=dev)
     ss = _f32(2, Cc, device=dev)
+    if sync is None:
+        C.slv_bn_stats_finalize(ptr(ssum), ptr(ssq), ssum.shape[1], float(count), ptr(gamma), ptr(beta), ptr(rmean),
+                                ptr(rvar), float(momentum), float(eps), ptr(mi), ptr(ss), Cc, stream())
+        return mi, ss
+    sums = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+    C.slv_bn_partials_to_sums(ptr(ssum), ptr(ssq), ssum.shape[1], Cc, ptr(sums), stream())
+    _allreduce(sums, sync[0])
+    count = count * sync[1]
     C.slv_bn_finalize(ptr(sums), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(momentum),
                       float(eps), ptr(mi), ptr(ss), Cc, stream())
     return mi, ss
@@ -299,11 +302,15 @@ def bn_bwd(g, x, mi, gamma, ss_mask=None, v_mask=None, x2=None, mi2=None, gamma2
         if pt_ is None:
             outs.append(None)
             continue
+        b5 = _f32(5, Cc, device=dev)
+        if sync is None:
+            C.slv_bn_bwd_sums_finalize(ptr(pt_), ns, count, ptr(ga_), ptr(mi_), ptr(ss_), ptr(b5), ptr(dg_), ptr(db_),
+                                       0, Cc, stream())
+            outs.append(b5)
+            continue
         sums = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
         C.slv_bn_bwd_sums(ptr(pt_), ns, Cc, ptr(sums), stream())
-        if sync is not None:
-            _allreduce(sums, sync[0])
-        b5 = _f32(5, Cc, device=dev)
+        _allreduce(sums, sync[0])
         C.slv_bn_bwd_finalize(ptr(sums), count, ptr(ga_), ptr(mi_), ptr(ss_), ptr(b5), ptr(dg_), ptr(db_), 0, Cc,
                               stream())
         outs.append(b5)
