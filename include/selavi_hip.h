@@ -131,8 +131,17 @@ int slv_conv_fwd(const int32_t* geom, const float* x, const float* w /* nullable
                  float* stat_sum /* nullable */, float* stat_sq, void* ws /* nullable if 0 bytes */,
                  size_t ws_bytes, int32_t cfg, slv_stream_t stream);
 size_t slv_conv_dgrad_ws_bytes(const int32_t* geom, int32_t cfg);
+/* Optional fused BatchNorm-backward reduction (the BN of the layer that produced this conv's input,
+ * consumed through ReLU): with g = dx as stored, x = bnr_x (raw output of that layer, shape of dx) and
+ * g' = g * (x*scale + shift > 0), every channel gets slv_conv_dgrad_bnr_slots() partial pairs
+ * bnr_part[c][slot] = {sum g', sum g' * (x - mean) * invstd} -- the input of slv_bn_bwd_sums[_finalize];
+ * replaces a separate slv_bn_bwd_reduce pass over g and x. */
+int32_t slv_conv_dgrad_bnr_slots(const int32_t* geom, int32_t cfg);
 int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* wt, const int32_t* tab,
-                   float* dx, const float* addend /* nullable, may alias dx */, void* ws /* nullable if 0 bytes */,
+                   float* dx, const float* addend /* nullable, may alias dx */,
+                   const float* bnr_x /* nullable: no fused reduction */,
+                   const float* bnr_scale_shift /* [2][Cin] */, const float* bnr_mean_invstd /* [2][Cin] */,
+                   float* bnr_part /* [Cin][slots][2] */, void* ws /* nullable if 0 bytes */,
                    size_t ws_bytes, int32_t cfg, slv_stream_t stream);
 size_t slv_conv_wgrad_ws_bytes(const int32_t* geom, int32_t cfg);
 /* dw = sum_p dy[co,p] * act(x_in)[ci, p*stride+tap-pad]; deterministic split-K via `ws`.  tab = fwd table */

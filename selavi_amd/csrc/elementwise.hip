@@ -217,16 +217,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-__global__ void bn_bwd_sums_kernel(const float* __restrict__ part, int nsplit, int C, double* __restrict__ sums) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int s = 0; s < nsplit; ++s) {
-    a += (double)part[((size_t)c * nsplit + s) * 2];
-    b += (double)part[((size_t)c * nsplit + s) * 2 + 1];
+// one workgroup per channel: fp64 tree over the slice partials (thousands of slots when they come from
+// a dgrad epilogue); fixed order
+__device__ __forceinline__ void bn_bwd_block_sums(const float* __restrict__ part, int nsplit, int c, double& a,
+                                                  double& b) {
+  __shared__ double sh[2][256];
+  double x = 0.0, y = 0.0;
+  for (int s = threadIdx.x; s < nsplit; s += 256) {
+    const float2 v = *(const float2*)(part + ((size_t)c * nsplit + s) * 2);
+    x += (double)v.x;
+    y += (double)v.y;
   }
-  sums[c] = a;
-  sums[C + c] = b;
+  sh[0][threadIdx.x] = x;
+  sh[1][threadIdx.x] = y;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  a = sh[0][0];
+  b = sh[1][0];
+}
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ part, int nsplit, int C,
+                                                         double* __restrict__ sums) {
+  double a, b;
+  bn_bwd_block_sums(part, nsplit, blockIdx.x, a, b);
+  if (threadIdx.x == 0) {
+    sums[blockIdx.x] = a;
+    sums[C + blockIdx.x] = b;
+  }
 }
 
 // dx = A1*g' + A2 + A3*x  with  A1 = gamma*invstd, A3 = -A1*c2*invstd, A2 = -A1*c1 - A3*mean,
@@ -265,20 +287,16 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
   if (c >= C) return;
   bn_bwd_finalize_one(c, sums[c], sums[C + c], count, gamma, mi, ss, bwd5, dgamma, dbeta, accumulate, C);
 }
-// single-process: slice partials -> sums -> coefficients in one launch (thread per channel)
-__global__ void bn_bwd_sums_finalize_kernel(const float* __restrict__ part, int nsplit, double count,
-                                            const float* __restrict__ gamma, const float* __restrict__ mi,
-                                            const float* __restrict__ ss, float* __restrict__ bwd5,
-                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                            int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int s = 0; s < nsplit; ++s) {
-    a += (double)part[((size_t)c * nsplit + s) * 2];
-    b += (double)part[((size_t)c * nsplit + s) * 2 + 1];
-  }
-  bn_bwd_finalize_one(c, a, b, count, gamma, mi, ss, bwd5, dgamma, dbeta, accumulate, C);
+// single-process: slice partials -> sums -> coefficients in one launch (workgroup per channel)
+__global__ __launch_bounds__(256) void bn_bwd_sums_finalize_kernel(const float* __restrict__ part, int nsplit,
+                                                                  double count, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mi,
+                                                                  const float* __restrict__ ss, float* __restrict__ bwd5,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  int accumulate, int C) {
+  double a, b;
+  bn_bwd_block_sums(part, nsplit, blockIdx.x, a, b);
+  if (threadIdx.x == 0) bn_bwd_finalize_one(blockIdx.x, a, b, count, gamma, mi, ss, bwd5, dgamma, dbeta, accumulate, C);
 }
 
 // materialise the gradient w.r.t. a raw conv output: out = A1*mask*g + A2 + A3*x  (bwd5 = s,h,A1,A2,A3)
@@ -541,8 +559,7 @@ int slv_bn_bwd_reduce(const float* g, const float* x, const float* mean_invstd, 
 
 int slv_bn_bwd_sums(const float* partial, int nsplit, int C, double* sums, slv_stream_t stream) {
   SLV_CHECK_ARG(partial && sums && nsplit > 0 && C > 0, "bad argument");
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nsplit,
-                     C, sums);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nsplit, C, sums);
   SLV_LAUNCH_CHECK();
   return 0;
 }
@@ -561,8 +578,8 @@ int slv_bn_bwd_sums_finalize(const float* partial, int nsplit, double count, con
                              const float* mean_invstd, const float* scale_shift, float* bwd5, float* dgamma,
                              float* dbeta, int accumulate, int C, slv_stream_t stream) {
   SLV_CHECK_ARG(partial && nsplit > 0 && gamma && mean_invstd && bwd5 && C > 0 && count > 0, "bad argument");
-  hipLaunchKernelGGL(bn_bwd_sums_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial,
-                     nsplit, count, gamma, mean_invstd, scale_shift, bwd5, dgamma, dbeta, accumulate, C);
+  hipLaunchKernelGGL(bn_bwd_sums_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nsplit, count,
+                     gamma, mean_invstd, scale_shift, bwd5, dgamma, dbeta, accumulate, C);
   SLV_LAUNCH_CHECK();
   return 0;
 }

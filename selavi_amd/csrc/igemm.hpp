@@ -44,6 +44,9 @@ enum { PRO_NONE = 0, PRO_ACT = 1, PRO_BWD = 2 };
 // tap-major (k = tap*Cpad + c with Cpad = round16(C), transformed weights): every 16-deep chunk then has
 // ONE tap, so padding validity / address math is per chunk instead of per element.
 enum { KORD_CHAN = 0, KORD_TAP = 1 };
+// CONV epilogue: plain store (+ addend, + forward BN statistics) or store + BatchNorm-backward partial sums
+// (IgemmArgs::R).  A template parameter: the plain kernels keep their register budget.
+enum { EPI_PLAIN = 0, EPI_BNR = 1 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond any buffer -> load returns 0
 
@@ -67,6 +70,14 @@ struct IgemmArgs {
   const float* bias; // GEMM: optional per-column bias
   float* stat_sum;   // CONV: [M][nblkN] per-channel partial sums of the output (or null)
   float* stat_sq;
+  // CONV (backward-data) epilogue: BatchNorm-backward reductions of the layer that PRODUCED this launch's
+  // input tensor: with g = the value stored at C (incl. addend), x = R at the same index,
+  // g' = g * (x*s + h > 0):  rpart[m][rslot0 + nblk] = { sum g', sum g' * (x - mean) * invstd }
+  const float* R;    // raw conv output of that layer (same shape/indexing as C) or null
+  const float* rss;  // [2][M] scale, shift (ReLU mask)
+  const float* rmi;  // [2][M] mean, invstd
+  float* rpart;      // [M][rslots][2]
+  int rslots, rslot0;
   int M, Kd;
   long long Ntot;    // columns: lattice positions (CONV) or Cin*taps (WGRAD) or N (GEMM)
   int nblkM, nblkN;
@@ -110,7 +121,7 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 // preconditions: CONV/GEMM Kd % 4 == 0; WGRAD To*Ho*Wo % 4 == 0 and no A prologue.
 // PRO: prologue of the gathered B operand (PRO_NONE / PRO_ACT) -- a template parameter so that the
 // steady-state loop stays one basic block.
-template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN>
+template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN, int EPI = EPI_PLAIN>
 #ifndef SLV_LB_CONV
 #define SLV_LB_CONV 3
 #endif
@@ -494,29 +505,104 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
       obase[j] = (size_t)b * g.M * dP + (size_t)(q0 * g.dmul0 + g.dorg0) * (g.D1 * g.D2) +
                  (size_t)(q1 * g.dmul1 + g.dorg1) * g.D2 + (size_t)(q2 * g.dmul2 + g.dorg2);
     }
+    float* red = smem;            // [2][4 waves][BM]   (the main loop ended with a barrier)
+    if constexpr (EPI == EPI_PLAIN) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      if (i < mtv) {
+      for (int i = 0; i < MT; ++i) {
+        if (i < mtv) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = i * 16 + fk * 4 + r;
-          if (m < mrem) {
+          for (int r = 0; r < 4; ++r) {
+            const int m = i * 16 + fk * 4 + r;
+            if (m < mrem) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              if (cok[j]) {
-                const size_t ad = obase[j] + (size_t)(m0 + m) * dP;
-                float v = acc[i][j][r];
-                if (g.E) v += g.E[ad];
-                Cp[ad] = v;
+              for (int j = 0; j < NT; ++j) {
+                if (cok[j]) {
+                  const size_t ad = obase[j] + (size_t)(m0 + m) * dP;
+                  float v = acc[i][j][r];
+                  if (g.E) v += g.E[ad];
+                  Cp[ad] = v;
+                }
               }
             }
           }
         }
       }
+    } else {
+    float* rpar = smem + 8 * BM;  // [4][BM] s, h, mean, invstd of this block's rows
+    constexpr bool bnr = true;
+    if (bnr) {
+      for (int m = tid; m < BM; m += 256) {
+        const int mm = (m0 + m < g.M) ? m0 + m : g.M - 1;
+        rpar[m] = g.rss[mm];
+        rpar[BM + m] = g.rss[g.M + mm];
+        rpar[2 * BM + m] = g.rmi[mm];
+        rpar[3 * BM + m] = g.rmi[g.M + mm];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (i < mtv) {
+        // all loads of this 16-row tile first (they are independent; the stores below would otherwise
+        // fence them one by one), then the arithmetic and the stores
+        float xv[4][NT], ev[4][NT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = i * 16 + fk * 4 + r;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const bool ok = (m < mrem) && cok[j];
+            const size_t ad = obase[j] + (size_t)(m0 + m) * dP;
+            xv[r][j] = (bnr && ok) ? g.R[ad] : 0.f;
+            ev[r][j] = (g.E && ok) ? g.E[ad] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = i * 16 + fk * 4 + r;
+          const bool mok = m < mrem;
+          float ps = 0.f, ph = 0.f, pm = 0.f, pi = 0.f, s0 = 0.f, s1 = 0.f;
+          if (bnr) { ps = rpar[m]; ph = rpar[BM + m]; pm = rpar[2 * BM + m]; pi = rpar[3 * BM + m]; }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            if (mok && cok[j]) {
+              const size_t ad = obase[j] + (size_t)(m0 + m) * dP;
+              const float v = acc[i][j][r] + ev[r][j];
+              Cp[ad] = v;
+              const float gm = (xv[r][j] * ps + ph > 0.f) ? v : 0.f;
+              s0 += gm;
+              s1 += gm * ((xv[r][j] - pm) * pi);
+            }
+          }
+          if (bnr) {  // wave-uniform; all lanes take part in the shuffles
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+              s0 += __shfl_xor(s0, o, 64);
+              s1 += __shfl_xor(s1, o, 64);
+            }
+            if (fi == 0) {
+              red[wave * BM + m] = s0;
+              red[(4 + wave) * BM + m] = s1;
+            }
+          }
+        }
+      }
+    }
+    if (bnr) {
+      __syncthreads();
+      for (int m = tid; m < BM; m += 256) {
+        if (m < mrem) {
+          const float a = ((red[m] + red[BM + m]) + red[2 * BM + m]) + red[3 * BM + m];
+          const float b = ((red[4 * BM + m] + red[5 * BM + m]) + red[6 * BM + m]) + red[7 * BM + m];
+          float* o = g.rpart + ((size_t)(m0 + m) * g.rslots + g.rslot0 + nblk) * 2;
+          o[0] = a;
+          o[1] = b;
+        }
+      }
+    }
     }
     if (g.stat_sum) {
       // per-channel partial statistics of this block's columns (fixed order -> deterministic)
-      float* red = smem;  // [2][4 waves][BM]   (main loop ended with a barrier)
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -584,6 +670,12 @@ inline void launch_igemm(const IgemmArgs& a, int splits, bool vec_a, hipStream_t
   const bool act = (MODE != MODE_GEMM) && a.b_pro == PRO_ACT;
 #define SLV_L(VA_, PRO_) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, VA_, PRO_>), grid, dim3(256), 0, st, a)
   if constexpr (MODE == MODE_CONV) {
+    if (a.R) {  // backward-data with the fused BatchNorm-backward reduction (never has an operand prologue)
+      if (a.kord == KORD_TAP) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_TAP, EPI_BNR>), grid, dim3(256), 0, st, a);
+      else if (vec_a) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_CHAN, EPI_BNR>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, false, PRO_NONE, KORD_CHAN, EPI_BNR>), grid, dim3(256), 0, st, a);
+      return;
+    }
     if (a.kord == KORD_TAP) {  // tap-major K: Kd is a multiple of 16 and A is 64-byte aligned -> always vector A loads
       if (act) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_ACT, KORD_TAP>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_TAP>), grid, dim3(256), 0, st, a);

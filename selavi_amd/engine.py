@@ -11,7 +11,12 @@ materialised.  See csrc/igemm.hpp.
 """
 import torch
 
+import os
+
 from . import ops
+
+# BatchNorm-backward partial sums from the dgrad epilogue (True) or from a separate reduce pass (False)
+FUSE_BN_BWD_REDUCE = os.environ.get("SELAVI_FUSE_BNR", "1") == "1"
 
 
 class Raw:
@@ -64,11 +69,12 @@ def tail(ctx, r, res=None, res_raw=None, relu=True):
     return ops.bn_act(r.y, r.ss, res=res, relu=relu)
 
 
-def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, keep_g=False):
+def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, keep_g=False, fuse_bn=False):
     """Backward through conv `r.conv` given the gradient `g` w.r.t. the ACTIVATED output of r's BN
     (or the masked tail gradient when a_relu is False) and its folded BN-backward coefficients.
     Writes the weight gradient; returns the gradient w.r.t. the conv input (activated, if the
-    source is itself Raw) or None."""
+    source is itself Raw) or None.  fuse_bn (source is Raw, consumed through its own ReLU): the dgrad
+    epilogue also forms the source BN's backward partial sums -> returns (dx, part) for bn_bwd_own."""
     src = r.src
     if isinstance(src, Raw):
         xin, in_ss = src.y, src.ss
@@ -83,13 +89,17 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
     if not need_dx:
         return None
     wt = r.wt if r.wt is not None else ops.conv_wt_transform(r.plan, r.conv.weight)
-    return ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out)
+    if fuse_bn and not FUSE_BN_BWD_REDUCE:
+        return ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out), None
+    bnr = (src.y, src.ss, src.mi) if fuse_bn else None
+    return ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out, bnr=bnr)
 
 
-def bn_bwd_own(ctx, r, g):
-    """BN backward coefficients for Raw r consumed through relu(bn(.)) with upstream gradient g."""
+def bn_bwd_own(ctx, r, g, part=None):
+    """BN backward coefficients for Raw r consumed through relu(bn(.)) with upstream gradient g
+    (part: the partial sums, when the dgrad that produced g already formed them)."""
     dg, db = torch.empty_like(r.bn.weight), torch.empty_like(r.bn.bias)
-    b5, _, _ = ops.bn_bwd(g, r.y, r.mi, r.bn.weight, ss_mask=r.ss, sync=ctx.sync, dgamma=dg, dbeta=db)
+    b5, _, _ = ops.bn_bwd(g, r.y, r.mi, r.bn.weight, ss_mask=r.ss, sync=ctx.sync, dgamma=dg, dbeta=db, part=part)
     ctx.grads[id(r.bn.weight)] = dg
     ctx.grads[id(r.bn.bias)] = db
     return b5
@@ -135,8 +145,9 @@ def block_bwd(ctx, rec, dv, need_du=True):
     for i in range(n - 1, -1, -1):
         r = rec.chain[i]
         if i > 0:
-            g = backprop_raw(ctx, r, g, b5, a_relu, keep_g=(i == n - 1))  # dz is reused by the shortcut
-            b5 = bn_bwd_own(ctx, rec.chain[i - 1], g)
+            g, part = backprop_raw(ctx, r, g, b5, a_relu, keep_g=(i == n - 1),  # dz is reused by the shortcut
+                                   fuse_bn=True)
+            b5 = bn_bwd_own(ctx, rec.chain[i - 1], g, part)
             a_relu = True
         else:
             if ds is not None:
@@ -173,8 +184,8 @@ def video_backward(ctx, saved, dfeat):
     for rec in reversed(recs):
         dv = block_bwd(ctx, rec, dv)
     b5 = bn_bwd_own(ctx, r1, dv)
-    g = backprop_raw(ctx, r1, dv, b5, True)
-    b5 = bn_bwd_own(ctx, r0, g)
+    g, part = backprop_raw(ctx, r1, dv, b5, True, fuse_bn=True)
+    b5 = bn_bwd_own(ctx, r0, g, part)
     backprop_raw(ctx, r0, g, b5, True, need_dx=False)
 
 

@@ -64,6 +64,7 @@ class ConvPlan:
             raise ValueError(f"invalid forward launch configuration {self.cfg_fwd:#x}")
         self.ws_fwd = C.slv_conv_fwd_ws_bytes(self.gp, self.cfg_fwd)       # split-K scratch, 0 if unsplit
         self.ws_dgrad = C.slv_conv_dgrad_ws_bytes(self.gp, self.cfg_dgrad)
+        self.bnr_slots = C.slv_conv_dgrad_bnr_slots(self.gp, self.cfg_dgrad)
         self.ws_bytes = C.slv_conv_wgrad_ws_bytes(self.gp, self.cfg_wgrad)
 
     def candidates(self, op):
@@ -207,14 +208,21 @@ def conv_wt_transform(plan, w):
     return conv_w_transform(plan, w, need_wf=False)[1]
 
 
-def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out=None):
+def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out=None, bnr=None):
+    """dx = conv_transpose(dy) (+ addend).  bnr = (x, scale_shift, mean_invstd) of the layer that produced
+    this conv's input: the kernel epilogue then also emits that BatchNorm's backward partial sums and
+    (dx, part) is returned -- pass `part` to bn_bwd."""
     dx = out if out is not None else _f32(*plan.in_shape, device=dy.device)
     if bwd5 is not None:     # BN backward of the conv's own output: materialised, then a plain dgrad
         dy = bn_bwd_apply(dy, x_out, bwd5, relu, out=torch.empty_like(dy))
     ws = workspace(plan.ws_dgrad, dy.device) if plan.ws_dgrad else None
-    C.slv_conv_dgrad(plan.gp, ptr(dy), ptr(wt), ptr(plan.tab_dgrad), ptr(dx), ptr(addend), ptr(ws), plan.ws_dgrad,
-                     plan.cfg_dgrad, stream())
-    return dx
+    part = rx = rss = rmi = None
+    if bnr is not None:
+        rx, rss, rmi = bnr
+        part = _f32(plan.Cin, plan.bnr_slots, 2, device=dy.device)
+    C.slv_conv_dgrad(plan.gp, ptr(dy), ptr(wt), ptr(plan.tab_dgrad), ptr(dx), ptr(addend), ptr(rx), ptr(rss), ptr(rmi),
+                     ptr(part), ptr(ws), plan.ws_dgrad, plan.cfg_dgrad, stream())
+    return dx if bnr is None else (dx, part)
 
 
 def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, in_relu=False, out=None):
@@ -278,7 +286,7 @@ def bn_act(x, ss, res=None, res_ss=None, relu=True):
 
 
 def bn_bwd(g, x, mi, gamma, ss_mask=None, v_mask=None, x2=None, mi2=None, gamma2=None, ss2=None, sync=None,
-           dgamma=None, dbeta=None, dgamma2=None, dbeta2=None):
+           dgamma=None, dbeta=None, dgamma2=None, dbeta2=None, part=None):
     """BN backward reductions for the BN whose input is ``x`` and upstream gradient ``g``.
 
     mask: ``ss_mask`` (the BN's own scale/shift -> ReLU mask on its output) or ``v_mask`` (block
@@ -287,12 +295,17 @@ def bn_bwd(g, x, mi, gamma, ss_mask=None, v_mask=None, x2=None, mi2=None, gamma2
     Bn, Cc = x.shape[0], x.shape[1]
     P = x.numel() // (Bn * Cc)
     dev = x.device
-    ns = C.slv_bn_bwd_nsplit(Bn, Cc, P)
-    part = _f32(Cc, ns, 2, device=dev)
-    part2 = _f32(Cc, ns, 2, device=dev) if x2 is not None else None
-    gout = torch.empty_like(g) if v_mask is not None else None
-    C.slv_bn_bwd_reduce(ptr(g), ptr(x), ptr(mi), ptr(ss_mask), ptr(v_mask), ptr(x2), ptr(mi2), ptr(gout), ptr(part),
-                        ptr(part2), Bn, Cc, P, ns, stream())
+    gout = part2 = None
+    if part is not None:        # partial sums already formed by the producing dgrad's epilogue (ss_mask case)
+        assert ss_mask is not None and v_mask is None and x2 is None
+        ns = part.shape[1]
+    else:
+        ns = C.slv_bn_bwd_nsplit(Bn, Cc, P)
+        part = _f32(Cc, ns, 2, device=dev)
+        part2 = _f32(Cc, ns, 2, device=dev) if x2 is not None else None
+        gout = torch.empty_like(g) if v_mask is not None else None
+        C.slv_bn_bwd_reduce(ptr(g), ptr(x), ptr(mi), ptr(ss_mask), ptr(v_mask), ptr(x2), ptr(mi2), ptr(gout),
+                            ptr(part), ptr(part2), Bn, Cc, P, ns, stream())
     count = float(Bn * P)
     if sync is not None:
         count *= sync[1]

@@ -126,6 +126,22 @@ def test_conv_every_launch_configuration(geo):
                 acc = add.to(dev).clone()
                 ops.conv_dgrad(plan, dyg, wt, addend=acc, out=acc)
                 _close_l2(acc, xr.grad + add.double())
+                # fused BatchNorm-backward reduction of the producing layer (epilogue / split-K reduce)
+                xp = _mk(tuple(x.shape), 15)
+                ss = torch.stack([_mk((Cin,), 16).abs() + 0.5, _mk((Cin,), 17) * 0.3])
+                mi = torch.stack([_mk((Cin,), 18) * 0.2, _mk((Cin,), 19).abs() + 0.5])
+                acc2 = add.to(dev).clone()
+                dx2, part = ops.conv_dgrad(plan, dyg, wt, addend=acc2, out=acc2,
+                                           bnr=(xp.to(dev), ss.to(dev).contiguous(), mi.to(dev).contiguous()))
+                assert torch.equal(dx2, acc)
+                v = lambda t: t.double().view(1, -1, 1, 1, 1)
+                gfin = xr.grad + add.double()
+                gm = gfin * ((xp.double() * v(ss[0]) + v(ss[1])) > 0)
+                want0 = gm.sum((0, 2, 3, 4))
+                want1 = (gm * (xp.double() - v(mi[0])) * v(mi[1])).sum((0, 2, 3, 4))
+                assert part.shape[0] == Cin and part.shape[2] == 2
+                _close(part[:, :, 0].sum(1), want0, rtol=2e-4)
+                _close(part[:, :, 1].sum(1), want1, rtol=2e-4)
             else:
                 _close_l2(ops.conv_wgrad(plan, dyg, xg).view_as(w), wr.grad)
     assert ncfg >= 3
