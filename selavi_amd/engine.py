@@ -159,34 +159,66 @@ def block_bwd(ctx, rec, dv, need_du=True):
 
 
 # ------------------------------------------------------------------------------------------ trunks
+VIDEO_STAGES = ("stem", "layer1", "layer2", "layer3", "layer4")
+
+
+def _video_blocks(layer):
+    for blk in layer:
+        chain = [(blk.conv1[0][0], blk.conv1[0][1]), (blk.conv1[0][3], blk.conv1[1]),
+                 (blk.conv2[0][0], blk.conv2[0][1]), (blk.conv2[0][3], blk.conv2[1])]
+        ds = (blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+        yield chain, ds
+
+
+def video_stage_forward(ctx, base, stage, x):
+    """One stage of R(2+1)D-18 (torchvision VideoResNet): the stem, or a residual layer
+    (layer4 ends with the global average pool -> feat [B,512]).  Returns (output, saved record).
+    The trunk is cut into stages so that every stage is its own autograd node: under DDP the
+    gradients of layer4 (75 % of the parameters) are all-reduced while layers 3..1 still run backward."""
+    if stage == "stem":
+        st = base.stem
+        r0 = conv_bn(ctx, x, st[0], st[1], need_dx=False)
+        r1 = conv_bn(ctx, r0, st[3], st[4])
+        return tail(ctx, r1), (r0, r1)
+    u, recs = x, []
+    for chain, ds in _video_blocks(getattr(base, stage)):
+        rec = block_fwd(ctx, u, chain, ds)
+        recs.append(rec)
+        u = rec.v
+    if stage == "layer4":
+        return ops.avgpool_fwd(u), (recs, u)
+    return u, (recs, None)
+
+
+def video_stage_backward(ctx, stage, saved, dout):
+    """Gradient w.r.t. the stage input (None for the stem); parameter gradients land in ctx.grads."""
+    if stage == "stem":
+        r0, r1 = saved
+        b5 = bn_bwd_own(ctx, r1, dout)
+        g, part = backprop_raw(ctx, r1, dout, b5, True, keep_g=True, fuse_bn=True)   # dout belongs to autograd
+        b5 = bn_bwd_own(ctx, r0, g, part)
+        backprop_raw(ctx, r0, g, b5, True, need_dx=False)
+        return None
+    recs, u_last = saved
+    dv = ops.avgpool_bwd(dout.contiguous(), u_last) if stage == "layer4" else dout
+    for rec in reversed(recs):
+        dv = block_bwd(ctx, rec, dv)
+    return dv
+
+
 def video_forward(ctx, base, x):
-    """R(2+1)D-18 (torchvision VideoResNet).  Returns (feat [B,512], saved record)."""
-    st = base.stem
-    r0 = conv_bn(ctx, x, st[0], st[1], need_dx=False)
-    r1 = conv_bn(ctx, r0, st[3], st[4])
-    u = tail(ctx, r1)
-    recs = []
-    for layer in (base.layer1, base.layer2, base.layer3, base.layer4):
-        for blk in layer:
-            chain = [(blk.conv1[0][0], blk.conv1[0][1]), (blk.conv1[0][3], blk.conv1[1]),
-                     (blk.conv2[0][0], blk.conv2[0][1]), (blk.conv2[0][3], blk.conv2[1])]
-            ds = (blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
-            rec = block_fwd(ctx, u, chain, ds)
-            recs.append(rec)
-            u = rec.v
-    feat = ops.avgpool_fwd(u)
-    return feat, (x, r0, r1, recs, u)
+    """Whole trunk in one call (used by tools/tests): returns (feat [B,512], saved records)."""
+    saved = []
+    for st in VIDEO_STAGES:
+        x, sv = video_stage_forward(ctx, base, st, x)
+        saved.append(sv)
+    return x, saved
 
 
 def video_backward(ctx, saved, dfeat):
-    x, r0, r1, recs, u_last = saved
-    dv = ops.avgpool_bwd(dfeat.contiguous(), u_last)
-    for rec in reversed(recs):
-        dv = block_bwd(ctx, rec, dv)
-    b5 = bn_bwd_own(ctx, r1, dv)
-    g, part = backprop_raw(ctx, r1, dv, b5, True, fuse_bn=True)
-    b5 = bn_bwd_own(ctx, r0, g, part)
-    backprop_raw(ctx, r0, g, b5, True, need_dx=False)
+    d = dfeat
+    for st, sv in zip(reversed(VIDEO_STAGES), reversed(saved)):
+        d = video_stage_backward(ctx, st, sv, d)
 
 
 def audio_forward(ctx, base, spec):

@@ -87,8 +87,10 @@ class AVModel(nn.Module):             # model.py:169-252
                [getattr(self, "mlp_a%d" % h) for h in range(self.hc)]
 
     def forward(self, img, spec, whichhead=0):
-        img_features = self.video_network(img).squeeze()
+        # audio first: autograd then runs the video backward BEFORE the (short) audio backward, whose
+        # kernels hide the tail of the video gradients' all-reduce under DDP
         aud_features = self.audio_network(spec).squeeze()
+        img_features = self.video_network(img).squeeze()
         if self.return_features:                                  # model.py:226-227
             return img_features, aud_features
         if aud_features.dim() == 1:
