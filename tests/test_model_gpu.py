@@ -201,6 +201,73 @@ def test_dropout_masks_and_larger_batch_match_oracle():
         np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-3, atol=2e-3)
 
 
+def test_cfg4_shaped_odd_temporal_extent_matches_oracle():
+    """cfg4's shape family at reduced size: T = 30 (-> 15 -> 8 -> 4 through the stride-2 temporal convs,
+    odd extents and empty stride-parity classes), K = 400, hc = 2, 257-bin spectrogram width class.
+    Eval-mode and train-mode (batch statistics) logits + features vs the oracle, and a state_dict
+    round trip (main.py:227 / utils.py:247 resume path) into a second model."""
+    from selavi_amd import model as smodel
+    hc, K, B = 2, 400, 2
+    m = _build(hc, K, True)
+    o = model_ref.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
+    portable_init_(o, seed=31)
+    step_ref.set_dropout_p(o, 0.0)
+    torch.set_num_threads(min(8, os.cpu_count()))
+    video = portable_fill_(torch.empty(B, 3, 30, 32, 32), 25)
+    audio = portable_fill_(torch.empty(B, 1, 65, 50), 26)
+    for mode in ("eval", "train"):
+        getattr(m, mode)(), getattr(o, mode)()
+        with torch.no_grad():
+            fv, fa = m(video.cuda(), audio.cuda())
+            wv, wa = o(video, audio)
+        for got, want in zip(list(fv) + list(fa), list(wv) + list(wa)):
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-3, atol=2e-3)
+    # running statistics moved identically (one train-mode forward each)
+    sd_m, sd_o = m.state_dict(), o.state_dict()
+    for k in ("video_network.base.layer3.0.conv1.0.1.running_var", "audio_network.base.layer4.0.bn2.running_mean",
+              "video_network.base.stem.4.running_mean"):
+        np.testing.assert_allclose(sd_m[k].cpu().numpy(), sd_o[k].numpy(), rtol=2e-3, atol=1e-4)
+    # checkpoint round trip: a fresh model loaded from the state_dict reproduces the eval output bit for bit
+    m2 = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc).cuda()
+    m2.load_state_dict({k: v.clone() for k, v in sd_m.items()})
+    m.eval(), m2.eval()
+    with torch.no_grad():
+        a1, b1 = m(video.cuda(), audio.cuda())
+        a2, b2 = m2(video.cuda(), audio.cuda())
+    for x, y in zip(list(a1) + list(b1), list(a2) + list(b2)):
+        assert torch.equal(x, y)
+
+
+def test_checkpoint_resume_continues_bit_identically():
+    """main.py:221-233 / utils.py:230-275 save and restore {model, optimizer} state_dicts: after
+    step 1 -> save -> (fresh model + fresh optimizer).load_state_dict -> step 2 must equal the uninterrupted
+    run bit for bit (momentum buffers under torch.optim.SGD's 'momentum_buffer' key)."""
+    from selavi_amd import model as smodel, optim, train
+    hc, K, B = 1, 7, 2
+    video = portable_fill_(torch.empty(B, 3, 4, 32, 32), 35).cuda()
+    audio = portable_fill_(torch.empty(B, 1, 40, 36), 36).cuda()
+    selflabels = torch.arange(64).remainder(K).view(64, 1).cuda()
+    selected = torch.tensor([5, 11]).cuda()
+    m = _build(hc, K, True).train()
+    opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+    train.train_step(m, opt, video, audio, selflabels, selected, hc)
+    ck = {"model": {k: v.clone() for k, v in m.state_dict().items()}, "opt": opt.state_dict()}
+    st = ck["opt"]["state"]
+    assert len(st) == len(list(m.parameters())) and all("momentum_buffer" in v for v in st.values())
+    ck["opt"] = {"state": {k: {"momentum_buffer": v["momentum_buffer"].clone()} for k, v in st.items()},
+                 "param_groups": ck["opt"]["param_groups"]}
+    l2 = train.train_step(m, opt, video, audio, selflabels, selected, hc)
+    m2 = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc).cuda().train()
+    step_ref.set_dropout_p(m2, 0.0)
+    m2.load_state_dict(ck["model"])
+    opt2 = optim.SGD(m2.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+    opt2.load_state_dict(ck["opt"])
+    l2b = train.train_step(m2, opt2, video, audio, selflabels, selected, hc)
+    assert float(l2) == float(l2b)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_single_head_forward_on_feature_bank():
     """head.forward(N x 512 bank) in eval mode -- the call sk_utils.py:309-312 makes."""
     m = _build(3, 12, True)
