@@ -33,13 +33,14 @@ PEAK_FP32_MFMA_TF = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32-inp
 PEAK_HBM_GBS = 8000.0
 
 
-def _pmc_traffic(prefix):
-    """Measured HBM bytes/launch recorded by the PMC passes of this round (None if not recorded)."""
+def _pmc_traffic(key):
+    """Measured HBM bytes/launch recorded by the PMC passes of this round (tools/pmc_traffic.sh ->
+    profiles/r01_pmc.json; None if not recorded)."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-        for k, v in d.items():
-            if k.startswith(prefix) and isinstance(v, dict) and "hbm_bytes_per_launch" in v:
-                return v["hbm_bytes_per_launch"]
+        v = d.get(key)
+        if isinstance(v, dict):
+            return v.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
     return None
@@ -69,19 +70,22 @@ def hot_conv_roofline(batch, dev):
     x = torch.randn(*shape, device=dev, generator=g)
     w = torch.randn(144, 64, 1, 3, 3, device=dev, generator=g) * 0.04
     ss = torch.stack([torch.rand(64, device=dev, generator=g) + 0.5, torch.randn(64, device=dev, generator=g) * 0.1])
+    wf, _ = ops.conv_w_transform(plan, w, need_wt=False)      # per-step weight re-layout, outside the launch timed here
     for _ in range(3):
-        ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True)
+        ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True, wf=wf)
     reps = 10
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True)
+        ops.conv_fwd(plan, x, w, in_ss=ss, in_relu=True, wf=wf)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     flop = 2.0 * batch * 16 * 56 * 56 * 144 * 64 * 9
-    return dict(kernel="igemm_kernel<MODE_FWD,MT=9,NT=2> layer1 (1,3,3) 64->144", ms=ms, flop=flop,
-                tflops=flop / ms / 1e9)
+    cfg = plan.cfg_fwd
+    tile = "MT=%d,NT=%d,K-slices=%d" % (cfg & 255, (cfg >> 8) & 255, cfg >> 16) if cfg else "heuristic tile (MT=9,NT=2)"
+    return dict(kernel="igemm_kernel<MODE_CONV, %s, BN+ReLU prologue, tap-major K> layer1 (1,3,3) 64->144 forward" % tile,
+                ms=ms, flop=flop, tflops=flop / ms / 1e9)
 
 
 def sk_bench(rank, world, dev, iters=50):
@@ -133,7 +137,7 @@ def sk_bench(rank, world, dev, iters=50):
     gbs = n * K * 8 / ms / 1e6      # per-GPU algorithmic bytes (one read of the fp64 shard) / time
     return dict(iters_per_s=1e3 / ms, us_per_iter=ms * 1e3, N=N, K=K, rows_per_gpu=n, grid=grid,
                 roofline=dict(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
-                              traffic=_pmc_traffic("sk_pass_kernel") if world == 1 else None))
+                              traffic=_pmc_traffic("sk_pass") if world == 1 else None))
 
 
 def cpu_baseline(batch):
@@ -238,7 +242,7 @@ def main():
                          "frac": hot["tflops"] / PEAK_FP32_MFMA_TF,
                          # HBM bytes per launch of this kernel at B=16 from rocprofv3 PMC passes
                          # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r01_pmc.json
-                         "traffic": _pmc_traffic("igemm_kernel<0,9,2>") if B == CFG2["batch"] else None,
+                         "traffic": _pmc_traffic("hot_conv_fwd") if B == CFG2["batch"] else None,
                          "kernel": hot["kernel"], "ms_per_launch": hot["ms"], "flop_per_launch": hot["flop"]},
             "step_roofline": {"bound": "mfma", "achieved": step_tflops, "peak": PEAK_FP32_MFMA_TF,
                               "unit": "TFLOP/s per GPU (algorithmic 3 x %.2f GFLOP/clip)" % FWD_GFLOP_PER_CLIP,

@@ -114,13 +114,14 @@ int32_t slv_conv_fwd_nblk(const int32_t* geom, int32_t cfg);
 /* split-K scratch (late layers: few columns, deep K): 0 when the layer runs unsplit */
 size_t slv_conv_fwd_ws_bytes(const int32_t* geom, int32_t cfg);
 /* Weight layouts.  Layers whose channel count pads to a multiple of 16 with <= 10 % waste run with a
- * TAP-MAJOR K order (k = tap*Cpad + c: every 16-deep K chunk has one tap, so padding validity and
- * address math are per chunk, not per element); they read re-laid-out copies of the weights made
+ * TAP-MAJOR K order (k = ((c/16)*ntaps + tap)*16 + c%16: every 16-deep K chunk has one tap, so padding
+ * validity and address math are per chunk, not per element; a 16-channel group visits its taps back to
+ * back so the shifted re-reads stay in L1/L2); they read re-laid-out copies of the weights made
  * once per step by slv_conv_w_transform (one read of w):
- *   wf  forward weights   [Cout][tap*CinPad + ci]               slv_conv_wf_elems() floats, 0 = the forward
+ *   wf  forward weights   [Cout][K order above over (ci, tap)]   slv_conv_wf_elems() floats, 0 = the forward
  *                                                               conv reads w itself (channel-major)
  *   wt  backward-data weights, per stride-parity class c:       slv_conv_wt_elems() floats
- *       [ci][j*CoutPad + co] (tap-major) or [ci][co*ntaps_c + j] (channel-major), classes concatenated */
+ *       [ci][K order above over (co, tap_j)] (tap-major) or [ci][co*ntaps_c + j] (channel-major), classes concatenated */
 size_t slv_conv_wf_elems(const int32_t* geom);
 size_t slv_conv_wt_elems(const int32_t* geom);
 int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf /* nullable */, float* wt /* nullable */,

@@ -163,12 +163,15 @@ static void fill_table_generic(const Desc& d, int32_t* w) {
   }
   fill_tapd(d, w + 2 * KP);
 }
-// tap-major table: one entry per 16-deep chunk (k = j*Cp + c): {offset of (tap j, channel c0), j | c0 << 8}
+// tap-major table: one entry per 16-deep chunk {offset of (tap j, channel c0), j | c0 << 8}.
+// K order k = ((c/16)*ntaps + j)*16 + c%16: the chunks of one 16-channel group visit its taps back to back,
+// so the shifted re-reads of the same input rows hit L1/L2 (a whole-tensor tap sweep between them cost
+// 4.1 GB of L2 misses per launch on the layer-1 backward-data conv, PMC FETCH_SIZE).
 static void fill_table_tap(const Desc& d, int32_t* w) {
   const int Sprod = d.S[0] * d.S[1] * d.S[2];
-  const int nch = d.Kd / 16, cpc = d.Cp / 16;
+  const int nch = d.Kd / 16;
   for (int ch = 0; ch < nch; ++ch) {
-    const int j = ch / cpc, c0 = (ch % cpc) * 16;
+    const int j = ch % d.ntaps, c0 = (ch / d.ntaps) * 16;
     w[2 * ch] = c0 * Sprod + d.delta[j][0] * d.S[1] * d.S[2] + d.delta[j][1] * d.S[2] + d.delta[j][2];
     w[2 * ch + 1] = j | (c0 << 8);
   }
@@ -376,9 +379,9 @@ struct TapMap {
   int off[64], nt[64], j[64];
 };
 // Per-step weight re-layouts (one read of w):
-//   wf (forward, tap-major layers only)  wf[co][tap*CpIn + ci]                 = w[co][ci][tap]
-//   wt (backward-data), per parity class  channel-major: wt_c[ci][co*nt_c + j]  = w[co][ci][tap_j]
-//                                         tap-major:     wt_c[ci][j*CpOut + co] = w[co][ci][tap_j]
+//   wf (forward, tap-major layers only)  wf[co][((ci/16)*taps + tap)*16 + ci%16]        = w[co][ci][tap]
+//   wt (backward-data), per parity class  channel-major: wt_c[ci][co*nt_c + j]           = w[co][ci][tap_j]
+//                                         tap-major: wt_c[ci][((co/16)*nt_c + j)*16 + co%16] = w[co][ci][tap_j]
 // Padding channels (ci >= Cin resp. co >= Cout) stay zero (buffers are cleared first when padded).
 __global__ void w_transform_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wt,
                                    int Cout, int Cin, int taps, const TapMap tm, int CpIn, int CpOut) {
@@ -388,9 +391,9 @@ __global__ void w_transform_kernel(const float* __restrict__ w, float* __restric
     const size_t r = i / taps;
     const int ci = (int)(r % Cin), co = (int)(r / Cin);
     const float v = w[i];
-    if (wf) wf[((size_t)co * taps + tap) * CpIn + ci] = v;
+    if (wf) wf[(size_t)co * taps * CpIn + ((size_t)(ci >> 4) * taps + tap) * 16 + (ci & 15)] = v;
     if (wt && tm.nt[tap] != 0) {
-      if (CpOut) wt[(size_t)tm.off[tap] + ((size_t)ci * tm.nt[tap] + tm.j[tap]) * CpOut + co] = v;
+      if (CpOut) wt[(size_t)tm.off[tap] + (size_t)ci * tm.nt[tap] * CpOut + ((size_t)(co >> 4) * tm.nt[tap] + tm.j[tap]) * 16 + (co & 15)] = v;
       else wt[(size_t)tm.off[tap] + ((size_t)ci * Cout + co) * tm.nt[tap] + tm.j[tap]] = v;
     }
   }
@@ -675,7 +678,8 @@ __global__ __launch_bounds__(256) void w_transform_tiled_kernel(const float* __r
       const int co_l = idx / row, r2 = idx - co_l * row;
       const int tap = r2 >> 5, ci_l = r2 & 31;
       const int co = co0 + co_l, ci = ci0 + ci_l;
-      if (co < Cout && ci < CpIn) wf[((size_t)co * taps + tap) * CpIn + ci] = t[co_l][ci_l * taps + tap];
+      if (co < Cout && ci < CpIn)
+        wf[(size_t)co * taps * CpIn + ((size_t)(ci >> 4) * taps + tap) * 16 + (ci & 15)] = t[co_l][ci_l * taps + tap];
     }
   }
   if (wt) {
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(256) void w_transform_tiled_kernel(const float* __r
       const int co = co0 + co_l, ci = ci0 + ci_l;
       if (ci < Cin && co < colim && tm.nt[tap] != 0) {
         const float v = t[co_l][ci_l * taps + tap];
-        if (CpOut) wt[(size_t)tm.off[tap] + ((size_t)ci * tm.nt[tap] + tm.j[tap]) * CpOut + co] = v;
+        if (CpOut) wt[(size_t)tm.off[tap] + (size_t)ci * tm.nt[tap] * CpOut + ((size_t)(co >> 4) * tm.nt[tap] + tm.j[tap]) * 16 + (co & 15)] = v;
         else wt[(size_t)tm.off[tap] + ((size_t)ci * Cout + co) * tm.nt[tap] + tm.j[tap]] = v;
       }
     }

@@ -41,8 +41,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 enum { MODE_CONV = 0, MODE_WGRAD = 2, MODE_GEMM = 3 };
 enum { PRO_NONE = 0, PRO_ACT = 1, PRO_BWD = 2 };
 // K ordering of MODE_CONV: channel-major (k = c*ntaps + tap, the nn.Conv weight layout, per-k table) or
-// tap-major (k = tap*Cpad + c with Cpad = round16(C), transformed weights): every 16-deep chunk then has
-// ONE tap, so padding validity / address math is per chunk instead of per element.
+// tap-major (k = ((c/16)*ntaps + tap)*16 + c%16 over Cpad = round16(C) channels, transformed weights): every
+// 16-deep chunk then has ONE tap, so padding validity / address math is per chunk instead of per element,
+// and the taps of a 16-channel group are consecutive chunks (L1/L2 reuse of the shifted input rows).
 enum { KORD_CHAN = 0, KORD_TAP = 1 };
 // CONV epilogue: plain store (+ addend, + forward BN statistics) or store + BatchNorm-backward partial sums
 // (IgemmArgs::R).  A template parameter: the plain kernels keep their register budget.
