@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
         const long long n = n0 + nn;
         pBs[i] = (n < g.Ntot) ? g.pb[which * g.Cin + (g.tab[n].y >> 8)] : 0.f;
       }
+      __syncthreads();  // store_chunk(0) of OTHER threads reads these before the first loop barrier
     }
   }
 

@@ -5,6 +5,8 @@ Same constructor arguments, attributes (``return_features``, ``use_mlp``, ``hc``
 keys as the reference, so ``main.py``'s loop (main.py:105-114,284) and ``sk_utils`` (:187,:266-282)
 run unchanged; the arithmetic is libselavi_hip.so.
 """
+import os
+
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -45,6 +47,9 @@ class AudioBaseNetwork(nn.Module):    # model.py:152-166
         return F.normalize(x, p=2, dim=1) if self.norm_feat else x
 
 
+_SIDE_STREAMS = {}      # device -> HIP stream of the audio trunk
+
+
 class AVModel(nn.Module):             # model.py:169-252
     def __init__(self, vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', pretrained=False, norm_feat=True,
                  use_mlp=False, headcount=1, num_classes=256, use_max_pool=False):
@@ -62,6 +67,7 @@ class AVModel(nn.Module):             # model.py:169-252
                 setattr(self, "mlp_v%d" % a, mk())
                 setattr(self, "mlp_a%d" % a, mk())
         self._dropout_masks = None      # tests may inject (m1, m2) [G][B][512] float masks
+        self.overlap_audio = os.environ.get("SELAVI_OVERLAP_AUDIO", "1") == "1"
         self.set_sync_bn("auto")
 
     # ---- SyncBN (main.py:117-118 converts every BN; here it is a switch on the fused BN kernels)
@@ -80,6 +86,13 @@ class AVModel(nn.Module):             # model.py:169-252
         for h in self._heads():
             h.sync = sync
 
+    @staticmethod
+    def _side_stream(device):
+        st = _SIDE_STREAMS.get(device)
+        if st is None:
+            st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+        return st
+
     def _heads(self):
         if self.hc == 1:
             return [self.mlp_v, self.mlp_a]
@@ -87,10 +100,22 @@ class AVModel(nn.Module):             # model.py:169-252
                [getattr(self, "mlp_a%d" % h) for h in range(self.hc)]
 
     def forward(self, img, spec, whichhead=0):
-        # audio first: autograd then runs the video backward BEFORE the (short) audio backward, whose
-        # kernels hide the tail of the video gradients' all-reduce under DDP
-        aud_features = self.audio_network(spec).squeeze()
-        img_features = self.video_network(img).squeeze()
+        # The audio trunk (0.6 % of the FLOPs, ~70 small launches that cannot fill 256 CUs) runs on its own
+        # HIP stream next to the video trunk, forward and -- autograd replays a node on the stream of its
+        # forward -- backward.  It is issued first: autograd then runs the video backward before the
+        # audio backward, which leaves the tail of the video gradients' all-reduce something to hide behind.
+        if self.overlap_audio and spec.is_cuda:
+            main = torch.cuda.current_stream(spec.device)
+            side = self._side_stream(spec.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                aud_features = self.audio_network(spec).squeeze()
+            img_features = self.video_network(img).squeeze()
+            main.wait_stream(side)
+            aud_features.record_stream(main)
+        else:
+            aud_features = self.audio_network(spec).squeeze()
+            img_features = self.video_network(img).squeeze()
         if self.return_features:                                  # model.py:226-227
             return img_features, aud_features
         if aud_features.dim() == 1:

@@ -148,16 +148,26 @@ def test_model_and_two_train_steps_match_reference_golden(golden_dir, fx):
                     assert torch.allclose(v.detach(), want, rtol=1e-5, atol=1e-6), k
                 losses.append(loss.item())
         else:
+            # the oracle evaluated AT THE HIP WEIGHTS after step 1 (train-mode forward + loss on CPU):
+            # isolates the step-2 forward/loss parity from the chaotic gradient (see below)
+            o = model_ref.load_model(use_mlp=use_mlp, num_classes=K, norm_feat=False, headcount=hc)
+            step_ref.set_dropout_p(o, 0.0)
+            o.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+            o.train()
+            with torch.no_grad():
+                ov, oa = o(video.cpu(), audio.cpu())
+                lab = (selflabels[selected, 0] if hc == 1 else selflabels[selected, :]).cpu()
+                loss2_oracle = float(0.5 * model_ref.get_loss(ov, lab, hc) + 0.5 * model_ref.get_loss(oa, lab, hc))
             losses.append(train.train_step(m, opt, video, audio, selflabels, selected, hc).item())
-    # step 1 is a pure forward: 1e-3 (measured ~3e-6).  Step 2 sees the weights after one lr=1e-2 SGD
-    # step along a gradient that is only reproducible to ~1e-2 between fp32 implementations (see
-    # _check_all_grads): the reference's own fp32 CPU run lands 5.9e-3 away from its fp64 run
-    # (2.62873 vs 2.63459 for the hc=1 fixture), the HIP path 1.5e-3..2.5e-2 depending on the K-split
-    # configuration.  The loss drops by 0.9 in this step, so 2e-2 still pins the update to ~6 %.
+    # Step 1 is a pure forward: 1e-3 (measured ~3e-6).  Step 2 is checked exactly where it can be: against
+    # the oracle's loss at the SAME (HIP) weights (1e-3), plus the SGD update itself above.  Against the
+    # golden step-2 loss only a band is meaningful: the gradient of this tiny fixture (16 elements per
+    # channel in layer4's BatchNorms) is reproducible to ~1e-2 between fp32 implementations (see
+    # _check_all_grads), the step changes the loss by 0.9, and HIP builds that differ only in summation
+    # order (K-split choice, tap-major K) landed at 2.636, 2.659 and 2.709 (reference fp32 2.629, fp64 2.635).
     np.testing.assert_allclose(losses[0], g["losses"][0], rtol=1e-3)
-    np.testing.assert_allclose(losses[1], g["losses"][1], rtol=2e-2)
-    if fx == "model_hc1_k28_mlp1":
-        assert abs(losses[1] - 2.6345948718456587) <= 6 * abs(2.6287312507629395 - 2.6345948718456587)
+    np.testing.assert_allclose(losses[1], loss2_oracle, rtol=1e-3)
+    np.testing.assert_allclose(losses[1], g["losses"][1], rtol=6e-2)
     # Weights after TWO steps are chaotic at this lr (the step-2 gradient norm of the stem is 186 in the
     # reference's fp64 run and 154 in its fp32 run), so only the BN running statistics are compared
     # after step 2; the SGD update itself is checked after step 1 in _check_all_grads / below.
@@ -266,6 +276,36 @@ def test_checkpoint_resume_continues_bit_identically():
     assert float(l2) == float(l2b)
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_training_step_is_bit_reproducible_run_to_run():
+    """Six repetitions of {two steps from the same state} (audio trunk on its own stream, dropout on)
+    give bit-identical parameters, running statistics and losses.  Guards the fixed-order reductions
+    and the kernels' LDS hand-offs: a missing barrier after the weight-gradient kernel's LDS parameter
+    fill made ~1 run in 5 differ at the 1e-3 level before it was found with this check."""
+    import hashlib
+    from selavi_amd import optim, train
+    hc, K, B = 2, 31, 4
+    m = _build(hc, K, True).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.3
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    video = portable_fill_(torch.empty(B, 3, 8, 64, 64), 5).cuda()
+    audio = portable_fill_(torch.empty(B, 1, 65, 50), 6).cuda()
+    selflabels = (torch.arange(64 * hc).view(64, hc) * 7 % K).cuda()
+    selected = torch.arange(B).cuda() * 3
+    sigs = set()
+    for _ in range(6):
+        m.load_state_dict(state0)
+        torch.manual_seed(0)
+        opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+        losses = [float(train.train_step(m, opt, video, audio, selflabels, selected, hc)) for _ in range(2)]
+        h = hashlib.sha256(repr(losses).encode())
+        for v in m.state_dict().values():
+            h.update(v.detach().cpu().numpy().tobytes())
+        sigs.add(h.hexdigest())
+    assert len(sigs) == 1
 
 
 def test_single_head_forward_on_feature_bank():
