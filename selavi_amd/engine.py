@@ -17,6 +17,25 @@ from . import ops
 
 # BatchNorm-backward partial sums from the dgrad epilogue (True) or from a separate reduce pass (False)
 FUSE_BN_BWD_REDUCE = os.environ.get("SELAVI_FUSE_BNR", "1") == "1"
+# Weight gradients on a second HIP stream: they are off the critical path of the backward sweep (only the
+# optimizer needs them), so their tails and the under-filled late-layer launches overlap the next dgrad.
+WGRAD_SIDE_STREAM = os.environ.get("SELAVI_WGRAD_STREAM", "1") == "1"
+_WGRAD_STREAMS = {}
+
+
+def _wgrad_stream(device, cur):
+    key = (device, cur.cuda_stream)
+    st = _WGRAD_STREAMS.get(key)
+    if st is None:
+        st = _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_streams(ctx):
+    """Called at the end of a backward schedule: the caller's stream waits for the weight gradients."""
+    if ctx.side is not None:
+        torch.cuda.current_stream(ctx.side.device).wait_stream(ctx.side)
+        ctx.side = None
 
 
 class Raw:
@@ -35,6 +54,7 @@ class Ctx:
         self.training = training
         self.sync = sync            # (process_group, world_size) for SyncBN or None
         self.grads = {}             # id(param) -> grad tensor
+        self.side = None            # HIP stream carrying this pass' weight-gradient launches, if any
 
 
 def _as5d(t):
@@ -50,6 +70,7 @@ def conv_bn(ctx, x, conv, bn, need_dx=True):
         xin, in_ss = x, None
     plan = ops.ConvPlan.get(tuple(xin.shape), conv.out_channels, conv.kernel3, conv.stride3, conv.padding3, xin.device)
     # one pass over the weights makes the forward (tap-major) and backward-data layouts of this step
+    # (issuing these small kernels on the side stream was measured: no gain)
     wf, wt = ops.conv_w_transform(plan, conv.weight, need_wt=ctx.training and need_dx)
     y, ssum, ssq = ops.conv_fwd(plan, xin, conv.weight, in_ss=in_ss, in_relu=in_ss is not None,
                                 want_stats=ctx.training, wf=wf)
@@ -84,7 +105,19 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
     # residual addend) and feed plain tensors to both GEMMs (1.8x faster than folding the BN backward
     # into the wgrad/dgrad operand loaders, which is what round 1 started with)
     dxo = ops.bn_bwd_apply(g, r.y, b5, a_relu, out=torch.empty_like(g) if (keep_g or addend is g) else None)
-    dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None)
+    if WGRAD_SIDE_STREAM:
+        cur = torch.cuda.current_stream(dxo.device)
+        side = _wgrad_stream(dxo.device, cur)
+        side.wait_stream(cur)                       # dXout is ready
+        with torch.cuda.stream(side):
+            dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None)
+        for t in (dxo, xin, in_ss):                 # allocated on `cur`, read on `side`
+            if t is not None:
+                t.record_stream(side)
+        dw.record_stream(cur)                       # allocated on `side`, consumed by the optimizer on `cur`
+        ctx.side = side
+    else:
+        dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None)
     ctx.grads[id(r.conv.weight)] = dw.view_as(r.conv.weight)
     if not need_dx:
         return None
@@ -198,11 +231,13 @@ def video_stage_backward(ctx, stage, saved, dout):
         g, part = backprop_raw(ctx, r1, dout, b5, True, keep_g=True, fuse_bn=True)   # dout belongs to autograd
         b5 = bn_bwd_own(ctx, r0, g, part)
         backprop_raw(ctx, r0, g, b5, True, need_dx=False)
+        join_side_streams(ctx)
         return None
     recs, u_last = saved
     dv = ops.avgpool_bwd(dout.contiguous(), u_last) if stage == "layer4" else dout
     for rec in reversed(recs):
         dv = block_bwd(ctx, rec, dv)
+    join_side_streams(ctx)
     return dv
 
 
@@ -246,3 +281,4 @@ def audio_backward(ctx, saved, dfeat):
     dy0 = ops.maxpool_bwd(dv, idx, tuple(r0.y.shape))
     b5 = bn_bwd_own(ctx, r0, dy0)
     backprop_raw(ctx, r0, dy0, b5, True, need_dx=False)
+    join_side_streams(ctx)
