@@ -143,7 +143,7 @@ def sk_bench(rank, world, dev, iters=50):
 def cpu_baseline(batch):
     """The oracle (oracle/step_ref.py: torch CPU restatement of main.py:284-302, validated against
     the executed reference) timed on this host's cores, on a bounded sample: cfg2-shaped step at a
-    smaller batch (1 warm-up + 1 timed step)."""
+    smaller batch (1 warm-up + 2..8 timed steps, ~12 s of CPU work)."""
     from oracle import model_ref, step_ref
     # torch/oneDNN conv3d backward degrades badly when oversubscribed across sockets (256 threads:
     # 210 s/step at batch 2 on the GPU box); 32 threads is the fastest setting measured there.
@@ -158,11 +158,15 @@ def cpu_baseline(batch):
     sl = torch.randint(0, CFG2["K"], (1024, CFG2["hc"]), generator=g)
     sel = torch.randint(0, 1024, (batch,), generator=g)
     step_ref.train_step(m, opt, video, audio, sl, sel, CFG2["hc"])
+    # bounded sample: as many timed steps as fit in ~12 s of CPU work (at least 2, at most 8)
     t0 = time.time()
-    step_ref.train_step(m, opt, video, audio, sl, sel, CFG2["hc"])
-    dt = time.time() - t0
+    n = 0
+    while n < 2 or (n < 8 and time.time() - t0 < 12.0):
+        step_ref.train_step(m, opt, video, audio, sl, sel, CFG2["hc"])
+        n += 1
+    dt = (time.time() - t0) / n
     return dict(value=batch / dt, unit="clips/s", cores=cores, kind="port",
-                sample=f"cfg2-shaped full step (fwd+loss+bwd+SGD) at batch {batch}, 1 warm-up + 1 timed step, "
+                sample=f"cfg2-shaped full step (fwd+loss+bwd+SGD) at batch {batch}, 1 warm-up + {n} timed steps, "
                        f"torch {torch.__version__} CPU fp32, {dt:.2f} s/step")
 
 
