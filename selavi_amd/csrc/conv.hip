@@ -659,39 +659,41 @@ int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const floa
   return 0;
 }
 
-// LDS-tiled variant for <= 9 taps: a workgroup owns a 32 (co) x 32 (ci) tile; reads are 32*taps-float runs,
-// writes are 128-byte runs in both target layouts; padding channels are written as zeros (no memset).
+// LDS-tiled variant for <= 9 taps: a workgroup (16 x 16 threads) owns a 16 (co) x 16 (ci) tile = one channel
+// group of either target layout; reads are 16*taps-float runs, writes 64-byte runs; padding channels are
+// written as zeros (no memset); no integer divisions.
 __global__ __launch_bounds__(256) void w_transform_tiled_kernel(const float* __restrict__ w, float* __restrict__ wf,
                                                                float* __restrict__ wt, int Cout, int Cin, int taps,
                                                                const TapMap tm, int CpIn, int CpOut) {
-  __shared__ float t[32][32 * 9 + 1];
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-  const int row = 32 * taps;
-  for (int idx = threadIdx.x; idx < 32 * row; idx += 256) {
-    const int co_l = idx / row, r = idx - co_l * row;
-    const int co = co0 + co_l, ci = ci0 + r / taps;
-    t[co_l][r] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci0) * taps + r] : 0.f;
+  __shared__ float t[16][16 * 9 + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 16;
+  const int row = 16 * taps;
+  {
+    const int co = co0 + ty;
+    const int cin_here = Cin - ci0 < 16 ? Cin - ci0 : 16;          // may be <= 0 in a pure padding tile
+    const int rlim = (co < Cout && cin_here > 0) ? cin_here * taps : 0;
+    const float* src = w + ((size_t)(co < Cout ? co : 0) * Cin + (ci0 < Cin ? ci0 : 0)) * taps;
+    for (int r = tx; r < row; r += 16) t[ty][r] = r < rlim ? src[r] : 0.f;
   }
   __syncthreads();
-  if (wf) {
-    for (int idx = threadIdx.x; idx < 32 * row; idx += 256) {
-      const int co_l = idx / row, r2 = idx - co_l * row;
-      const int tap = r2 >> 5, ci_l = r2 & 31;
-      const int co = co0 + co_l, ci = ci0 + ci_l;
-      if (co < Cout && ci < CpIn)
-        wf[(size_t)co * taps * CpIn + ((size_t)(ci >> 4) * taps + tap) * 16 + (ci & 15)] = t[co_l][ci_l * taps + tap];
+  if (wf) {   // thread (tx = ci, ty = co)
+    const int co = co0 + ty, ci = ci0 + tx;
+    if (co < Cout && ci < CpIn) {
+      float* dst = wf + (size_t)co * taps * CpIn + (size_t)(ci0 >> 4) * taps * 16 + tx;
+      for (int tap = 0; tap < taps; ++tap) dst[tap * 16] = t[ty][tx * taps + tap];
     }
   }
-  if (wt) {
+  if (wt) {   // thread (tx = co, ty = ci)
+    const int co = co0 + tx, ci = ci0 + ty;
     const int colim = CpOut ? CpOut : Cout;
-    for (int idx = threadIdx.x; idx < 32 * row; idx += 256) {
-      const int ci_l = idx / row, r2 = idx - ci_l * row;
-      const int tap = r2 >> 5, co_l = r2 & 31;
-      const int co = co0 + co_l, ci = ci0 + ci_l;
-      if (ci < Cin && co < colim && tm.nt[tap] != 0) {
-        const float v = t[co_l][ci_l * taps + tap];
-        if (CpOut) wt[(size_t)tm.off[tap] + (size_t)ci * tm.nt[tap] * CpOut + ((size_t)(co >> 4) * tm.nt[tap] + tm.j[tap]) * 16 + (co & 15)] = v;
-        else wt[(size_t)tm.off[tap] + ((size_t)ci * Cout + co) * tm.nt[tap] + tm.j[tap]] = v;
+    if (ci < Cin && co < colim) {
+      for (int tap = 0; tap < taps; ++tap) {
+        const int nt = tm.nt[tap];
+        if (nt == 0) continue;
+        const float v = t[tx][ty * taps + tap];
+        if (CpOut) wt[(size_t)tm.off[tap] + (size_t)ci * nt * CpOut + ((size_t)(co0 >> 4) * nt + tm.j[tap]) * 16 + tx] = v;
+        else wt[(size_t)tm.off[tap] + ((size_t)ci * Cout + co) * nt + tm.j[tap]] = v;
       }
     }
   }
@@ -741,7 +743,7 @@ int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf, float* 
   hipStream_t st = (hipStream_t)stream;
   if (taps <= 9) {
     const int cin_ext = wf ? df.Cp : g.Cin, cout_ext = cp_out ? cp_out : g.Cout;
-    hipLaunchKernelGGL(w_transform_tiled_kernel, dim3((cin_ext + 31) / 32, (cout_ext + 31) / 32), dim3(256), 0, st, w,
+    hipLaunchKernelGGL(w_transform_tiled_kernel, dim3((cin_ext + 15) / 16, (cout_ext + 15) / 16), dim3(256), 0, st, w,
                        wf, wt, g.Cout, g.Cin, taps, tm, df.Cp, cp_out);
     SLV_LAUNCH_CHECK();
     return 0;
