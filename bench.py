@@ -177,12 +177,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    # Dry-run knobs for exercising the N > 1 path on a one-GPU box (all ranks on cuda:0 over gloo); the
+    # measured configuration is always one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("SELAVI_BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("SELAVI_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from selavi_amd import model as smodel, ops, optim, train
