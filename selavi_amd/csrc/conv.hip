@@ -344,7 +344,7 @@ static int dispatch(const IgemmArgs& a0, int mt, int nt, int splits, hipStream_t
   if (a.nblkN == 0) return 0;
   // 16-byte A loads when the layout allows it (see igemm.hpp, template flag VA)
   bool vec_a;
-  if (MODE == MODE_WGRAD) vec_a = ((a.To * a.Ho * a.Wo) % 4 == 0) && a.a_pro == PRO_NONE && (a.Ptot % 4 == 0);
+  if (MODE == MODE_WGRAD) vec_a = ((a.To * a.Ho * a.Wo) % 4 == 0) && (a.Ptot % 4 == 0);
   else vec_a = (a.Kd % 4 == 0) && (((size_t)a.A & 15) == 0);
   if (getenv("SLV_NO_VECA")) vec_a = false;
 #define SLV_CASE(MT_, NT_) \
@@ -372,7 +372,6 @@ static void conv_args(IgemmArgs& a, const Geom& g, const Desc& d, const int32_t*
   a.D0 = d.D[0]; a.D1 = d.D[1]; a.D2 = d.D[2];
   a.A_bytes = (unsigned)((size_t)d.M * d.Kd * 4);
   a.B_bytes = (unsigned)((size_t)g.Bn * a.sbatch * 4);
-  a.B2_bytes = a.B_bytes;
 }
 
 struct TapMap {
@@ -861,9 +860,9 @@ int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_in, cons
   a.tapd = (const int*)(tab + 2 * kpad(g.Cin * taps));
   a.Cin = g.Cin; a.Ti = g.Ti; a.Hi = g.Hi; a.Wi = g.Wi; a.Cout = g.Cout; a.To = g.To; a.Ho = g.Ho; a.Wo = g.Wo;
   a.st = g.st; a.sh = g.sh; a.sw = g.sw; a.pt = g.pt; a.ph = g.ph; a.pw = g.pw;
-  a.A = dy; a.a_pro = PRO_NONE;
+  a.A = dy;
   a.B = x_in; a.pb = in_scale_shift; a.b_pro = in_scale_shift ? PRO_ACT : PRO_NONE; a.b_relu = in_relu;
-  a.A_bytes = a.A2_bytes = (unsigned)((size_t)g.Bn * g.Cout * g.To * g.Ho * g.Wo * 4);
+  a.A_bytes = (unsigned)((size_t)g.Bn * g.Cout * g.To * g.Ho * g.Wo * 4);
   a.B_bytes = (unsigned)((size_t)g.Bn * g.Cin * g.Ti * g.Hi * g.Wi * 4);
   a.M = g.Cout; a.Kd = 0; a.Ntot = (long long)g.Cin * taps; a.ldc = g.Cin * taps;
   a.Ptot = (long long)g.Bn * g.To * g.Ho * g.Wo;

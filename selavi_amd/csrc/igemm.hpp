@@ -8,13 +8,17 @@
 //               - backward data:  m = ci, one launch per stride-parity class of the INPUT positions
 //                                 (q*stride + class), taps restricted to the class, delta = (class+pad-tap)/stride
 //                                 -> no wasted MFMA work for stride-2 layers, all offsets stay linear
-//   MODE_WGRAD  dW[co, (ci,tap)] = sum_p pro(dXout)[co, p] * pro(X)[ci, p*stride + tap - pad]
+//   MODE_WGRAD  dW[co, (ci,tap)] = sum_p dXout[co, p] * pro(X)[ci, p*stride + tap - pad]
 //   MODE_GEMM   C[m, n]   = sum_k A[m, k] * B[n, k]          (dense "NT" GEMM for the heads)
 // with the BatchNorm that surrounds every conv of the model fused into the operand loaders:
 //   PRO_ACT  v = relu?(x*scale[c] + shift[c])                (consumer-side BN apply + ReLU)
 // so activated tensors are never materialised in HBM (the BN-backward gradient is materialised once
 // per layer by slv_bn_bwd_apply: measured 1.8x faster than folding it into the loaders), and the forward
-// epilogue emits per-channel sum / sum-of-squares partials (training-mode batch statistics).
+// epilogue emits per-channel sum / sum-of-squares partials (training-mode batch statistics); the
+// backward-data epilogue can emit the BatchNorm-backward partial sums of the producing layer (EPI_BNR).
+// K of MODE_CONV is ordered channel-major (per-k table, the stems) or tap-major in 16-channel groups
+// (KORD_TAP: one tap per 16-deep chunk -> validity/address math per chunk, SGPR channel offsets).
+// Deep-K launches with few columns are split over K (deterministic partials + fixed-order reduce).
 //
 // Tiling (wave64, 256 threads = 4 waves): block tile (MT*16) x (NT*64) x 16; each wave owns all
 // MT*16 rows and NT*16 of the columns, i.e. MT x NT accumulators of 16x16 (4 VGPRs each).  The M
@@ -39,7 +43,7 @@ namespace slv {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { MODE_CONV = 0, MODE_WGRAD = 2, MODE_GEMM = 3 };
-enum { PRO_NONE = 0, PRO_ACT = 1, PRO_BWD = 2 };
+enum { PRO_NONE = 0, PRO_ACT = 1 };
 // K ordering of MODE_CONV: channel-major (k = c*ntaps + tap, the nn.Conv weight layout, per-k table) or
 // tap-major (k = ((c/16)*ntaps + tap)*16 + c%16 over Cpad = round16(C) channels, transformed weights): every
 // 16-deep chunk then has ONE tap, so padding validity / address math is per chunk instead of per element,
@@ -54,11 +58,8 @@ constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond any buffer -> load 
 struct IgemmArgs {
   // operands (device pointers + byte sizes for the buffer descriptors)
   const float* A;  unsigned A_bytes;    // CONV/GEMM: dense [M][Kd]; WGRAD: gradient tensor (conv-output side)
-  const float* A2; unsigned A2_bytes;   // WGRAD + PRO_BWD: raw conv output x
   const float* B;  unsigned B_bytes;    // CONV: gathered tensor; WGRAD: conv input; GEMM: dense [N][Kd]
-  const float* B2; unsigned B2_bytes;   // CONV + PRO_BWD: raw conv output x (same shape as B)
-  const float* pa;   // WGRAD A prologue params [5][Cout] = s, h, A1, A2, A3
-  const float* pb;   // B prologue params: PRO_ACT [2][Cb] = s, h ; PRO_BWD [5][Cb]
+  const float* pb;   // B prologue params (PRO_ACT): [2][Cb] = scale, shift
   const int2* tab;   // per-k (CONV) / per-column (WGRAD) entries {element offset, tap | chan << 8}; padded with
                      // invalid entries {0, 63} to a multiple of 16 (+16).
                      // CONV with KORD_TAP: one entry per 16-deep CHUNK {element offset of (tap, first channel),
@@ -89,7 +90,7 @@ struct IgemmArgs {
   // destination lattice (CONV): dst coord = q*dmul + dorg inside [D0][D1][D2]
   int dmul0, dmul1, dmul2, dorg0, dorg1, dorg2, D0, D1, D2;
   int ntaps;
-  int a_pro, b_pro, a_relu, b_relu;
+  int b_pro, b_relu;
   // WGRAD geometry
   int Cin, Ti, Hi, Wi, Cout, To, Ho, Wo, st, sh, sw, pt, ph, pw;
   int chunks_per_split;   // WGRAD: always; CONV: > 0 selects split-K (partials to C + split*split_stride)
@@ -103,11 +104,6 @@ __device__ __forceinline__ float apply_act(float x, float s, float h, int relu) 
   const float v = x * s + h;
   return relu ? fmaxf(v, 0.f) : v;
 }
-__device__ __forceinline__ float apply_bwd(float g, float x, float s, float h, float a1, float a2,
-                                           float a3, int relu) {
-  const float gm = (relu && !(x * s + h > 0.f)) ? 0.f : g;
-  return a1 * gm + a2 + a3 * x;
-}
 __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
@@ -119,7 +115,7 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 }
 
 // VA: the A operand is read with 16-byte loads (4 consecutive k per lane).  Host-checked
-// preconditions: CONV/GEMM Kd % 4 == 0; WGRAD To*Ho*Wo % 4 == 0 and no A prologue.
+// preconditions: CONV/GEMM Kd % 4 == 0; WGRAD To*Ho*Wo % 4 == 0.
 // PRO: prologue of the gathered B operand (PRO_NONE / PRO_ACT) -- a template parameter so that the
 // steady-state loop stays one basic block.
 template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN, int EPI = EPI_PLAIN>
