@@ -282,3 +282,55 @@ def test_pools_and_sgd():
         ops.sgd_step(pg, [(g * (step + 1)).to(dev) for g in gs], bufs, 0.01, 0.9, 1e-5, step == 0)
     for p, r in zip(pg, ref):
         _close(p, r.detach(), 1e-6)
+
+
+# ------------------------------------------------------------------ full cfg2 sizes (B = 16)
+FULL = [
+    ("layer1 spatial", (16, 64, 16, 56, 56, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1))),
+    ("layer2.0 spatial stride 2", (16, 64, 16, 56, 56, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1))),
+    ("layer2.0 temporal stride 2", (16, 230, 16, 28, 28, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0))),
+    ("layer4.1 spatial", (16, 512, 2, 7, 7, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1))),
+    ("stem.0", (16, 3, 16, 112, 112, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3))),
+]
+
+
+@pytest.mark.parametrize("name,geo", FULL, ids=[n for n, _ in FULL])
+@pytest.mark.parametrize("tuned", [False, True], ids=["heuristic", "benchmark-mode"])
+def test_full_size_adjoint_identities(name, geo, tuned):
+    """BASELINE cfg2 sizes, where no CPU oracle is affordable: size-independent identities.
+    conv is bilinear, so for random x, w, g:  <conv(x, w), g> = <x, dgrad(g, w)> = <w, wgrad(g, x)>
+    (fp64 inner products on the device), and the fused BatchNorm statistics of the forward epilogue
+    equal the sums of the tensor it wrote.  The forward itself is pinned at small sizes against fp64
+    (above) and here by linearity: conv(x1 + 2*x2) = conv(x1) + 2*conv(x2)."""
+    from selavi_amd import ops
+    Bn, Cin, T, H, W, Cout, k, st, pd = geo
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(Bn, Cin, T, H, W, device=dev, generator=gen)
+    x2 = torch.randn(Bn, Cin, T, H, W, device=dev, generator=gen)
+    w = torch.randn(Cout, Cin, *k, device=dev, generator=gen) * (Cin * k[0] * k[1] * k[2]) ** -0.5
+    was = ops.benchmark
+    ops.benchmark = tuned
+    try:
+        plan = ops.ConvPlan(Bn, Cin, T, H, W, Cout, k, st, pd, dev)     # private plan (tuned or heuristic)
+    finally:
+        ops.benchmark = was
+    wf, wt = ops.conv_w_transform(plan, w)
+    y, ssum, ssq = ops.conv_fwd(plan, x, w, wf=wf)
+    g = torch.randn(y.shape, device=dev, generator=gen)
+    dx = ops.conv_dgrad(plan, g, wt)
+    dw = ops.conv_wgrad(plan, g, x).view_as(w)
+    dot = lambda a, b: float((a.double().flatten() * b.double().flatten()).sum())
+    a, b, c = dot(y, g), dot(x, dx), dot(w, dw)
+    scale = (dot(y, y) * dot(g, g)) ** 0.5
+    assert abs(a - b) <= 2e-6 * scale and abs(a - c) <= 2e-6 * scale, (a, b, c, scale)
+    # statistics epilogue vs the stored tensor
+    np.testing.assert_allclose(ssum.double().sum(1).cpu().numpy(), y.double().sum((0, 2, 3, 4)).cpu().numpy(),
+                               rtol=1e-4, atol=1e-3 * float(y.abs().max()) * 10)
+    np.testing.assert_allclose(ssq.double().sum(1).cpu().numpy(), (y.double() ** 2).sum((0, 2, 3, 4)).cpu().numpy(),
+                               rtol=1e-5)
+    # linearity of the forward
+    y12, _, _ = ops.conv_fwd(plan, x + 2 * x2, w, wf=wf, want_stats=False)
+    y2, _, _ = ops.conv_fwd(plan, x2, w, wf=wf, want_stats=False)
+    err = float(((y12.double() - (y.double() + 2 * y2.double())).norm()) / y12.double().norm())
+    assert err <= 2e-6, err
