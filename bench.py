@@ -33,6 +33,9 @@ PEAK_FP32_MFMA_TF = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32-inp
 PEAK_HBM_GBS = 8000.0
 
 
+FWD_MB_PER_CLIP = 518.1 + 3.38          # sum over convs of (in + out) fp32 bytes, BN/ReLU/add/pool fused
+
+
 def _pmc_traffic(key):
     """Measured HBM bytes/launch recorded by the PMC passes of this round (tools/pmc_traffic.sh ->
     profiles/r01_pmc.json; None if not recorded)."""
@@ -233,6 +236,17 @@ def main():
     ms_step = dt / a.steps * 1e3
     clips = world * B * a.steps / dt
 
+    # forward only (train-mode batch statistics, no autograd state): the north star quotes the R(2+1)D
+    # forward against the HBM roofline; at fp32 the forward is MFMA-bound, both are reported
+    with torch.no_grad():
+        for _ in range(2):
+            m(video, audio)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(5):
+            m(video, audio)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - tf0) / 5 * 1e3
     hot = hot_conv_roofline(B, dev)
     sk = None if a.no_sk else sk_bench(rank, world, dev)
     cpu = None
@@ -259,6 +273,13 @@ def main():
             "step_roofline": {"bound": "mfma", "achieved": step_tflops, "peak": PEAK_FP32_MFMA_TF,
                               "unit": "TFLOP/s per GPU (algorithmic 3 x %.2f GFLOP/clip)" % FWD_GFLOP_PER_CLIP,
                               "frac": step_tflops / PEAK_FP32_MFMA_TF},
+            "forward": {"ms": fwd_ms, "clips_per_s_per_gpu": B / fwd_ms * 1e3,
+                        "mfma": {"achieved": FWD_GFLOP_PER_CLIP * B / fwd_ms, "peak": PEAK_FP32_MFMA_TF,
+                                 "unit": "TFLOP/s", "frac": FWD_GFLOP_PER_CLIP * B / fwd_ms / PEAK_FP32_MFMA_TF},
+                        "hbm": {"achieved": FWD_MB_PER_CLIP * B / fwd_ms, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": FWD_MB_PER_CLIP * B / fwd_ms / PEAK_HBM_GBS,
+                                "note": "algorithmic fused-forward bytes (SURVEY 8d: 518.1 + 3.4 MB/clip); the fp32 "
+                                        "forward is MFMA-bound, its compute ceiling is 12.5 % of the HBM roofline"}},
             "sk": sk,
             "cpu_baseline": cpu,
         }
