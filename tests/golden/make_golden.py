@@ -134,7 +134,48 @@ def grad_fixture(ref_model, ref_utils, fname="grads_hc1_k28.npz", B=4, T=4, S=32
     print("grad fixture: median fp32 noise %.2e max %.2e" % (np.median(e_cpu), e_cpu.max()))
 
 
+def cfg1_fixture(ref_model, ref_utils):
+    """BASELINE configs[0] at FULL size (the reference's own CPU-runnable case): bs=4, 8x112x112 clips,
+    1x40x100 log-mel, K=28, headcount=1.  Eval and train-mode logits, trunk features and the loss of
+    main.py:284-293, produced by the executed reference."""
+    hc, K, B = 1, 28, 4
+    m = ref_model.load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', use_mlp=True, num_classes=K,
+                             pretrained=False, norm_feat=False, use_max_pool=False, headcount=hc)
+    portable_init_(m, seed=31)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    video = portable_fill_(torch.empty(B, 3, 8, 112, 112), 45, kind="normal")
+    audio = portable_fill_(torch.empty(B, 1, 40, 100), 46, kind="normal")
+    selflabels = torch.from_numpy((np.arange(3328) * 7919 % K).astype(np.int64)).view(-1, 1)
+    selected = torch.tensor([3, 1700, 42, 3327])
+    out = {}
+    m.eval()
+    with torch.no_grad():
+        fv, fa = m(video, audio)
+        m.return_features = True
+        gv, ga = m(video, audio)
+        m.return_features = False
+    out["eval_v"], out["eval_a"], out["feat_v"], out["feat_a"] = fv.numpy(), fa.numpy(), gv.numpy(), ga.numpy()
+    m.train()
+    fv, fa = m(video, audio)
+    labels = selflabels[selected, 0]
+    loss = 0.5 * ref_utils.get_loss(fv, labels, headcount=hc) + 0.5 * ref_utils.get_loss(fa, labels, headcount=hc)
+    out["train_v"], out["train_a"], out["loss"] = fv.detach().numpy(), fa.detach().numpy(), np.float64(loss.item())
+    sd = m.state_dict()
+    for key in ("video_network.base.layer4.1.conv2.1.running_var", "audio_network.base.bn1.running_mean"):
+        out["post/" + key] = sd[key].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "cfg1_full.npz"), hc=hc, K=K, B=B, selflabels=selflabels.numpy(),
+                        selected=selected.numpy(), **out)
+    print("cfg1 full-size fixture: loss", loss.item())
+
+
 def main():
+    if "--only-cfg1" in sys.argv:
+        ref_model, ref_utils, ref_sk = import_reference()
+        torch.set_num_threads(os.cpu_count())
+        cfg1_fixture(ref_model, ref_utils)
+        return
     if "--only-grads" in sys.argv:
         ref_model, ref_utils, ref_sk = import_reference()
         torch.set_num_threads(os.cpu_count())
@@ -258,6 +299,8 @@ def main():
                             hc=hc, K=K, use_mlp=use_mlp, B=B, T=T, S=S, selflabels=selflabels.numpy(),
                             selected=selected.numpy(), **out)
         print("model fixture", hc, K, use_mlp, "losses", losses, "keys", len(sdict))
+
+    cfg1_fixture(ref_model_mod, ref_utils)
 
     # state-dict key lists of the full-size configs (cfg1 hc=1, cfg2 hc=10): names only
     for hc, K in [(1, 28), (10, 309)]:

@@ -351,3 +351,34 @@ def test_full_cfg2_step_reproducible_and_learning():
     assert abs(losses[0] - math.log(K)) <= 0.10 * math.log(K), losses
     assert losses[-1] < losses[0] - 0.05, losses
     assert all(torch.isfinite(v).all() for v in runs[0][1] if v.is_floating_point())
+
+
+def test_cfg1_full_size_matches_executed_reference(golden_dir):
+    """BASELINE configs[0] at full size (bs=4, 8x112x112 clips, 1x40x100 log-mel, K=28, hc=1): logits,
+    trunk features, loss and running statistics against tests/golden/cfg1_full.npz, which
+    make_golden.py produced by executing the reference's model.py / utils.py on CPU.  1e-3, fp32."""
+    from selavi_amd.utils import get_loss
+    g = np.load(os.path.join(golden_dir, "cfg1_full.npz"))
+    hc, K, B = int(g["hc"]), int(g["K"]), int(g["B"])
+    m = _build(hc, K, True)
+    video = portable_fill_(torch.empty(B, 3, 8, 112, 112), 45).cuda()
+    audio = portable_fill_(torch.empty(B, 1, 40, 100), 46).cuda()
+    m.eval()
+    with torch.no_grad():
+        fv, fa = m(video, audio)
+        m.return_features = True
+        gv, ga = m(video, audio)
+        m.return_features = False
+    for got, key in ((fv, "eval_v"), (fa, "eval_a"), (gv, "feat_v"), (ga, "feat_a")):
+        np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=1e-3, atol=1e-3)
+    m.train()
+    fv, fa = m(video, audio)
+    np.testing.assert_allclose(fv.detach().cpu().numpy(), g["train_v"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(fa.detach().cpu().numpy(), g["train_a"], rtol=1e-3, atol=1e-3)
+    labels = torch.from_numpy(g["selflabels"]).cuda()[torch.from_numpy(g["selected"]).cuda(), 0]
+    loss = 0.5 * get_loss(fv, labels, hc) + 0.5 * get_loss(fa, labels, hc)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-4)
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith("post/"):
+            np.testing.assert_allclose(sd[k[5:]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-5)
