@@ -170,11 +170,43 @@ def cfg1_fixture(ref_model, ref_utils):
     print("cfg1 full-size fixture: loss", loss.item())
 
 
+def cfg2_fixture(ref_model, ref_utils):
+    """BASELINE configs[1] at FULL size (the configuration the metric is quoted on): bs=16, 16x112x112
+    clips, 1x129x100 log-mel, K=309, headcount=10.  Train-mode (batch statistics) trunk features, the
+    logits of heads 0 and 9 of both modalities and the loss of main.py:284-293 from the executed reference."""
+    hc, K, B = 10, 309, 16
+    m = ref_model.load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', use_mlp=True, num_classes=K,
+                             pretrained=False, norm_feat=False, use_max_pool=False, headcount=hc)
+    portable_init_(m, seed=31)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    video = portable_fill_(torch.empty(B, 3, 16, 112, 112), 55, kind="normal")
+    audio = portable_fill_(torch.empty(B, 1, 129, 100), 56, kind="normal")
+    selflabels = torch.from_numpy((np.arange(1024 * hc).reshape(1024, hc) * 7919 % K).astype(np.int64))
+    selected = torch.arange(B) * 61
+    m.train()
+    with torch.no_grad():
+        fv, fa = m(video, audio)
+        labels = selflabels[selected, :]
+        loss = 0.5 * ref_utils.get_loss(fv, labels, headcount=hc) + 0.5 * ref_utils.get_loss(fa, labels, headcount=hc)
+    out = dict(train_v0=fv[0].numpy(), train_v9=fv[9].numpy(), train_a0=fa[0].numpy(), train_a9=fa[9].numpy(),
+               loss=np.float64(loss.item()))
+    m.eval()
+    m.return_features = True
+    with torch.no_grad():
+        gv, ga = m(video, audio)       # eval-mode features with the running statistics of ONE train-mode forward
+    out["feat_v"], out["feat_a"] = gv.numpy(), ga.numpy()
+    np.savez_compressed(os.path.join(OUT, "cfg2_full.npz"), hc=hc, K=K, B=B, selflabels=selflabels.numpy(),
+                        selected=selected.numpy(), **out)
+    print("cfg2 full-size fixture: loss", loss.item())
+
+
 def main():
-    if "--only-cfg1" in sys.argv:
+    if "--only-cfg1" in sys.argv or "--only-cfg2" in sys.argv:
         ref_model, ref_utils, ref_sk = import_reference()
         torch.set_num_threads(os.cpu_count())
-        cfg1_fixture(ref_model, ref_utils)
+        (cfg1_fixture if "--only-cfg1" in sys.argv else cfg2_fixture)(ref_model, ref_utils)
         return
     if "--only-grads" in sys.argv:
         ref_model, ref_utils, ref_sk = import_reference()
@@ -301,6 +333,7 @@ def main():
         print("model fixture", hc, K, use_mlp, "losses", losses, "keys", len(sdict))
 
     cfg1_fixture(ref_model_mod, ref_utils)
+    cfg2_fixture(ref_model_mod, ref_utils)
 
     # state-dict key lists of the full-size configs (cfg1 hc=1, cfg2 hc=10): names only
     for hc, K in [(1, 28), (10, 309)]:

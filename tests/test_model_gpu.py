@@ -382,3 +382,29 @@ def test_cfg1_full_size_matches_executed_reference(golden_dir):
     for k in g.files:
         if k.startswith("post/"):
             np.testing.assert_allclose(sd[k[5:]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-5)
+
+
+def test_cfg2_full_size_forward_matches_executed_reference(golden_dir):
+    """BASELINE configs[1] at full size -- the configuration the headline metric is quoted on (bs=16,
+    16x112x112 clips, 1x129x100 log-mel, K=309, hc=10): train-mode logits of heads 0 and 9 of both
+    modalities, the loss of main.py:284-293 and the eval-mode trunk features after that one training-mode
+    forward, against tests/golden/cfg2_full.npz from the executed reference.  1e-3, fp32."""
+    from selavi_amd.utils import get_loss
+    g = np.load(os.path.join(golden_dir, "cfg2_full.npz"))
+    hc, K, B = int(g["hc"]), int(g["K"]), int(g["B"])
+    m = _build(hc, K, True).train()
+    video = portable_fill_(torch.empty(B, 3, 16, 112, 112), 55).cuda()
+    audio = portable_fill_(torch.empty(B, 1, 129, 100), 56).cuda()
+    with torch.no_grad():
+        fv, fa = m(video, audio)
+        labels = torch.from_numpy(g["selflabels"]).cuda()[torch.from_numpy(g["selected"]).cuda(), :]
+        loss = 0.5 * get_loss(fv, labels, hc) + 0.5 * get_loss(fa, labels, hc)
+    for got, key in ((fv[0], "train_v0"), (fv[9], "train_v9"), (fa[0], "train_a0"), (fa[9], "train_a9")):
+        np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-4)
+    m.eval()
+    m.return_features = True
+    with torch.no_grad():
+        gv, ga = m(video, audio)
+    np.testing.assert_allclose(gv.cpu().numpy(), g["feat_v"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(ga.cpu().numpy(), g["feat_a"], rtol=1e-3, atol=1e-3)
