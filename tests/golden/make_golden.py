@@ -101,7 +101,7 @@ def grad_fixture(ref_model, ref_utils, fname="grads_hc1_k28.npz", B=4, T=4, S=32
     audio = portable_fill_(torch.empty(B, 1, FA, TA), 6, kind="normal")
     N = 64
     selflabels = torch.from_numpy((np.arange(N * hc).reshape(N, hc) * 7919 % K).astype(np.int64))
-    selected = torch.tensor([3, 17, 42, 63, 8, 29][:B])
+    selected = torch.tensor([3, 17, 42, 63, 8, 29][:B]) if B <= 6 else (torch.arange(B) * 4 + 1)
     res = {}
     for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
         m = ref_model.load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', use_mlp=True,
@@ -207,6 +207,11 @@ def main():
         ref_model, ref_utils, ref_sk = import_reference()
         torch.set_num_threads(os.cpu_count())
         (cfg1_fixture if "--only-cfg1" in sys.argv else cfg2_fixture)(ref_model, ref_utils)
+        return
+    if "--only-cfg2-grads" in sys.argv:       # full-size (bs 16, 16x112x112) fp64 + fp32 gradients: ~10 min of CPU
+        ref_model, ref_utils, ref_sk = import_reference()
+        torch.set_num_threads(os.cpu_count())
+        grad_fixture(ref_model, ref_utils, "grads_cfg2_full.npz", B=16, T=16, S=112, FA=129, TA=100)
         return
     if "--only-grads" in sys.argv:
         ref_model, ref_utils, ref_sk = import_reference()
