@@ -105,10 +105,22 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
     # residual addend) and feed plain tensors to both GEMMs (1.8x faster than folding the BN backward
     # into the wgrad/dgrad operand loaders, which is what round 1 started with)
     dxo = ops.bn_bwd_apply(g, r.y, b5, a_relu, out=torch.empty_like(g) if (keep_g or addend is g) else None)
+
+    def dgrad():
+        wt = r.wt if r.wt is not None else ops.conv_wt_transform(r.plan, r.conv.weight)
+        if fuse_bn and not FUSE_BN_BWD_REDUCE:
+            return ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out), None
+        bnr = (src.y, src.ss, src.mi) if fuse_bn else None
+        return ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out, bnr=bnr)
+
     if WGRAD_SIDE_STREAM:
+        # the backward-data conv is on the critical path: it is enqueued first; the weight gradient starts on
+        # the side stream as soon as dXout exists (event recorded before the dgrad launch)
         cur = torch.cuda.current_stream(dxo.device)
         side = _wgrad_stream(dxo.device, cur)
-        side.wait_stream(cur)                       # dXout is ready
+        ready = cur.record_event()
+        res = dgrad() if need_dx else None
+        side.wait_event(ready)
         with torch.cuda.stream(side):
             dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None)
         for t in (dxo, xin, in_ss):                 # allocated on `cur`, read on `side`
@@ -118,14 +130,9 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
         ctx.side = side
     else:
         dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None)
+        res = dgrad() if need_dx else None
     ctx.grads[id(r.conv.weight)] = dw.view_as(r.conv.weight)
-    if not need_dx:
-        return None
-    wt = r.wt if r.wt is not None else ops.conv_wt_transform(r.plan, r.conv.weight)
-    if fuse_bn and not FUSE_BN_BWD_REDUCE:
-        return ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out), None
-    bnr = (src.y, src.ss, src.mi) if fuse_bn else None
-    return ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out, bnr=bnr)
+    return res
 
 
 def bn_bwd_own(ctx, r, g, part=None):
