@@ -408,3 +408,27 @@ def test_cfg2_full_size_forward_matches_executed_reference(golden_dir):
         gv, ga = m(video, audio)
     np.testing.assert_allclose(gv.cpu().numpy(), g["feat_v"], rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(ga.cpu().numpy(), g["feat_a"], rtol=1e-3, atol=1e-3)
+
+
+def test_full_size_gradients_within_reference_noise(golden_dir):
+    """Backward at the headline configuration's FULL input size (bs 16, 16x112x112 video, 1x129x100 log-mel;
+    hc=1, K=28 heads): all 190 parameter gradients against the reference's fp64 run
+    (tests/golden/grads_cfg2_full.npz, ~10 min of CPU in make_golden.py --only-cfg2-grads).  Even at this size
+    the reference's own fp32 run deviates from fp64 by a median 7.8e-3 / max 1.1e-2 (train-mode BN ResNet at
+    random init), so the bar is the same noise-derived one as for the small fixtures; the loss agrees to 1e-5."""
+    from selavi_amd.utils import get_loss
+    g = np.load(os.path.join(golden_dir, "grads_cfg2_full.npz"))
+    hc, K = int(g["hc"]), int(g["K"])
+    B, T, S, FA, TA = (int(g[k]) for k in ("B", "T", "S", "FA", "TA"))
+    assert (B, T, S, FA, TA) == (16, 16, 112, 129, 100)
+    m = _build(hc, K, True).train()
+    video = portable_fill_(torch.empty(B, 3, T, S, S), 5).cuda()
+    audio = portable_fill_(torch.empty(B, 1, FA, TA), 6).cuda()
+    selflabels = torch.from_numpy(g["selflabels"]).cuda()
+    selected = torch.from_numpy(g["selected"]).cuda()
+    fv, fa = m(video, audio)
+    labels = selflabels[selected, 0]
+    loss = 0.5 * get_loss(fv, labels, hc) + 0.5 * get_loss(fa, labels, hc)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g["loss64"]), rtol=1e-5)
+    _check_all_grads(m, golden_dir, "grads_cfg2_full.npz")
