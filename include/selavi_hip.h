@@ -106,7 +106,7 @@ int slv_sk_labels(const double* P, int64_t N_local, int K, const double* beta, v
 int32_t slv_conv_table_len(const int32_t* geom, int dgrad);
 int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out /* host, table_len words */);
 /* Launch configuration `cfg`: 0 = built-in heuristic, otherwise one of the values enumerated by
- * slv_conv_configs (tile rows/16 | tile cols/64 << 8 | K-slices << 16).  The host may time the
+ * slv_conv_configs (tile rows/16 | tile cols/64 << 8 | MFMA shape << 12 (0: 16x16x4, 1: 32x32x2) | K-slices << 16).  The host may time the
  * candidates once per layer shape -- what the reference gets from cudnn.benchmark = True (main.py:187).
  * op: 0 forward, 1 backward-data, 2 backward-weight.  Returns the number of candidates written. */
 int32_t slv_conv_configs(const int32_t* geom, int op, int32_t* cfg_out, int32_t max_out);

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_bnr_kernel(const float
 }
 
 template <int MODE>
-static int dispatch(const IgemmArgs& a0, int mt, int nt, int splits, hipStream_t st) {
+static int dispatch(const IgemmArgs& a0, int mt, int nt, int splits, hipStream_t st, int mf = 0) {
   IgemmArgs a = a0;
   const int bm = mt * 16, bn = nt * 64;
   a.nblkM = (a.M + bm - 1) / bm;
@@ -349,9 +349,16 @@ static int dispatch(const IgemmArgs& a0, int mt, int nt, int splits, hipStream_t
   if (getenv("SLV_NO_VECA")) vec_a = false;
 #define SLV_CASE(MT_, NT_) \
   if (mt == MT_ && nt == NT_) { launch_igemm<MODE, MT_, NT_>(a, splits, vec_a, st); return 0; }
+#define SLV_CASE_MF(MT_, MT32_) \
+  if (mt == MT_ && nt == 2) { launch_igemm<MODE, MT32_, 1, 1>(a, splits, vec_a, st); return 0; }
+  if (mf) {
+    SLV_CASE_MF(4, 2) SLV_CASE_MF(6, 3) SLV_CASE_MF(8, 4)
+    return -1;
+  }
   SLV_CASE(4, 1) SLV_CASE(4, 2) SLV_CASE(8, 1) SLV_CASE(8, 2)
   SLV_CASE(9, 1) SLV_CASE(9, 2) SLV_CASE(15, 1)
 #undef SLV_CASE
+#undef SLV_CASE_MF
   return -1;
 }
 
@@ -491,16 +498,19 @@ int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out) {
 // cfg == 0: built-in heuristic.  Otherwise mt | nt << 8 | splits << 16, one of slv_conv_configs():
 // the host may time the candidates once per layer shape, which is what the reference does through
 // cudnn.benchmark = True (main.py:187).
+// mt / nt: block tile in units of 16 rows / 64 columns.  mf = 1: the 32x32x2 MFMA variant of that tile
+// (block tiles 64x128, 96x128, 128x128 = (4,2), (6,2), (8,2)).
 struct Cfg {
-  int mt, nt, sp;
+  int mt, nt, sp, mf;
 };
-static bool tile_ok(int mt, int nt) {
+static bool tile_ok(int mt, int nt, int mf) {
+  if (mf) return nt == 2 && (mt == 4 || mt == 6 || mt == 8);
   return ((mt == 4 || mt == 8 || mt == 9) && (nt == 1 || nt == 2)) || (mt == 15 && nt == 1);
 }
-static int32_t pack_cfg(int mt, int nt, int sp) { return mt | (nt << 8) | (sp << 16); }
+static int32_t pack_cfg(int mt, int nt, int sp, int mf) { return mt | (nt << 8) | (mf << 12) | (sp << 16); }
 static int unpack_cfg(int32_t cfg, Cfg& c) {
-  c.mt = cfg & 255; c.nt = (cfg >> 8) & 255; c.sp = (cfg >> 16) & 0x7FFF;
-  return (tile_ok(c.mt, c.nt) && c.sp >= 1) ? 0 : -1;
+  c.mt = cfg & 255; c.nt = (cfg >> 8) & 15; c.mf = (cfg >> 12) & 15; c.sp = (cfg >> 16) & 0x7FFF;
+  return (c.mf <= 1 && tile_ok(c.mt, c.nt, c.mf) && c.sp >= 1) ? 0 : -1;
 }
 static int clamp_splits(int sp, long long chunks) {
   if (sp > chunks) sp = (int)(chunks > 0 ? chunks : 1);
@@ -511,6 +521,7 @@ static int clamp_splits(int sp, long long chunks) {
 static int fwd_cfg(const Geom& g, int32_t cfg, Cfg& c) {
   const long long P = (long long)g.Bn * g.To * g.Ho * g.Wo;
   const int Kd = g.Cin * g.kt * g.kh * g.kw;
+  c.mf = 0;
   if (cfg == 0) { plan_conv(g.Cout, P, Kd, &c.mt, &c.nt, &c.sp); return 0; }
   if (unpack_cfg(cfg, c) != 0 || c.sp > 64) return -1;
   c.sp = clamp_splits(c.sp, (Kd + 15) / 16);
@@ -521,6 +532,7 @@ static int dgrad_cfg(const Geom& g, const Desc* ds, int n, int32_t cfg, Cfg* per
   int sp = 1;
   if (cfg == 0) {
     for (int i = 0; i < n; ++i) {
+      per_class[i].mf = 0;
       plan_conv(ds[i].M, ds[i].Ntot, ds[i].Kd, &per_class[i].mt, &per_class[i].nt, &per_class[i].sp);
       if (per_class[i].sp > sp) sp = per_class[i].sp;
     }
@@ -539,6 +551,7 @@ static int dgrad_cfg(const Geom& g, const Desc* ds, int n, int32_t cfg, Cfg* per
 }
 static int wgrad_cfg(const Geom& g, int32_t cfg, Cfg& c) {
   const long long chunks = ((long long)g.Bn * g.To * g.Ho * g.Wo + 15) / 16;
+  c.mf = 0;
   if (cfg == 0) {
     c.mt = pick_mt(g.Cout);
     c.nt = c.mt >= 15 ? 1 : 2;
@@ -553,7 +566,8 @@ static int wgrad_cfg(const Geom& g, int32_t cfg, Cfg& c) {
 int32_t slv_conv_configs(const int32_t* geom, int op, int32_t* out, int32_t max_out) {
   Geom g;
   if (read_geom(geom, g) != 0 || !out || max_out <= 0 || op < 0 || op > 2) return -1;
-  static const int tiles[7][2] = {{9, 2}, {8, 2}, {15, 1}, {4, 2}, {9, 1}, {8, 1}, {4, 1}};
+  static const int tiles[10][3] = {{9, 2, 0}, {8, 2, 0}, {15, 1, 0}, {4, 2, 0}, {9, 1, 0}, {8, 1, 0}, {4, 1, 0},
+                                   {8, 2, 1}, {6, 2, 1}, {4, 2, 1}};
   const int taps = g.kt * g.kh * g.kw;
   int M;
   long long N, chunks;
@@ -595,7 +609,7 @@ int32_t slv_conv_configs(const int32_t* geom, int op, int32_t* out, int32_t max_
         if (!dup) cand[nc++] = sp;
       }
     }
-    for (int j = 0; j < nc && cnt < max_out; ++j) out[cnt++] = pack_cfg(t[0], t[1], cand[j]);
+    for (int j = 0; j < nc && cnt < max_out; ++j) out[cnt++] = pack_cfg(t[0], t[1], cand[j], t[2]);
   }
   return cnt;
 }
@@ -641,7 +655,7 @@ int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const floa
     const int chunks = (a.Kd + 15) / 16;
     a.chunks_per_split = (chunks + sp - 1) / sp;
   }
-  SLV_CHECK_ARG(dispatch<MODE_CONV>(a, mt, nt, sp, (hipStream_t)stream) == 0, "no kernel for tile");
+  SLV_CHECK_ARG(dispatch<MODE_CONV>(a, mt, nt, sp, (hipStream_t)stream, c.mf) == 0, "no kernel for tile");
   SLV_LAUNCH_CHECK();
   if (sp > 1) {
     if (stat_sum) {
@@ -817,7 +831,7 @@ int slv_conv_dgrad(const int32_t* geom, const float* dy, const float* wt, const 
       a.rslots = rslots; a.rslot0 = rslot0;
       rslot0 += (int)((d.Ntot + pc[i].nt * 64 - 1) / (pc[i].nt * 64));
     }
-    SLV_CHECK_ARG(dispatch<MODE_CONV>(a, pc[i].mt, pc[i].nt, sp, (hipStream_t)stream) == 0, "no kernel for tile");
+    SLV_CHECK_ARG(dispatch<MODE_CONV>(a, pc[i].mt, pc[i].nt, sp, (hipStream_t)stream, pc[i].mf) == 0, "no kernel for tile");
     SLV_LAUNCH_CHECK();
   }
   if (sp > 1) {
@@ -880,7 +894,7 @@ int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_in, cons
   } else {
     a.C = dw;
   }
-  SLV_CHECK_ARG(dispatch<MODE_WGRAD>(a, mt, nt, splits, (hipStream_t)stream) == 0, "no kernel for tile");
+  SLV_CHECK_ARG(dispatch<MODE_WGRAD>(a, mt, nt, splits, (hipStream_t)stream, c.mf) == 0, "no kernel for tile");
   SLV_LAUNCH_CHECK();
   if (splits > 1) {
     launch_splitk_reduce((const float*)ws, dw, nel, splits, (hipStream_t)stream);

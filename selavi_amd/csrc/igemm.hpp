@@ -41,6 +41,7 @@
 namespace slv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { MODE_CONV = 0, MODE_WGRAD = 2, MODE_GEMM = 3 };
 enum { PRO_NONE = 0, PRO_ACT = 1 };
@@ -118,15 +119,24 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 // preconditions: CONV/GEMM Kd % 4 == 0; WGRAD To*Ho*Wo % 4 == 0.
 // PRO: prologue of the gathered B operand (PRO_NONE / PRO_ACT) -- a template parameter so that the
 // steady-state loop stays one basic block.
-template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN, int EPI = EPI_PLAIN>
+// MF: MFMA shape.  0: v_mfma_f32_16x16x4_f32 (tile edge 16, MT x NT tiles of 16x16 per wave, block (MT*16) x (NT*64));
+//     1: v_mfma_f32_32x32x2_f32 (tile edge 32, block (MT*32) x (NT*128)): one A + one B fragment read per 4096 FLOP
+//        instead of per 2048 -- the LDS+MFMA-only loop reaches 145 TF with it against 127-135 TF
+//        (tools/mfma_lds_bench.hip); usable where the row count pads well to 32/64/96/128.
+template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN, int EPI = EPI_PLAIN, int MF = 0>
 #ifndef SLV_LB_CONV
 #define SLV_LB_CONV 3
 #endif
 #ifndef SLV_LB_WGRAD
 #define SLV_LB_WGRAD 2
 #endif
-__global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_WGRAD : SLV_LB_CONV))) void igemm_kernel(const IgemmArgs g) {
-  constexpr int BM = MT * 16, BN = NT * 64;
+__global__ __launch_bounds__(256, ((MF == 0 && MT >= 15) ? 2 : (MODE == MODE_WGRAD ? SLV_LB_WGRAD : SLV_LB_CONV))) void igemm_kernel(const IgemmArgs g) {
+  constexpr int RT = MF ? 32 : 16;   // MFMA tile edge
+  constexpr int AR = MF ? 16 : 4;    // accumulator registers per MFMA tile
+  constexpr int KPS = MF ? 2 : 4;    // k per MFMA step
+  constexpr int BM = MT * RT, BN = NT * RT * 4;
+  constexpr int MR16 = BM / 16;      // 16-row passes of the scalar A loader
+  using Acc = std::conditional_t<MF != 0, f32x16, f32x4>;
   constexpr int AS = 18;
   constexpr bool BKF = (MODE == MODE_WGRAD || MODE == MODE_GEMM);  // B tile K-contiguous?
   constexpr int BS = BKF ? 18 : (BN + 16);
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
   }
 
   // staging registers hold RAW loaded values; masking + prologue math run in store_chunk
-  float ra[VA ? 1 : MT];
+  float ra[VA ? 1 : MR16];
   constexpr int NP = (BM + 63) / 64;  // VA: passes of 64 rows x 4 k-quads
   f32x4 ra4[VA ? NP : 1];
   (void)ra; (void)ra4;
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
         const unsigned abase = (unsigned)(((m0 + a_r) * (long long)g.Kd + k0 + a_kk) * 4);
         const bool kok = (MODE != MODE_GEMM) || (k0 + a_kk < g.Kd);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MR16; ++i) {
           const unsigned off = abase + (unsigned)(i * 16 * g.Kd * 4);
           ra[i] = bload(rA, kok ? off : OOB);
         }
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
       } else {
         const unsigned abase = (b * (unsigned)g.Cout + (unsigned)(m0 + a_r)) * (unsigned)Pout + rem;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MR16; ++i) {
           const unsigned off = pok ? ((abase + (unsigned)(16 * i) * (unsigned)Pout) << 2) : OOB;
           ra[i] = bload(rA, off);
         }
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
     if constexpr (MODE == MODE_WGRAD) {
       if constexpr (!VA) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MR16; ++i) {
           const int m = a_r + 16 * i;
           As[m * AS + a_kk] = ra[i];
         }
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
     } else {
       if constexpr (!VA) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) As[(a_r + 16 * i) * AS + a_kk] = ra[i];
+        for (int i = 0; i < MR16; ++i) As[(a_r + 16 * i) * AS + a_kk] = ra[i];
       }
       if constexpr (MODE == MODE_GEMM) {
 #pragma unroll
@@ -427,35 +437,41 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
     }
   };
 
-  f32x4 acc[MT][NT];
+  Acc acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
 
-  const int fi = lane & 15, fk = lane >> 4;
-  const int mtv = __builtin_amdgcn_readfirstlane((mrem + 15) >> 4);  // valid 16-row tiles (wave-uniform)
+  // fragment lane mapping: lane (fi, fk) holds A[row fi][k fk] and B[k fk][col fi] of an MFMA step
+  const int fi = lane & (RT - 1), fk = lane / RT;
+  const int mtv = __builtin_amdgcn_readfirstlane((mrem + RT - 1) / RT);  // valid row tiles (wave-uniform)
+  // row of accumulator register r inside its tile
+  auto rowof = [&](int r) __attribute__((always_inline)) { return MF ? (8 * (r >> 2) + 4 * fk + (r & 3)) : (fk * 4 + r); };
 
   auto compute = [&](int buf, auto full_tag) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_tag)::value;
     const float* As = smem + buf * (A_ELEMS + B_ELEMS);
     const float* Bs = As + A_ELEMS;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < 16 / KPS; ++kk) {
       float a[MT], b[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = As[(i * 16 + fi) * AS + kk * 4 + fk];
+      for (int i = 0; i < MT; ++i) a[i] = As[(i * RT + fi) * AS + kk * KPS + fk];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        if constexpr (BKF) b[j] = Bs[((wave * NT + j) * 16 + fi) * 18 + kk * 4 + fk];
-        else b[j] = Bs[(kk * 4 + fk) * BS + (wave * NT + j) * 16 + fi];
+        if constexpr (BKF) b[j] = Bs[((wave * NT + j) * RT + fi) * 18 + kk * KPS + fk];
+        else b[j] = Bs[(kk * KPS + fk) * BS + (wave * NT + j) * RT + fi];
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         if (FULL || i < mtv) {  // wave-uniform: skip row tiles beyond M in ragged blocks
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            if constexpr (MF) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
       }
     }
@@ -483,7 +499,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
   }
 
   // ---------------------------------------------------------------- epilogue
-  // accumulator layout: row = i*16 + fk*4 + r, col = (wave*NT + j)*16 + fi
+  // accumulator layout: row = i*RT + rowof(r), col = (wave*NT + j)*RT + fi
   if constexpr (MODE == MODE_CONV) {
     const int dP = g.D0 * g.D1 * g.D2;
     float* Cp = g.C + (size_t)split * (size_t)g.split_stride;  // split-K: slice-private partial output
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
     const int NQ = g.Q0 * g.Q1 * g.Q2, Q12 = g.Q1 * g.Q2;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const long long n = n0 + (wave * NT + j) * 16 + fi;
+      const long long n = n0 + (wave * NT + j) * RT + fi;
       cok[j] = n < g.Ntot;
       const long long nn = cok[j] ? n : 0;
       const int b = (int)(nn / NQ);
@@ -509,8 +525,8 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
       for (int i = 0; i < MT; ++i) {
         if (i < mtv) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = i * 16 + fk * 4 + r;
+          for (int r = 0; r < AR; ++r) {
+            const int m = i * RT + rowof(r);
             if (m < mrem) {
 #pragma unroll
               for (int j = 0; j < NT; ++j) {
@@ -543,10 +559,10 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
       if (i < mtv) {
         // all loads of this 16-row tile first (they are independent; the stores below would otherwise
         // fence them one by one), then the arithmetic and the stores
-        float xv[4][NT], ev[4][NT];
+        float xv[AR][NT], ev[AR][NT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = i * 16 + fk * 4 + r;
+        for (int r = 0; r < AR; ++r) {
+          const int m = i * RT + rowof(r);
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const bool ok = (m < mrem) && cok[j];
@@ -556,8 +572,8 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = i * 16 + fk * 4 + r;
+        for (int r = 0; r < AR; ++r) {
+          const int m = i * RT + rowof(r);
           const bool mok = m < mrem;
           float ps = 0.f, ph = 0.f, pm = 0.f, pi = 0.f, s0 = 0.f, s1 = 0.f;
           if (bnr) { ps = rpar[m]; ph = rpar[BM + m]; pm = rpar[2 * BM + m]; pi = rpar[3 * BM + m]; }
@@ -574,7 +590,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
           }
           if (bnr) {  // wave-uniform; all lanes take part in the shuffles
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
+            for (int o = 1; o < RT; o <<= 1) {
               s0 += __shfl_xor(s0, o, 64);
               s1 += __shfl_xor(s1, o, 64);
             }
@@ -604,7 +620,7 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < AR; ++r) {
           float s = 0.f, q = 0.f;
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
@@ -613,12 +629,12 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
             q += v * v;
           }
 #pragma unroll
-          for (int o = 1; o < 16; o <<= 1) {
+          for (int o = 1; o < RT; o <<= 1) {
             s += __shfl_xor(s, o, 64);
             q += __shfl_xor(q, o, 64);
           }
           if (fi == 0) {
-            const int m = i * 16 + fk * 4 + r;
+            const int m = i * RT + rowof(r);
             red[wave * BM + m] = s;
             red[(4 + wave) * BM + m] = q;
           }
@@ -641,12 +657,12 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
     for (int i = 0; i < MT; ++i) {
       if (i < mtv) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = i * 16 + fk * 4 + r;
+        for (int r = 0; r < AR; ++r) {
+          const int m = i * RT + rowof(r);
           if (m < mrem) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-              const long long n = n0 + (wave * NT + j) * 16 + fi;
+              const long long n = n0 + (wave * NT + j) * RT + fi;
               if (n < g.Ntot) {
                 float v = acc[i][j][r];
                 if constexpr (MODE == MODE_GEMM) {
@@ -662,21 +678,21 @@ __global__ __launch_bounds__(256, (MT >= 15 ? 2 : (MODE == MODE_WGRAD ? SLV_LB_W
   }
 }
 
-template <int MODE, int MT, int NT>
+template <int MODE, int MT, int NT, int MF = 0>
 inline void launch_igemm(const IgemmArgs& a, int splits, bool vec_a, hipStream_t st) {
   dim3 grid(a.nblkM * a.nblkN * splits, 1, 1);
   const bool act = (MODE != MODE_GEMM) && a.b_pro == PRO_ACT;
-#define SLV_L(VA_, PRO_) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, VA_, PRO_>), grid, dim3(256), 0, st, a)
+#define SLV_L(VA_, PRO_) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, VA_, PRO_, KORD_CHAN, EPI_PLAIN, MF>), grid, dim3(256), 0, st, a)
   if constexpr (MODE == MODE_CONV) {
     if (a.R) {  // backward-data with the fused BatchNorm-backward reduction (never has an operand prologue)
-      if (a.kord == KORD_TAP) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_TAP, EPI_BNR>), grid, dim3(256), 0, st, a);
-      else if (vec_a) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_CHAN, EPI_BNR>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, false, PRO_NONE, KORD_CHAN, EPI_BNR>), grid, dim3(256), 0, st, a);
+      if (a.kord == KORD_TAP) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_TAP, EPI_BNR, MF>), grid, dim3(256), 0, st, a);
+      else if (vec_a) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_CHAN, EPI_BNR, MF>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, false, PRO_NONE, KORD_CHAN, EPI_BNR, MF>), grid, dim3(256), 0, st, a);
       return;
     }
     if (a.kord == KORD_TAP) {  // tap-major K: Kd is a multiple of 16 and A is 64-byte aligned -> always vector A loads
-      if (act) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_ACT, KORD_TAP>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_TAP>), grid, dim3(256), 0, st, a);
+      if (act) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_ACT, KORD_TAP, EPI_PLAIN, MF>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_TAP, EPI_PLAIN, MF>), grid, dim3(256), 0, st, a);
       return;
     }
   }
