@@ -216,6 +216,7 @@ def main():
     def step():
         return train.train_step(net, opt, video, audio, selflabels, selected, hc)
 
+    loss = step()        # plan-building pass (benchmark-mode launch-configuration timing), never timed
     for _ in range(a.warmup):
         loss = step()
     torch.cuda.synchronize()
