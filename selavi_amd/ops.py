@@ -123,14 +123,22 @@ def _tune_cache_save():
 
 
 def _time_call(fn, reps=3):
+    """Mean device time of fn() in ms: one warm call, then enough repetitions for >= ~2 ms of timed work
+    (small launches are noisy), best of two such groups."""
     fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / reps
+    best = None
+    for _ in range(2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1) / reps
+        if best is None:
+            reps = int(min(20, max(reps, 2.0 / max(t, 1e-3))))
+        best = t if best is None else min(best, t)
+    return best
 
 
 def _autotune(plan):
