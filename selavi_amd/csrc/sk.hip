@@ -52,6 +52,9 @@ static inline SkWs carve(void* ws, int K, int grid) {
 
 constexpr int SK_THREADS = 512;           // 8 waves per workgroup
 constexpr int SK_WAVES = SK_THREADS / 64;
+#ifndef SK_PASS_ROWS
+#define SK_PASS_ROWS 4                    // rows a wave keeps in flight in the fused pass
+#endif
 
 // torch.argmax semantics: NaN counts as the maximum, first index wins ties.
 __device__ __forceinline__ bool beats(double a, int ia, double b, int ib) {
@@ -476,8 +479,10 @@ size_t slv_sk_workspace_bytes(int K, int grid) {
 }
 
 int32_t slv_sk_default_grid(int64_t N, int K) {
-  // 2 workgroups of 8 waves per CU on a 256-CU part; never more blocks than 8-row chunks
-  int64_t g = 2048;  // 8 workgroups per CU's worth of 8-row chunks: best tail balance (81 vs 85 us at 256)
+  // 2 workgroups of 8 waves per CU on a 256-CU part; never more blocks than 8-row chunks.  Measured per
+  // iteration at N=170752, K=309 (pass + grid reduce + update): 256: 88.5, 512: 87.9, 1024: 90.9, 2048: 95.9 us
+  // (the reduce over [grid][K] partials grows with the grid).
+  int64_t g = 512;
   const int64_t maxg = (N + 7) / 8;
   if (g > maxg) g = maxg;
   if (g < 1) g = 1;
@@ -560,7 +565,7 @@ int slv_sk_pass(const double* P, int64_t N_local, int64_t N_global, int K, doubl
   SkWs w = carve(ws, K, grid);
   const int64_t rpb = (N_local + grid - 1) / grid;
   const double c = 1.0 / (double)N_global;  // sk_utils.py:395
-  SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_pass_kernel<KJ, 4>), dim3(grid), dim3(SK_THREADS), sh_bytes(KJ),
+  SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_pass_kernel<KJ, SK_PASS_ROWS>), dim3(grid), dim3(SK_THREADS), sh_bytes(KJ),
                                         (hipStream_t)stream, P, N_local, K, c, beta, w, rpb));
   SLV_LAUNCH_CHECK();
   return 0;

@@ -35,7 +35,7 @@ for k, d in list(res.items()):          # aliases bench.py looks up
     m = re.match(r"igemm_kernel<(\d+), (\d+), (\d+), (\w+), (\d+)", k)
     if m and m.group(1) == "0" and m.group(5) == "1":
         out["hot_conv_fwd"] = dict(d, kernel=k)
-    if "sk_pass_kernel" in k and k.endswith("grid=524288"):
+    if "sk_pass_kernel" in k and k.endswith("grid=262144"):
         out["sk_pass"] = dict(d, kernel=k)
 json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
