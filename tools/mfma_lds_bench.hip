@@ -45,6 +45,47 @@ __global__ __launch_bounds__(256, OCC) void bench16(const float* __restrict__ sr
   dst[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
+// 16x16x4 with 8-byte A fragment reads: k assignment k = 8h + 2fk + s, row stride 20 (64-bank conflict-free)
+template <int MT, int NT, int OCC>
+__global__ __launch_bounds__(256, OCC) void bench16b64(const float* __restrict__ src, float* __restrict__ dst, int chunks) {
+  constexpr int BM = MT * 16, BN = NT * 64, AS = 20, BS = BN + 8;
+  __shared__ float smem[2 * (BM * AS + 16 * BS)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 2 * (BM * AS + 16 * BS); i += 256) smem[i] = src[i & 1023];
+  __syncthreads();
+  const int fi = lane & 15, fk = lane >> 4;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x4 acc[MT][NT];
+  for (int i = 0; i < MT; ++i)
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < chunks; ++c) {
+    const float* As = smem + (c & 1) * (BM * AS + 16 * BS);
+    const float* Bs = As + BM * AS;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x2 a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = *(const f32x2*)&As[(i * 16 + fi) * AS + 8 * h + 2 * fk];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        b[j][0] = Bs[(8 * h + 2 * fk) * BS + (wave * NT + j) * 16 + fi];
+        b[j][1] = Bs[(8 * h + 2 * fk + 1) * BS + (wave * NT + j) * 16 + fi];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s2], b[j][s2], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float s = 0.f;
+  for (int i = 0; i < MT; ++i)
+    for (int j = 0; j < NT; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  dst[(size_t)blockIdx.x * 256 + tid] = s;
+}
+
 // 32x32x2: lane (fi = lane & 31, fk = lane >> 5) holds A[row fi][k fk] / B[k fk][col fi]; 16 accumulator regs
 template <int MT, int NT, int OCC>
 __global__ __launch_bounds__(256, OCC) void bench32(const float* __restrict__ src, float* __restrict__ dst, int chunks) {
@@ -115,6 +156,10 @@ int main() {
   RUN16(4, 2, 5);
   RUN16(4, 1, 8);
   RUN16(15, 1, 3);
+#define RUN16B(MT, NT, OCC) run("16x16x4 b64-A tile " #MT "x16 x " #NT "x64 occ " #OCC, [&] { hipLaunchKernelGGL((bench16b64<MT, NT, OCC>), dim3(blocks), dim3(256), 0, 0, src, dst, chunks); }, 2.0 * MT * 16 * NT * 64 * 16, blocks, chunks)
+  RUN16B(9, 2, 3);
+  RUN16B(8, 2, 4);
+  RUN16B(4, 1, 8);
   RUN32(4, 1, 3);
   RUN32(2, 1, 5);
   RUN32(5, 1, 2);
