@@ -264,7 +264,8 @@ def main():
             "config": {"workload": "cfg2: R(2+1)D-18 + ResNet-9, per-GPU bs=%d, 16x112x112 video, 1x129x100 "
                                    "log-mel, K=309, headcount=10, SGD(m=0.9, wd=1e-5), fp32" % B,
                        "global_batch": world * B, "parallelism": "dp%d" % world,
-                       "sync_bn": world > 1, "loss_last_step": loss_v},
+                       "sync_bn": world > 1, "loss_last_step": loss_v,
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
             "roofline": {"bound": "mfma", "achieved": hot["tflops"], "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
                          "frac": hot["tflops"] / PEAK_FP32_MFMA_TF,
                          # HBM bytes per launch of this kernel at B=16 from rocprofv3 PMC passes
