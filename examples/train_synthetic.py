@@ -5,7 +5,7 @@ checkpoint restore, BN warm-up, per-iteration `cluster()` when the schedule says
 labels, checkpoint per epoch), with its dataset / logging / SLURM plumbing replaced by the synthetic dataset of
 selavi_amd.data.  Every device-side operation goes through libselavi_hip.so.
 
-    python examples/train_synthetic.py --epochs 2 --n 256 --batch 8 --frames 8 --size 64
+    python examples/train_synthetic.py --epochs 2 --dataset-size 256 --batch 8 --frames 8 --size 64
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_synthetic.py ...
 """
 import argparse
@@ -27,7 +27,7 @@ from selavi_amd.data import SyntheticAVDataset
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=2)
-    ap.add_argument("--n", type=int, default=256, help="dataset size")
+    ap.add_argument("--dataset-size", dest="n", type=int, default=256)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch size")
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--size", type=int, default=64)

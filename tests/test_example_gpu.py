@@ -23,7 +23,7 @@ def test_train_synthetic_runs_clusters_and_resumes(tmp_path):
 
 
 def _run(ts, tmp_path):
-    common = ["--n", "64", "--batch", "8", "--frames", "4", "--size", "32", "--mel", "40", "36",
+    common = ["--dataset-size", "64", "--batch", "8", "--frames", "4", "--size", "32", "--mel", "40", "36",
               "--num-clusters", "8", "--headcount", "2", "--nopts", "3", "--dump-path", str(tmp_path)]
     log, labels, model = ts.main(["--epochs", "2"] + common)
     assert len(log) == 2 * 8 and all(math.isfinite(v) for v in log)
