@@ -8,6 +8,22 @@
 
 namespace slv {
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+// Streaming accesses of tensors far larger than the 4 MB L2 slices: non-temporal loads/stores keep them from
+// evicting the operands of the neighbouring GEMMs (bn_bwd_apply on the 462 MB layer-1 tensors: 5.0 -> 5.9 TB/s).
+// NT is a template flag chosen by tensor size; small late-layer tensors stay cacheable for their consumer.
+constexpr size_t NT_MIN_BYTES = 32u << 20;
+template <bool NT>
+__device__ __forceinline__ void ld4(float* dst, const float* src) {
+  if constexpr (NT) *(v4f*)dst = __builtin_nontemporal_load((const v4f*)src);
+  else *(v4f*)dst = *(const v4f*)src;
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float* dst, const float* src) {
+  if constexpr (NT) __builtin_nontemporal_store(*(const v4f*)src, (v4f*)dst);
+  else *(v4f*)dst = *(const v4f*)src;
+}
+
 // ------------------------------------------------------------------ BN statistics
 // partial[c][nblk] (float, written by the conv epilogue) -> sums[2C] (double): sum, sum of squares
 __global__ __launch_bounds__(256) void bn_partials_to_sums_kernel(const float* __restrict__ ps,
@@ -114,7 +130,7 @@ __global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const flo
 // out = relu?( x*s + h  +  (res ? (rss ? res*rs + rh : res) : 0) ),  tensors [Bn][C][P]
 // V = 4: P % 4 == 0 and 16-byte aligned tensors -> float4 accesses (4 consecutive elements share a channel).
 // 32-bit exact division by P and C (FastDiv): the flat index stays below 2^32 (checked by the entry point).
-template <int V>
+template <int V, bool NT>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ ss,
                                                     const float* __restrict__ res, const float* __restrict__ rss,
                                                     int relu, float* __restrict__ out, int C, const FastDiv dP,
@@ -128,8 +144,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
     if (res && rss) { rs = rss[c]; rh = rss[C + c]; }
     float xv[V], rv[V], ov[V];
     if constexpr (V == 4) {
-      *(float4*)xv = *(const float4*)(x + i);
-      if (res) *(float4*)rv = *(const float4*)(res + i);
+      ld4<NT>(xv, x + i);
+      if (res) ld4<NT>(rv, res + i);
     } else {
       xv[0] = x[i];
       if (res) rv[0] = res[i];
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
       if (res) v += rss ? (rv[j] * rs + rh) : rv[j];
       ov[j] = relu ? fmaxf(v, 0.f) : v;
     }
-    if constexpr (V == 4) *(float4*)(out + i) = *(float4*)ov;
+    if constexpr (V == 4) *(float4*)(out + i) = *(float4*)ov;   // the block output feeds the next conv: cacheable
     else out[i] = ov[0];
   }
 }
@@ -149,7 +165,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
 // For channel c (blockIdx.x) and slice blockIdx.y of the (b,p) space:
 //   g' = mask * g ;  partial = { sum g', sum g' * xhat(x) [, sum g' * xhat2(x2)] }
 // MASK 0: none; 1: own BN output > 0 (s*x+h); 2: external tensor v > 0 (and g' is written to gout)
-template <int MASK, bool TWO, int V>
+template <int MASK, bool TWO, int V, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ gin,
                                                            const float* __restrict__ x,
                                                            const float* __restrict__ mi,  // mean,invstd [2C]
@@ -172,10 +188,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const size_t ad = ((size_t)b * C + c) * P + (size_t)(e - b * P);
     float g[V], xv[V], vv[V], x2v[V];
     if constexpr (V == 4) {
-      *(float4*)g = *(const float4*)(gin + ad);
-      *(float4*)xv = *(const float4*)(x + ad);
-      if (MASK == 2) *(float4*)vv = *(const float4*)(v + ad);
-      if (TWO) *(float4*)x2v = *(const float4*)(x2 + ad);
+      ld4<NT>(g, gin + ad);
+      ld4<NT>(xv, x + ad);
+      if (MASK == 2) ld4<NT>(vv, v + ad);
+      if (TWO) ld4<NT>(x2v, x2 + ad);
     } else {
       g[0] = gin[ad];
       xv[0] = x[ad];
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_finalize_kernel(const float* 
 }
 
 // materialise the gradient w.r.t. a raw conv output: out = A1*mask*g + A2 + A3*x  (bwd5 = s,h,A1,A2,A3)
-template <int V>
+template <int V, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ b5, int relu,
                                                           float* __restrict__ out, int C, const FastDiv dP,
@@ -312,8 +328,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float s = b5[c], h = b5[C + c], a1 = b5[2 * C + c], a2 = b5[3 * C + c], a3 = b5[4 * C + c];
     float xv[V], gv[V], ov[V];
     if constexpr (V == 4) {
-      *(float4*)xv = *(const float4*)(x + i);
-      *(float4*)gv = *(const float4*)(g + i);
+      ld4<NT>(xv, x + i);
+      ld4<NT>(gv, g + i);
     } else {
       xv[0] = x[i];
       gv[0] = g[i];
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       const float gm = (relu && !(xv[j] * s + h > 0.f)) ? 0.f : gv[j];
       ov[j] = a1 * gm + a2 + a3 * xv[j];
     }
-    if constexpr (V == 4) *(float4*)(out + i) = *(float4*)ov;
+    if constexpr (V == 4) st4<NT>(out + i, ov);
     else out[i] = ov[0];
   }
 }
@@ -505,10 +521,14 @@ int slv_bn_act(const float* x, const float* scale_shift, const float* res, const
   SLV_CHECK_ARG(total < (1ull << 32), "more than 2^32 elements");
   const FastDiv dP = make_fastdiv((unsigned)P), dC = make_fastdiv((unsigned)C);
   if (P % 4 == 0 && aligned16(x) && aligned16(out) && aligned16(res))
-    hipLaunchKernelGGL((bn_act_kernel<4>), dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, x,
-                       scale_shift, res, res_scale_shift, relu, out, C, dP, dC, (unsigned)(total / 4));
+    if (total * 4 >= NT_MIN_BYTES)
+      hipLaunchKernelGGL((bn_act_kernel<4, true>), dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                         scale_shift, res, res_scale_shift, relu, out, C, dP, dC, (unsigned)(total / 4));
+    else
+      hipLaunchKernelGGL((bn_act_kernel<4, false>), dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                         scale_shift, res, res_scale_shift, relu, out, C, dP, dC, (unsigned)(total / 4));
   else
-    hipLaunchKernelGGL((bn_act_kernel<1>), dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL((bn_act_kernel<1, false>), dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x,
                        scale_shift, res, res_scale_shift, relu, out, C, dP, dC, (unsigned)total);
   SLV_LAUNCH_CHECK();
   return 0;
@@ -539,11 +559,17 @@ int slv_bn_bwd_reduce(const float* g, const float* x, const float* mean_invstd, 
   unsigned per = (tot + nsplit - 1) / nsplit;
   per = (per + 3u) & ~3u;                       // slices start on 4-element boundaries
   const FastDiv dP = make_fastdiv((unsigned)P);
-#define SLV_RED2(MASK, TWO, V)                                                                               \
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<MASK, TWO, V>), grid, dim3(256), 0, st, g, x, mean_invstd,         \
+  const bool big = (size_t)tot * C * 4 >= NT_MIN_BYTES;
+#define SLV_RED2(MASK, TWO, V, NT_)                                                                          \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<MASK, TWO, V, NT_>), grid, dim3(256), 0, st, g, x, mean_invstd,    \
                      scale_shift_mask, v_mask, x2, mean_invstd2, g_out, partial, partial2, C, (unsigned)P, dP, tot, \
                      per, nsplit)
-#define SLV_RED(MASK, TWO) do { if (vec) SLV_RED2(MASK, TWO, 4); else SLV_RED2(MASK, TWO, 1); } while (0)
+#define SLV_RED(MASK, TWO)                                                                     \
+  do {                                                                                         \
+    if (vec && big) SLV_RED2(MASK, TWO, 4, true);                                              \
+    else if (vec) SLV_RED2(MASK, TWO, 4, false);                                               \
+    else SLV_RED2(MASK, TWO, 1, false);                                                        \
+  } while (0)
   if (v_mask) {
     if (x2) SLV_RED(2, true); else SLV_RED(2, false);
   } else if (scale_shift_mask) {
@@ -591,11 +617,15 @@ int slv_bn_bwd_apply(const float* g, const float* x, const float* bwd5, int relu
   SLV_CHECK_ARG(total < (1ull << 32), "more than 2^32 elements");
   const FastDiv dP = make_fastdiv((unsigned)P), dC = make_fastdiv((unsigned)C);
   if (P % 4 == 0 && aligned16(g) && aligned16(x) && aligned16(out))
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream,
-                       g, x, bwd5, relu, out, C, dP, dC, (unsigned)(total / 4));
+    if (total * 4 >= NT_MIN_BYTES)
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3(grid_for(total / 4, 8192)), dim3(256), 0,
+                         (hipStream_t)stream, g, x, bwd5, relu, out, C, dP, dC, (unsigned)(total / 4));
+    else
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<4, false>), dim3(grid_for(total / 4, 8192)), dim3(256), 0,
+                         (hipStream_t)stream, g, x, bwd5, relu, out, C, dP, dC, (unsigned)(total / 4));
   else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, g,
-                       x, bwd5, relu, out, C, dP, dC, (unsigned)total);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<1, false>), dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       g, x, bwd5, relu, out, C, dP, dC, (unsigned)total);
   SLV_LAUNCH_CHECK();
   return 0;
 }
