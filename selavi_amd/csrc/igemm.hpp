@@ -66,6 +66,7 @@ struct IgemmArgs {
                      // CONV with KORD_TAP: one entry per 16-deep CHUNK {element offset of (tap, first channel),
                      // tap | first channel << 8}
   int kord;          // CONV: KORD_CHAN / KORD_TAP
+  int vec_b;         // WGRAD: 16-byte loads of the gathered operand allowed (see template flag VB)
   unsigned sprod4;   // KORD_TAP: bytes between consecutive channels of the gathered tensor (S0*S1*S2*4)
   const int* tapd;   // per-tap packed deltas: (d0+64) | (d1+64)<<8 | (d2+64)<<16, 64 entries
   float* C;          // output
@@ -123,7 +124,11 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 //     1: v_mfma_f32_32x32x2_f32 (tile edge 32, block (MT*32) x (NT*128)): one A + one B fragment read per 4096 FLOP
 //        instead of per 2048 -- the LDS+MFMA-only loop reaches 145 TF with it against 127-135 TF
 //        (tools/mfma_lds_bench.hip); usable where the row count pads well to 32/64/96/128.
-template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN, int EPI = EPI_PLAIN, int MF = 0>
+// VB (MODE_WGRAD, with VA): the gathered operand is read with 16-byte loads as well.  Host-checked: kh = kw = 1,
+// spatial stride 1, no spatial padding (the temporal (3,1,1) convs and the 1x1x1 downsample convs with stride 1 in
+// H/W), Ho*Wo % 4 == 0, 16-byte aligned input: a quad of consecutive output positions then reads 4 consecutive,
+// aligned input elements and is valid or padded as a whole (only the temporal index can fall outside).
+template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN, int EPI = EPI_PLAIN, int MF = 0, bool VB = false>
 #ifndef SLV_LB_CONV
 #define SLV_LB_CONV 3
 #endif
@@ -244,7 +249,24 @@ __global__ __launch_bounds__(256, ((MF == 0 && MT >= 15) ? 2 : (MODE == MODE_WGR
   int wt_off[BROWS], wt_d[BROWS];
   (void)wt_off; (void)wt_d;
   float* pBs = smem + 2 * (A_ELEMS + B_ELEMS);  // [2][BN]
-  if constexpr (MODE == MODE_WGRAD) {
+  constexpr int NBQ = BN / 64;                   // VB: 64-column passes (column = tid >> 2 + 64 i, k quad = tid & 3)
+  f32x4 rb4[VB ? NBQ : 1];
+  int vb_off[NBQ], vb_dt[NBQ];
+  float vb_s[NBQ], vb_h[NBQ];
+  (void)rb4; (void)vb_off; (void)vb_dt; (void)vb_s; (void)vb_h;
+  if constexpr (MODE == MODE_WGRAD && VB) {
+#pragma unroll
+    for (int i = 0; i < NBQ; ++i) {
+      const long long n = n0 + (tid >> 2) + 64 * i;
+      const int2 e = g.tab[n < g.Ntot ? n : g.Ntot];          // entry Ntot is an invalid pad entry (tap 63)
+      vb_off[i] = e.x;
+      vb_dt[i] = ((e.y & 63) == 63) ? (1 << 20) : ((g.tapd[e.y & 63] & 255) - 64);   // temporal delta (incl. -pad)
+      const int ch = ((e.y & 63) == 63) ? 0 : (e.y >> 8);
+      vb_s[i] = (PRO == PRO_ACT) ? g.pb[ch] : 1.f;
+      vb_h[i] = (PRO == PRO_ACT) ? g.pb[g.Cin + ch] : 0.f;
+    }
+  }
+  if constexpr (MODE == MODE_WGRAD && !VB) {
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
       const long long n = n0 + a_r + 16 * i;
@@ -364,6 +386,24 @@ __global__ __launch_bounds__(256, ((MF == 0 && MT >= 15) ? 2 : (MODE == MODE_WGR
           ra[i] = bload(rA, off);
         }
       }
+      if constexpr (VB) {
+        // quad of 4 consecutive output positions = 4 consecutive input elements of (b, ci, to*st + dt, :)
+        const unsigned pq = (wp - (unsigned)a_kk) + (unsigned)c * 16u + 4u * (unsigned)v_kq;
+        const bool qok = (long long)pq < g.Ptot;
+        const unsigned pqq = qok ? pq : 0u;
+        const unsigned bq = fdiv(pqq, g.dPout);
+        const unsigned remq = pqq - bq * (unsigned)Pout;
+        const unsigned toq = fdiv(remq, g.dHoWo);
+        const unsigned r2q = remq - toq * (unsigned)HoWo;
+        const unsigned xbq = bq * (unsigned)(g.Cin * THWi) + toq * (unsigned)(g.st * HWi) + r2q;
+#pragma unroll
+        for (int i = 0; i < NBQ; ++i) {
+          const bool ok = qok && (unsigned)((int)toq * g.st + vb_dt[i]) < (unsigned)g.Ti;
+          rb4[i] = bload4(rB, ok ? ((xbq + (unsigned)vb_off[i]) << 2) : OOB);
+          okB |= (ok ? 1u : 0u) << i;
+        }
+        return;
+      }
       // B[n][p] = act(X)[b][ci][in_pos(p, tap)]
       // table offsets / tap deltas already contain "- pad" (same table as the forward conv)
       const int ti0 = (int)to * g.st - 64, hi0 = (int)ho * g.sh - 64, wi0 = (int)wo * g.sw - 64;
@@ -403,6 +443,21 @@ __global__ __launch_bounds__(256, ((MF == 0 && MT >= 15) ? 2 : (MODE == MODE_WGR
           As[m * AS + a_kk] = ra[i];
         }
       }
+      if constexpr (VB) {
+#pragma unroll
+        for (int i = 0; i < NBQ; ++i) {
+          const int nn = (tid >> 2) + 64 * i;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = rb4[i][j];
+            if constexpr (PRO == PRO_ACT) {
+              v = apply_act(v, vb_s[i], vb_h[i], g.b_relu);
+              v = ((okB >> i) & 1u) ? v : 0.f;
+            }
+            Bs[nn * 18 + 4 * v_kq + j] = v;
+          }
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
         const int nn = a_r + 16 * i;
@@ -412,6 +467,7 @@ __global__ __launch_bounds__(256, ((MF == 0 && MT >= 15) ? 2 : (MODE == MODE_WGR
           v = ((okB >> i) & 1u) ? v : 0.f;
         }
         Bs[nn * 18 + a_kk] = v;
+      }
       }
     } else {
       if constexpr (!VA) {
@@ -682,6 +738,13 @@ template <int MODE, int MT, int NT, int MF = 0>
 inline void launch_igemm(const IgemmArgs& a, int splits, bool vec_a, hipStream_t st) {
   dim3 grid(a.nblkM * a.nblkN * splits, 1, 1);
   const bool act = (MODE != MODE_GEMM) && a.b_pro == PRO_ACT;
+  if constexpr (MODE == MODE_WGRAD) {
+    if (a.vec_b && vec_a) {   // 16-byte loads for both operands (temporal / pointwise convs)
+      if (act) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_ACT, KORD_CHAN, EPI_PLAIN, MF, true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_CHAN, EPI_PLAIN, MF, true>), grid, dim3(256), 0, st, a);
+      return;
+    }
+  }
 #define SLV_L(VA_, PRO_) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, VA_, PRO_, KORD_CHAN, EPI_PLAIN, MF>), grid, dim3(256), 0, st, a)
   if constexpr (MODE == MODE_CONV) {
     if (a.R) {  // backward-data with the fused BatchNorm-backward reduction (never has an operand prologue)
