@@ -124,10 +124,11 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 //     1: v_mfma_f32_32x32x2_f32 (tile edge 32, block (MT*32) x (NT*128)): one A + one B fragment read per 4096 FLOP
 //        instead of per 2048 -- the LDS+MFMA-only loop reaches 145 TF with it against 127-135 TF
 //        (tools/mfma_lds_bench.hip); usable where the row count pads well to 32/64/96/128.
-// VB (MODE_WGRAD, with VA): the gathered operand is read with 16-byte loads as well.  Host-checked: kh = kw = 1,
-// spatial stride 1, no spatial padding (the temporal (3,1,1) convs and the 1x1x1 downsample convs with stride 1 in
-// H/W), Ho*Wo % 4 == 0, 16-byte aligned input: a quad of consecutive output positions then reads 4 consecutive,
-// aligned input elements and is valid or padded as a whole (only the temporal index can fall outside).
+// VB (MODE_WGRAD, with VA): the gathered operand is read with 16-byte loads as well.  Host-checked: spatial stride 1,
+// "same" spatial padding with kh, kw in {1, 3} (Ho = Hi, Wo = Wi), Wo % 4 == 0, 16-byte aligned input.  A quad of
+// consecutive output positions (one row, wo % 4 == 0) then reads the 4 consecutive input elements wo+dw .. wo+dw+3
+// of row (to*st + dt, ho + dh): the row is valid or padded as a whole; for dw = -1 / +1 only the first / last
+// element of a quad at the left / right image border is padding -- there the aligned quad is loaded and shifted.
 template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN, int EPI = EPI_PLAIN, int MF = 0, bool VB = false>
 #ifndef SLV_LB_CONV
 #define SLV_LB_CONV 3
@@ -251,16 +252,21 @@ __global__ __launch_bounds__(256, ((MF == 0 && MT >= 15) ? 2 : (MODE == MODE_WGR
   float* pBs = smem + 2 * (A_ELEMS + B_ELEMS);  // [2][BN]
   constexpr int NBQ = BN / 64;                   // VB: 64-column passes (column = tid >> 2 + 64 i, k quad = tid & 3)
   f32x4 rb4[VB ? NBQ : 1];
-  int vb_off[NBQ], vb_dt[NBQ];
+  int vb_off[NBQ], vb_dt[NBQ], vb_dh[NBQ], vb_dw[NBQ];
   float vb_s[NBQ], vb_h[NBQ];
-  (void)rb4; (void)vb_off; (void)vb_dt; (void)vb_s; (void)vb_h;
+  unsigned edgeLo = 0, edgeHi = 0;   // per column-pass bit: the quad was loaded one element to the right / left
+  (void)rb4; (void)vb_off; (void)vb_dt; (void)vb_dh; (void)vb_dw; (void)vb_s; (void)vb_h; (void)edgeLo; (void)edgeHi;
   if constexpr (MODE == MODE_WGRAD && VB) {
 #pragma unroll
     for (int i = 0; i < NBQ; ++i) {
       const long long n = n0 + (tid >> 2) + 64 * i;
       const int2 e = g.tab[n < g.Ntot ? n : g.Ntot];          // entry Ntot is an invalid pad entry (tap 63)
       vb_off[i] = e.x;
-      vb_dt[i] = ((e.y & 63) == 63) ? (1 << 20) : ((g.tapd[e.y & 63] & 255) - 64);   // temporal delta (incl. -pad)
+      const bool pad_entry = (e.y & 63) == 63;
+      const int d = pad_entry ? 0 : g.tapd[e.y & 63];
+      vb_dt[i] = pad_entry ? (1 << 20) : ((d & 255) - 64);            // deltas include "- pad"
+      vb_dh[i] = ((d >> 8) & 255) - 64;
+      vb_dw[i] = ((d >> 16) & 255) - 64;
       const int ch = ((e.y & 63) == 63) ? 0 : (e.y >> 8);
       vb_s[i] = (PRO == PRO_ACT) ? g.pb[ch] : 1.f;
       vb_h[i] = (PRO == PRO_ACT) ? g.pb[g.Cin + ch] : 0.f;
@@ -395,12 +401,21 @@ __global__ __launch_bounds__(256, ((MF == 0 && MT >= 15) ? 2 : (MODE == MODE_WGR
         const unsigned remq = pqq - bq * (unsigned)Pout;
         const unsigned toq = fdiv(remq, g.dHoWo);
         const unsigned r2q = remq - toq * (unsigned)HoWo;
-        const unsigned xbq = bq * (unsigned)(g.Cin * THWi) + toq * (unsigned)(g.st * HWi) + r2q;
+        const unsigned hoq = fdiv(r2q, g.dWo);
+        const unsigned woq = r2q - hoq * (unsigned)g.Wo;
+        const unsigned xbq = bq * (unsigned)(g.Cin * THWi) + toq * (unsigned)(g.st * HWi) + r2q;   // Hi = Ho, Wi = Wo
+        edgeLo = edgeHi = 0;
 #pragma unroll
         for (int i = 0; i < NBQ; ++i) {
-          const bool ok = qok && (unsigned)((int)toq * g.st + vb_dt[i]) < (unsigned)g.Ti;
-          rb4[i] = bload4(rB, ok ? ((xbq + (unsigned)vb_off[i]) << 2) : OOB);
+          const bool ok = qok && (unsigned)((int)toq * g.st + vb_dt[i]) < (unsigned)g.Ti &&
+                          (unsigned)((int)hoq + vb_dh[i]) < (unsigned)g.Hi;
+          const bool lo = vb_dw[i] < 0 && woq == 0u;                       // element 0 is left padding
+          const bool hi = vb_dw[i] > 0 && woq + 4u == (unsigned)g.Wo;      // element 3 is right padding
+          const unsigned el = xbq + (unsigned)vb_off[i] + (lo ? 1u : 0u) - (hi ? 1u : 0u);
+          rb4[i] = bload4(rB, ok ? (el << 2) : OOB);
           okB |= (ok ? 1u : 0u) << i;
+          edgeLo |= (lo ? 1u : 0u) << i;
+          edgeHi |= (hi ? 1u : 0u) << i;
         }
         return;
       }
@@ -447,15 +462,16 @@ __global__ __launch_bounds__(256, ((MF == 0 && MT >= 15) ? 2 : (MODE == MODE_WGR
 #pragma unroll
         for (int i = 0; i < NBQ; ++i) {
           const int nn = (tid >> 2) + 64 * i;
+          const bool lo = (edgeLo >> i) & 1u, hi = (edgeHi >> i) & 1u;
+          f32x4 q = rb4[i];
+          if constexpr (PRO == PRO_ACT) {   // activation BEFORE the border shift: padding is zero after BN+ReLU
+            const bool ok = (okB >> i) & 1u;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float v = rb4[i][j];
-            if constexpr (PRO == PRO_ACT) {
-              v = apply_act(v, vb_s[i], vb_h[i], g.b_relu);
-              v = ((okB >> i) & 1u) ? v : 0.f;
-            }
-            Bs[nn * 18 + 4 * v_kq + j] = v;
+            for (int j = 0; j < 4; ++j) q[j] = ok ? apply_act(q[j], vb_s[i], vb_h[i], g.b_relu) : 0.f;
           }
+          const f32x4 sh = lo ? (f32x4){0.f, q[0], q[1], q[2]} : (hi ? (f32x4){q[1], q[2], q[3], 0.f} : q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Bs[nn * 18 + 4 * v_kq + j] = sh[j];
         }
       } else {
 #pragma unroll
