@@ -885,8 +885,12 @@ int slv_conv_wgrad(const int32_t* geom, const float* dy, const float* x_in, cons
   a.dHoWo = make_fastdiv((unsigned)(g.Ho * g.Wo));
   a.dWo = make_fastdiv((unsigned)g.Wo);
   // both operands by 16-byte loads when a quad of output positions maps to 4 consecutive aligned input elements
-  a.vec_b = (g.sh == 1 && g.sw == 1 && (g.kh == 1 || g.kh == 3) && (g.kw == 1 || g.kw == 3) && g.ph == g.kh / 2 &&
-             g.pw == g.kw / 2 && g.Wo % 4 == 0 && (((size_t)x_in) & 15) == 0 && !getenv("SLV_NO_VECB")) ? 1 : 0;
+  a.vec_b = 0;
+  if (g.sh == 1 && g.sw == 1 && (((size_t)x_in) & 15) == 0 && !getenv("SLV_NO_VECB")) {
+    if (g.kh == 1 && g.kw == 1 && g.ph == 0 && g.pw == 0 && (g.Ho * g.Wo) % 4 == 0) a.vec_b = 1;
+    else if ((g.kh == 1 || g.kh == 3) && (g.kw == 1 || g.kw == 3) && g.ph == g.kh / 2 && g.pw == g.kw / 2 &&
+             g.Wo % 4 == 0) a.vec_b = 2;
+  }
   const int mt = c.mt, nt = c.nt, splits = c.sp;
   const long long chunks = (a.Ptot + 15) / 16;
   a.chunks_per_split = (int)((chunks + splits - 1) / splits);

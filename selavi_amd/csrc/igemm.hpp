@@ -66,7 +66,7 @@ struct IgemmArgs {
                      // CONV with KORD_TAP: one entry per 16-deep CHUNK {element offset of (tap, first channel),
                      // tap | first channel << 8}
   int kord;          // CONV: KORD_CHAN / KORD_TAP
-  int vec_b;         // WGRAD: 16-byte loads of the gathered operand allowed (see template flag VB)
+  int vec_b;         // WGRAD: 16-byte loads of the gathered operand: 0 no, 1 / 2 = template flag VB
   unsigned sprod4;   // KORD_TAP: bytes between consecutive channels of the gathered tensor (S0*S1*S2*4)
   const int* tapd;   // per-tap packed deltas: (d0+64) | (d1+64)<<8 | (d2+64)<<16, 64 entries
   float* C;          // output
@@ -129,7 +129,8 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 // consecutive output positions (one row, wo % 4 == 0) then reads the 4 consecutive input elements wo+dw .. wo+dw+3
 // of row (to*st + dt, ho + dh): the row is valid or padded as a whole; for dw = -1 / +1 only the first / last
 // element of a quad at the left / right image border is padding -- there the aligned quad is loaded and shifted.
-template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN, int EPI = EPI_PLAIN, int MF = 0, bool VB = false>
+// VB = 1: kh = kw = 1 (temporal / pointwise convs; only Ho*Wo % 4 == 0 needed), VB = 2: the general form.
+template <int MODE, int MT, int NT, bool VA, int PRO, int KORD = KORD_CHAN, int EPI = EPI_PLAIN, int MF = 0, int VB = 0>
 #ifndef SLV_LB_CONV
 #define SLV_LB_CONV 3
 #endif
@@ -401,16 +402,19 @@ __global__ __launch_bounds__(256, ((MF == 0 && MT >= 15) ? 2 : (MODE == MODE_WGR
         const unsigned remq = pqq - bq * (unsigned)Pout;
         const unsigned toq = fdiv(remq, g.dHoWo);
         const unsigned r2q = remq - toq * (unsigned)HoWo;
-        const unsigned hoq = fdiv(r2q, g.dWo);
-        const unsigned woq = r2q - hoq * (unsigned)g.Wo;
+        unsigned hoq = 0, woq = 4;
+        if constexpr (VB == 2) {
+          hoq = fdiv(r2q, g.dWo);
+          woq = r2q - hoq * (unsigned)g.Wo;
+        }
         const unsigned xbq = bq * (unsigned)(g.Cin * THWi) + toq * (unsigned)(g.st * HWi) + r2q;   // Hi = Ho, Wi = Wo
         edgeLo = edgeHi = 0;
 #pragma unroll
         for (int i = 0; i < NBQ; ++i) {
           const bool ok = qok && (unsigned)((int)toq * g.st + vb_dt[i]) < (unsigned)g.Ti &&
-                          (unsigned)((int)hoq + vb_dh[i]) < (unsigned)g.Hi;
-          const bool lo = vb_dw[i] < 0 && woq == 0u;                       // element 0 is left padding
-          const bool hi = vb_dw[i] > 0 && woq + 4u == (unsigned)g.Wo;      // element 3 is right padding
+                          (VB == 1 || (unsigned)((int)hoq + vb_dh[i]) < (unsigned)g.Hi);
+          const bool lo = VB == 2 && vb_dw[i] < 0 && woq == 0u;                       // element 0 is left padding
+          const bool hi = VB == 2 && vb_dw[i] > 0 && woq + 4u == (unsigned)g.Wo;      // element 3 is right padding
           const unsigned el = xbq + (unsigned)vb_off[i] + (lo ? 1u : 0u) - (hi ? 1u : 0u);
           rb4[i] = bload4(rB, ok ? (el << 2) : OOB);
           okB |= (ok ? 1u : 0u) << i;
@@ -755,9 +759,14 @@ inline void launch_igemm(const IgemmArgs& a, int splits, bool vec_a, hipStream_t
   dim3 grid(a.nblkM * a.nblkN * splits, 1, 1);
   const bool act = (MODE != MODE_GEMM) && a.b_pro == PRO_ACT;
   if constexpr (MODE == MODE_WGRAD) {
-    if (a.vec_b && vec_a) {   // 16-byte loads for both operands (temporal / pointwise convs)
-      if (act) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_ACT, KORD_CHAN, EPI_PLAIN, MF, true>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_CHAN, EPI_PLAIN, MF, true>), grid, dim3(256), 0, st, a);
+    if (a.vec_b == 1 && vec_a) {   // 16-byte loads for both operands: temporal / pointwise convs
+      if (act) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_ACT, KORD_CHAN, EPI_PLAIN, MF, 1>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_CHAN, EPI_PLAIN, MF, 1>), grid, dim3(256), 0, st, a);
+      return;
+    }
+    if (a.vec_b == 2 && vec_a) {   // ... same-padded 3x3 spatial taps
+      if (act) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_ACT, KORD_CHAN, EPI_PLAIN, MF, 2>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_CHAN, EPI_PLAIN, MF, 2>), grid, dim3(256), 0, st, a);
       return;
     }
   }
