@@ -112,8 +112,11 @@ def main(argv=None):
             loss = train.train_step(net, optimizer, video, audio, selflabels, selected, args.headcount)
             log.append(float(loss))
         if args.rank == 0:
+            from sklearn.metrics.cluster import normalized_mutual_info_score
+            nmi = normalized_mutual_info_score(selflabels[:, 0].cpu().numpy(), np.array(dataset._labels))
             print(f"epoch {epoch}: mean loss {np.mean(log[-n_dl:]):.4f}, SK rounds so far {sk_counter}, "
-                  f"distinct labels head 0: {int(selflabels[:, 0].unique().numel())}", flush=True)
+                  f"distinct labels head 0: {int(selflabels[:, 0].unique().numel())}, "
+                  f"NMI(pseudo labels, synthetic classes) {nmi:.3f}", flush=True)
             if ckpt:
                 torch.save({"epoch": epoch + 1, "dist": args.dist, "model": net.state_dict(),
                             "optimizer": optimizer.state_dict(), "selflabels": selflabels}, ckpt)   # :223-242
