@@ -1,0 +1,308 @@
+// C-ABI entry points of the implicit-GEMM convolution family -- gather tables, launch configurations, weight re-layouts, FORWARD conv
+// (see igemm.hpp for the kernel, conv_common.hpp for geometry / tables / launch configurations).
+// Replaces cuDNN conv3d/conv2d forward, backward-data and backward-weight as reached from the torchvision nets
+// instantiated by /root/reference/model.py:95,114 and their autograd backward (main.py:301).
+#include "conv_common.hpp"
+
+namespace slv {
+
+// forward conv: y = sum of the K-slice partials + the per-channel statistics partials the fused epilogue
+// would have produced.  One wave per (channel, column block of BN lattice columns).
+__global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(const float* __restrict__ part,
+                                                                        float* __restrict__ y, float* __restrict__ ssum,
+                                                                        float* __restrict__ ssq, int M, long long Ntot,
+                                                                        int P, int BN, int nblkN, size_t total,
+                                                                        int splits) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long long n0 = (long long)blockIdx.x * BN;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < BN; c += 64) {
+    const long long n = n0 + c;
+    if (n < Ntot) {
+      const long long b = n / P;
+      const size_t ad = ((size_t)b * M + m) * P + (size_t)(n - b * P);
+      float v = part[ad];
+      for (int s = 1; s < splits; ++s) v += part[(size_t)s * total + ad];
+      y[ad] = v;
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    ssum[(size_t)m * nblkN + blockIdx.x] = s1;
+    ssq[(size_t)m * nblkN + blockIdx.x] = s2;
+  }
+}
+
+
+struct TapMap {
+  int off[64], nt[64], j[64];
+};
+// Per-step weight re-layouts (one read of w):
+//   wf (forward, tap-major layers only)  wf[co][((ci/16)*taps + tap)*16 + ci%16]        = w[co][ci][tap]
+//   wt (backward-data), per parity class  channel-major: wt_c[ci][co*nt_c + j]           = w[co][ci][tap_j]
+//                                         tap-major: wt_c[ci][((co/16)*nt_c + j)*16 + co%16] = w[co][ci][tap_j]
+// Padding channels (ci >= Cin resp. co >= Cout) stay zero (buffers are cleared first when padded).
+__global__ void w_transform_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wt,
+                                   int Cout, int Cin, int taps, const TapMap tm, int CpIn, int CpOut) {
+  const size_t n = (size_t)Cout * Cin * taps;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const size_t r = i / taps;
+    const int ci = (int)(r % Cin), co = (int)(r / Cin);
+    const float v = w[i];
+    if (wf) wf[(size_t)co * taps * CpIn + ((size_t)(ci >> 4) * taps + tap) * 16 + (ci & 15)] = v;
+    if (wt && tm.nt[tap] != 0) {
+      if (CpOut) wt[(size_t)tm.off[tap] + (size_t)ci * tm.nt[tap] * CpOut + ((size_t)(co >> 4) * tm.nt[tap] + tm.j[tap]) * 16 + (co & 15)] = v;
+      else wt[(size_t)tm.off[tap] + ((size_t)ci * Cout + co) * tm.nt[tap] + tm.j[tap]] = v;
+    }
+  }
+}
+
+// dW[i] = sum_s partial[s][i], fixed order.  The weight gradients have few elements (83 k for layer1)
+// but up to hundreds of K-slices, so the slice loop is spread over G waves per element group and
+// unrolled 8-fold (independent loads in flight); partial sums are combined in a fixed tree.
+}  // namespace slv
+
+using namespace slv;
+
+extern "C" {
+
+
+// int32 words of the table buffer: dgrad == 0 -> forward/weight-gradient table, 1 -> all parity classes
+int32_t slv_conv_table_len(const int32_t* geom, int dgrad) {
+  Geom g;
+  if (read_geom(geom, g) != 0) return -1;
+  if (!dgrad) return (int32_t)fwd_desc(g).tab_words;
+  Desc ds[8];
+  const int n = dgrad_descs(g, ds);
+  size_t t = 0;
+  for (int i = 0; i < n; ++i) t += ds[i].tab_words;
+  return (int32_t)t;
+}
+
+int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out) {
+  Geom g;
+  SLV_CHECK_ARG(read_geom(geom, g) == 0 && tab_host_out, "invalid geometry");
+  if (!dgrad) {
+    fill_table(fwd_desc(g), tab_host_out);
+    return 0;
+  }
+  Desc ds[8];
+  const int n = dgrad_descs(g, ds);
+  for (int i = 0; i < n; ++i) fill_table(ds[i], tab_host_out + ds[i].tab_off);
+  return 0;
+}
+
+int32_t slv_conv_configs(const int32_t* geom, int op, int32_t* out, int32_t max_out) {
+  Geom g;
+  if (read_geom(geom, g) != 0 || !out || max_out <= 0 || op < 0 || op > 2) return -1;
+  static const int tiles[10][3] = {{9, 2, 0}, {8, 2, 0}, {15, 1, 0}, {4, 2, 0}, {9, 1, 0}, {8, 1, 0}, {4, 1, 0},
+                                   {8, 2, 1}, {6, 2, 1}, {4, 2, 1}};
+  const int taps = g.kt * g.kh * g.kw;
+  int M;
+  long long N, chunks;
+  if (op == 0) { M = g.Cout; N = (long long)g.Bn * g.To * g.Ho * g.Wo; chunks = (g.Cin * taps + 15) / 16; }
+  else if (op == 1) {
+    Desc ds[8];
+    const int n = dgrad_descs(g, ds);
+    M = g.Cin; N = 0; chunks = 1;
+    for (int i = 0; i < n; ++i) {
+      if (ds[i].Ntot > N) N = ds[i].Ntot;
+      if ((ds[i].Kd + 15) / 16 > chunks) chunks = (ds[i].Kd + 15) / 16;
+    }
+  } else { M = g.Cout; N = (long long)g.Cin * taps; chunks = ((long long)g.Bn * g.To * g.Ho * g.Wo + 15) / 16; }
+  long long minpad = 1LL << 62;
+  for (const auto& t : tiles) {
+    const long long bm = t[0] * 16, bn = t[1] * 64;
+    const long long pad = ((M + bm - 1) / bm) * bm * (((N + bn - 1) / bn) * bn);
+    if (pad < minpad) minpad = pad;
+  }
+  int cnt = 0;
+  for (const auto& t : tiles) {
+    const long long bm = t[0] * 16, bn = t[1] * 64;
+    const long long nb = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    if ((double)(nb * bm * bn) > 1.35 * (double)minpad) continue;   // too much padded work
+    int cand[12], nc = 0;
+    if (op != 2) {
+      static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+      for (int sp : sps) {
+        if (sp > 1 && (nb >= 1536 || chunks / sp < 8 || nb * sp > 8192)) continue;
+        cand[nc++] = sp;
+      }
+    } else {
+      const int s0 = wgrad_splits(g, t[0], t[1]);
+      const int raw[5] = {s0 / 2, (s0 * 3) / 4, s0, (s0 * 3) / 2, s0 * 2};
+      for (int r : raw) {
+        const int sp = clamp_splits(r, chunks);
+        bool dup = false;
+        for (int j = 0; j < nc; ++j) dup |= cand[j] == sp;
+        if (!dup) cand[nc++] = sp;
+      }
+    }
+    for (int j = 0; j < nc && cnt < max_out; ++j) out[cnt++] = pack_cfg(t[0], t[1], cand[j], t[2]);
+  }
+  return cnt;
+}
+
+int32_t slv_conv_fwd_nblk(const int32_t* geom, int32_t cfg) {
+  Geom g;
+  Cfg c;
+  if (read_geom(geom, g) != 0 || fwd_cfg(g, cfg, c) != 0) return -1;
+  const long long P = (long long)g.Bn * g.To * g.Ho * g.Wo;
+  return (int32_t)((P + c.nt * 64 - 1) / (c.nt * 64));
+}
+
+size_t slv_conv_fwd_ws_bytes(const int32_t* geom, int32_t cfg) {
+  Geom g;
+  Cfg c;
+  if (read_geom(geom, g) != 0 || fwd_cfg(g, cfg, c) != 0) return 0;
+  const long long P = (long long)g.Bn * g.To * g.Ho * g.Wo;
+  return c.sp > 1 ? sizeof(float) * (size_t)c.sp * g.Cout * (size_t)P : 0;
+}
+
+int slv_conv_fwd(const int32_t* geom, const float* x, const float* w, const float* wf, const int32_t* tab,
+                 const float* in_scale_shift, int in_relu, float* y, float* stat_sum, float* stat_sq,
+                 void* ws, size_t ws_bytes, int32_t cfg, slv_stream_t stream) {
+  Geom g;
+  SLV_CHECK_ARG(read_geom(geom, g) == 0, "invalid geometry");
+  SLV_CHECK_ARG(x && tab && y, "null pointer");
+  Cfg c;
+  SLV_CHECK_ARG(fwd_cfg(g, cfg, c) == 0, "invalid launch configuration");
+  const Desc d = fwd_desc(g);
+  IgemmArgs a;
+  conv_args(a, g, d, tab);
+  if (d.kord == KORD_TAP) SLV_CHECK_ARG(wf, "this layer reads the tap-major weights: pass wf (slv_conv_w_transform)");
+  else SLV_CHECK_ARG(w, "null weight pointer");
+  a.A = d.kord == KORD_TAP ? wf : w; a.B = x; a.C = y;
+  a.pb = in_scale_shift; a.b_pro = in_scale_shift ? PRO_ACT : PRO_NONE; a.b_relu = in_relu;
+  a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+  const int mt = c.mt, nt = c.nt, sp = c.sp;
+  const size_t total = (size_t)g.Cout * (size_t)a.Ntot;
+  if (sp > 1) {
+    SLV_CHECK_ARG(ws && ws_bytes >= sizeof(float) * total * sp, "workspace too small (slv_conv_fwd_ws_bytes)");
+    a.C = (float*)ws; a.stat_sum = a.stat_sq = nullptr;
+    a.split_stride = (long long)total;
+    const int chunks = (a.Kd + 15) / 16;
+    a.chunks_per_split = (chunks + sp - 1) / sp;
+  }
+  SLV_CHECK_ARG((dispatch<MODE_CONV, SUB_FWD>(a, mt, nt, sp, (hipStream_t)stream, c.mf) == 0), "no kernel for tile");
+  SLV_LAUNCH_CHECK();
+  if (sp > 1) {
+    if (stat_sum) {
+      const int bn = nt * 64, nblkN = (int)((a.Ntot + bn - 1) / bn);
+      hipLaunchKernelGGL(conv_splitk_reduce_stats_kernel, dim3(nblkN, (g.Cout + 3) / 4), dim3(256), 0,
+                         (hipStream_t)stream, (const float*)ws, y, stat_sum, stat_sq, g.Cout, a.Ntot,
+                         g.To * g.Ho * g.Wo, bn, nblkN, total, sp);
+    } else {
+      hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)),
+                         dim3(256), 0, (hipStream_t)stream, (const float*)ws, (const float*)nullptr, y, total, sp);
+    }
+    SLV_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// LDS-tiled variant for <= 9 taps: a workgroup (16 x 16 threads) owns a 16 (co) x 16 (ci) tile = one channel
+// group of either target layout; reads are 16*taps-float runs, writes 64-byte runs; padding channels are
+// written as zeros (no memset); no integer divisions.
+__global__ __launch_bounds__(256) void w_transform_tiled_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                                               float* __restrict__ wt, int Cout, int Cin, int taps,
+                                                               const TapMap tm, int CpIn, int CpOut) {
+  __shared__ float t[16][16 * 9 + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 16;
+  const int row = 16 * taps;
+  {
+    const int co = co0 + ty;
+    const int cin_here = Cin - ci0 < 16 ? Cin - ci0 : 16;          // may be <= 0 in a pure padding tile
+    const int rlim = (co < Cout && cin_here > 0) ? cin_here * taps : 0;
+    const float* src = w + ((size_t)(co < Cout ? co : 0) * Cin + (ci0 < Cin ? ci0 : 0)) * taps;
+    for (int r = tx; r < row; r += 16) t[ty][r] = r < rlim ? src[r] : 0.f;
+  }
+  __syncthreads();
+  if (wf) {   // thread (tx = ci, ty = co)
+    const int co = co0 + ty, ci = ci0 + tx;
+    if (co < Cout && ci < CpIn) {
+      float* dst = wf + (size_t)co * taps * CpIn + (size_t)(ci0 >> 4) * taps * 16 + tx;
+      for (int tap = 0; tap < taps; ++tap) dst[tap * 16] = t[ty][tx * taps + tap];
+    }
+  }
+  if (wt) {   // thread (tx = co, ty = ci)
+    const int co = co0 + tx, ci = ci0 + ty;
+    const int colim = CpOut ? CpOut : Cout;
+    if (ci < Cin && co < colim) {
+      for (int tap = 0; tap < taps; ++tap) {
+        const int nt = tm.nt[tap];
+        if (nt == 0) continue;
+        const float v = t[tx][ty * taps + tap];
+        if (CpOut) wt[(size_t)tm.off[tap] + (size_t)ci * nt * CpOut + ((size_t)(co0 >> 4) * nt + tm.j[tap]) * 16 + tx] = v;
+        else wt[(size_t)tm.off[tap] + ((size_t)ci * Cout + co) * nt + tm.j[tap]] = v;
+      }
+    }
+  }
+}
+
+size_t slv_conv_wf_elems(const int32_t* geom) {
+  Geom g;
+  if (read_geom(geom, g) != 0) return 0;
+  const Desc d = fwd_desc(g);
+  return d.kord == KORD_TAP ? (size_t)d.M * d.Kd : 0;
+}
+
+size_t slv_conv_wt_elems(const int32_t* geom) {
+  Geom g;
+  if (read_geom(geom, g) != 0) return 0;
+  Desc ds[8];
+  const int n = dgrad_descs(g, ds);
+  size_t t = 0;
+  for (int i = 0; i < n; ++i) t += (size_t)g.Cin * ds[i].Kd;
+  return t > 0 ? t : 1;
+}
+
+int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf, float* wt, slv_stream_t stream) {
+  Geom g;
+  SLV_CHECK_ARG(read_geom(geom, g) == 0 && w && (wf || wt), "invalid geometry or null pointer");
+  const Desc df = fwd_desc(g);
+  if (df.kord != KORD_TAP) wf = nullptr;   // the forward conv of this layer reads w directly
+  Desc ds[8];
+  const int n = dgrad_descs(g, ds);
+  TapMap tm;
+  memset(&tm, 0, sizeof(tm));
+  const int taps = g.kt * g.kh * g.kw;
+  int cp_out = 0;
+  size_t wt_elems = 0;
+  for (int i = 0; i < n; ++i) {
+    wt_elems += (size_t)g.Cin * ds[i].Kd;
+    if (ds[i].kord == KORD_TAP) cp_out = ds[i].Cp;
+    for (int j = 0; j < ds[i].ntaps; ++j) {
+      const int t = ds[i].taps[j];
+      tm.off[t] = (int)ds[i].wt_off;
+      tm.nt[t] = ds[i].ntaps;
+      tm.j[t] = j;
+    }
+  }
+  // taps whose parity class has an empty lattice (input extent smaller than the stride) keep nt = 0:
+  // no input position ever sees them, the kernel skips them
+  hipStream_t st = (hipStream_t)stream;
+  if (taps <= 9) {
+    const int cin_ext = wf ? df.Cp : g.Cin, cout_ext = cp_out ? cp_out : g.Cout;
+    hipLaunchKernelGGL(w_transform_tiled_kernel, dim3((cin_ext + 15) / 16, (cout_ext + 15) / 16), dim3(256), 0, st, w,
+                       wf, wt, g.Cout, g.Cin, taps, tm, df.Cp, cp_out);
+    SLV_LAUNCH_CHECK();
+    return 0;
+  }
+  if (wf && df.Cp != g.Cin) SLV_HIP(hipMemsetAsync(wf, 0, sizeof(float) * (size_t)df.M * df.Kd, st));
+  if (wt && cp_out && cp_out != g.Cout) SLV_HIP(hipMemsetAsync(wt, 0, sizeof(float) * wt_elems, st));
+  const size_t nel = (size_t)g.Cout * g.Cin * taps;
+  hipLaunchKernelGGL(w_transform_kernel, dim3((unsigned)((nel + 255) / 256 < 4096 ? (nel + 255) / 256 : 4096)),
+                     dim3(256), 0, st, w, wf, wt, g.Cout, g.Cin, taps, tm, df.Cp, cp_out);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

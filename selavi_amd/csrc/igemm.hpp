@@ -754,7 +754,11 @@ __global__ __launch_bounds__(256, ((MF == 0 && MT >= 15) ? 2 : (MODE == MODE_WGR
   }
 }
 
-template <int MODE, int MT, int NT, int MF = 0>
+// SUBSET: which MODE_CONV variants a translation unit instantiates (the forward conv never uses the BNR epilogue,
+// the backward-data conv never has an operand prologue) -- keeps the per-file compile time down.
+enum { SUB_ALL = 0, SUB_FWD = 1, SUB_DGRAD = 2 };
+
+template <int MODE, int MT, int NT, int MF = 0, int SUBSET = SUB_ALL>
 inline void launch_igemm(const IgemmArgs& a, int splits, bool vec_a, hipStream_t st) {
   dim3 grid(a.nblkM * a.nblkN * splits, 1, 1);
   const bool act = (MODE != MODE_GEMM) && a.b_pro == PRO_ACT;
@@ -770,27 +774,36 @@ inline void launch_igemm(const IgemmArgs& a, int splits, bool vec_a, hipStream_t
       return;
     }
   }
-#define SLV_L(VA_, PRO_) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, VA_, PRO_, KORD_CHAN, EPI_PLAIN, MF>), grid, dim3(256), 0, st, a)
+#define SLV_K(VA_, PRO_, KORD_, EPI_) \
+  hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, VA_, PRO_, KORD_, EPI_, MF>), grid, dim3(256), 0, st, a)
   if constexpr (MODE == MODE_CONV) {
-    if (a.R) {  // backward-data with the fused BatchNorm-backward reduction (never has an operand prologue)
-      if (a.kord == KORD_TAP) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_TAP, EPI_BNR, MF>), grid, dim3(256), 0, st, a);
-      else if (vec_a) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_CHAN, EPI_BNR, MF>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, false, PRO_NONE, KORD_CHAN, EPI_BNR, MF>), grid, dim3(256), 0, st, a);
-      return;
+    if constexpr (SUBSET != SUB_FWD) {
+      if (a.R) {  // backward-data with the fused BatchNorm-backward reduction (never has an operand prologue)
+        if (a.kord == KORD_TAP) SLV_K(true, PRO_NONE, KORD_TAP, EPI_BNR);
+        else if (vec_a) SLV_K(true, PRO_NONE, KORD_CHAN, EPI_BNR);
+        else SLV_K(false, PRO_NONE, KORD_CHAN, EPI_BNR);
+        return;
+      }
     }
-    if (a.kord == KORD_TAP) {  // tap-major K: Kd is a multiple of 16 and A is 64-byte aligned -> always vector A loads
-      if (act) hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_ACT, KORD_TAP, EPI_PLAIN, MF>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((igemm_kernel<MODE, MT, NT, true, PRO_NONE, KORD_TAP, EPI_PLAIN, MF>), grid, dim3(256), 0, st, a);
-      return;
+    // tap-major K: Kd is a multiple of 16 and A is 64-byte aligned -> always vector A loads
+    if constexpr (SUBSET != SUB_DGRAD) {
+      if (act) {
+        if (a.kord == KORD_TAP) SLV_K(true, PRO_ACT, KORD_TAP, EPI_PLAIN);
+        else if (vec_a) SLV_K(true, PRO_ACT, KORD_CHAN, EPI_PLAIN);
+        else SLV_K(false, PRO_ACT, KORD_CHAN, EPI_PLAIN);
+        return;
+      }
     }
+    if (a.kord == KORD_TAP) SLV_K(true, PRO_NONE, KORD_TAP, EPI_PLAIN);
+    else if (vec_a) SLV_K(true, PRO_NONE, KORD_CHAN, EPI_PLAIN);
+    else SLV_K(false, PRO_NONE, KORD_CHAN, EPI_PLAIN);
+  } else if constexpr (MODE == MODE_GEMM) {
+    if (vec_a) SLV_K(true, PRO_NONE, KORD_CHAN, EPI_PLAIN); else SLV_K(false, PRO_NONE, KORD_CHAN, EPI_PLAIN);
+  } else {   // MODE_WGRAD without the 16-byte gathered-operand path
+    if (vec_a) { if (act) SLV_K(true, PRO_ACT, KORD_CHAN, EPI_PLAIN); else SLV_K(true, PRO_NONE, KORD_CHAN, EPI_PLAIN); }
+    else { if (act) SLV_K(false, PRO_ACT, KORD_CHAN, EPI_PLAIN); else SLV_K(false, PRO_NONE, KORD_CHAN, EPI_PLAIN); }
   }
-  if constexpr (MODE == MODE_GEMM) {
-    if (vec_a) SLV_L(true, PRO_NONE); else SLV_L(false, PRO_NONE);
-  } else {
-    if (vec_a) { if (act) SLV_L(true, PRO_ACT); else SLV_L(true, PRO_NONE); }
-    else { if (act) SLV_L(false, PRO_ACT); else SLV_L(false, PRO_NONE); }
-  }
-#undef SLV_L
+#undef SLV_K
 }
 
 // choose the row-tile: returns MT for a given M (rows) -- see header comment
