@@ -1,7 +1,7 @@
 """Run-to-run determinism of the training step (GPU): N repetitions of {2 steps from the same state}
-must give bit-identical parameters and losses.  Usage: python tools/determinism_check.py [reps] [B T S]"""
+must give bit-identical parameters and losses.  Usage: python tests/diag/determinism_check.py [reps] [B T S]"""
 import os, sys, hashlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from oracle.model_ref import portable_fill_, portable_init_

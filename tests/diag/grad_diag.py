@@ -1,7 +1,7 @@
 """Diagnostic: per-parameter gradient error of the HIP engine vs an fp64 CPU oracle, next to the
 fp32 CPU oracle's own error (noise floor)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import model_ref, step_ref
 from oracle.model_ref import portable_fill_, portable_init_

@@ -1,8 +1,8 @@
 """Diagnostic (GPU): per-parameter gradient error of the HIP engine against the committed fp64 golden
 gradients of the executed reference (tests/golden/grads_hc1_k28.npz), next to the reference's own
-fp32-vs-fp64 deviation e_cpu.  Needs no oracle run.  Usage: python tools/grad_vs_golden.py [top]"""
+fp32-vs-fp64 deviation e_cpu.  Needs no oracle run.  Usage: python tests/diag/grad_vs_golden.py [top]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from oracle.model_ref import portable_fill_, portable_init_
