@@ -245,6 +245,26 @@ int slv_heads_sum_groups(const float* src /* [2*hc][n] */, float* out /* [2][n] 
 int slv_rowwise_affine(const float* x, const float* scale_shift, int relu, float* y, int64_t rows, int C,
                        slv_stream_t stream);
 
+/* ---- input pipeline: what the reference's DataLoader workers compute per clip on the CPU -------
+ * slv_clip_augment replaces datasets/video_transforms.py:462-510 (clip_augmentation: /255, -mean, /std, THWC->TCHW,
+ *   spatial_sampling :420-459 = bilinear short-side resize :35-80 + crop :101-134/:167-210 + flip :137-164, ->CTHW)
+ *   for a batch of B clips in one launch.  desc: B x 8 int64 on the device per clip = {byte offset of the clip's
+ *   T*H*W*3 uint8 frames inside frames_u8, H, W, resized H, resized W, crop y offset, crop x offset, flip}; the
+ *   random draws stay on the host (selavi_amd/datasets/video_transforms.py makes them in the reference's order).
+ *   out: [B][3][T][S][S] float32.  mean3/std3: host pointers.
+ * slv_logfbank replaces datasets/audio_utils.py:46-72 (python_speech_features.logfbank 0.6 with winfunc = ones,
+ *   lowfreq 0, highfreq samplerate/2) for B clips: wav_i16 [B][wav_stride] int16 PCM, start_i64[b] first sample of
+ *   the clip's window, volume_f64 nullable per-clip factor (audio_utils.py:42-43), slen samples per window;
+ *   twiddle_f64 = cos(2 pi j / nfft), j < nfft, then sin(...) (device, float64); bins_i32 = the nfilt + 2 filterbank
+ *   bin edges floor((nfft+1) * mel2hz(linspace) / samplerate) (device).  out_f32: [B][1][nfilt][frames] with
+ *   frames = slv_logfbank_frames(slen, frame_len, frame_step); z_normalize applies (x - 1.93) / 17.89 (:71-72). */
+int slv_clip_augment(const void* frames_u8, const int64_t* desc, float* out, int B, int T, int S,
+                     const float* mean3, const float* std3, slv_stream_t stream);
+int32_t slv_logfbank_frames(int slen, int frame_len, int frame_step);   /* sigproc.framesig frame count; -1 on bad sizes */
+int slv_logfbank(const void* wav_i16, const int64_t* start_i64, const double* volume_f64, int64_t wav_stride, int B,
+                 int slen, int frame_len, int frame_step, int nfft, int nfilt, const double* twiddle_f64,
+                 const int32_t* bins_i32, double preemph, int z_normalize, float* out_f32, slv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
