@@ -245,6 +245,15 @@ int slv_heads_sum_groups(const float* src /* [2*hc][n] */, float* out /* [2][n] 
 int slv_rowwise_affine(const float* x, const float* scale_shift, int relu, float* y, int64_t rows, int C,
                        slv_stream_t stream);
 
+/* ---- evaluation dumps (clustering_metrics.py:95-175) -----------------------------------------------------------
+ * slv_av_argmax: labels[i] = argmax_k softmax64(lv[i])_k * softmax64(la[i])_k (:121-126 / :140-144), first index
+ *   on ties -- the same arithmetic as slv_sk_prepare without materialising the N x K matrix.
+ * slv_contingency: counts[a][b] = #{i : pred[i] == a and target[i] == b} (the K x K vote table _hungarian_match
+ *   :41-56 builds with K*K masked sums); *bad is set to 1 if any index is out of range. */
+int slv_av_argmax(const float* lv, const float* la, int64_t N, int K, int64_t* labels, slv_stream_t stream);
+int slv_contingency(const int64_t* pred, const int64_t* target, int64_t N, int K1, int K2, int64_t* counts,
+                    int32_t* bad, slv_stream_t stream);
+
 /* ---- input pipeline: what the reference's DataLoader workers compute per clip on the CPU -------
  * slv_clip_augment replaces datasets/video_transforms.py:462-510 (clip_augmentation: /255, -mean, /std, THWC->TCHW,
  *   spatial_sampling :420-459 = bilinear short-side resize :35-80 + crop :101-134/:167-210 + flip :137-164, ->CTHW)

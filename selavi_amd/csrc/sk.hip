@@ -71,7 +71,8 @@ template <int KJ, bool TWO>
 __global__ __launch_bounds__(SK_THREADS) void sk_prepare_kernel(const float* __restrict__ lv,
                                                                const float* __restrict__ la,
                                                                double* __restrict__ P, int64_t N,
-                                                               int K, double power, int do_pow) {
+                                                               int K, double power, int do_pow,
+                                                               int64_t* __restrict__ labels = nullptr) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * SK_WAVES + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * SK_WAVES;
@@ -103,6 +104,8 @@ __global__ __launch_bounds__(SK_THREADS) void sk_prepare_kernel(const float* __r
     }
     sv = wave_sum(sv);
     if (TWO) sa = wave_sum(sa);
+    double best = 0.0;
+    int bi = 0x7fffffff;
 #pragma unroll
     for (int j = 0; j < KJ; ++j) {
       const int k = lane + 64 * j;
@@ -110,9 +113,43 @@ __global__ __launch_bounds__(SK_THREADS) void sk_prepare_kernel(const float* __r
         double p = xv[j] / sv;
         if (TWO) p = p * (xa[j] / sa);
         if (do_pow) p = pow(p, power);
-        P[i * K + k] = p;
+        if (P) P[i * K + k] = p;
+        if (bi == 0x7fffffff || beats(p, k, best, bi)) {
+          best = p;
+          bi = k;
+        }
       }
     }
+    if (labels) {                            // clustering_metrics.py:121-126: PS_av.argmax(1)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || beats(ov, oi, best, bi))) {
+          best = ov;
+          bi = oi;
+        }
+      }
+      if (lane == 0) labels[i] = bi;
+    }
+  }
+}
+
+// counts[pred[i]][target[i]] += 1 (clustering_metrics.py:41-56 builds this with K*K masked sums over N).
+// Integer atomics commute, so the result does not depend on the schedule.
+__global__ __launch_bounds__(256) void contingency_kernel(const int64_t* __restrict__ pred,
+                                                          const int64_t* __restrict__ target, int64_t N, int K1,
+                                                          int K2, unsigned long long* __restrict__ counts,
+                                                          int* __restrict__ bad) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < N; i += stride) {
+    const int64_t a = pred[i], b = target[i];
+    if (a < 0 || a >= K1 || b < 0 || b >= K2) {
+      *bad = 1;
+      continue;
+    }
+    atomicAdd(&counts[a * K2 + b], 1ull);
   }
 }
 
@@ -500,6 +537,29 @@ int slv_sk_prepare(const float* lv, const float* la, double* P, int64_t N, int K
   const int grid = (int)((N + SK_WAVES - 1) / SK_WAVES < 4096 ? (N + SK_WAVES - 1) / SK_WAVES : 4096);
   SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_prepare_kernel<KJ, true>), dim3(grid), dim3(SK_THREADS), 0,
                                         (hipStream_t)stream, lv, la, P, N, K, power, power != 1.0));
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_av_argmax(const float* lv, const float* la, int64_t N, int K, int64_t* labels, slv_stream_t stream) {
+  SLV_CHECK_ARG(lv && la && labels && N >= 0 && K > 0, "null pointer or empty shape");
+  if (N == 0) return 0;
+  const int grid = (int)((N + SK_WAVES - 1) / SK_WAVES < 4096 ? (N + SK_WAVES - 1) / SK_WAVES : 4096);
+  SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_prepare_kernel<KJ, true>), dim3(grid), dim3(SK_THREADS), 0,
+                                        (hipStream_t)stream, lv, la, (double*)nullptr, N, K, 1.0, 0, labels));
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_contingency(const int64_t* pred, const int64_t* target, int64_t N, int K1, int K2, int64_t* counts,
+                    int32_t* bad, slv_stream_t stream) {
+  SLV_CHECK_ARG(pred && target && counts && bad && N >= 0 && K1 > 0 && K2 > 0, "null pointer or empty shape");
+  SLV_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)K1 * K2, (hipStream_t)stream));
+  SLV_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), (hipStream_t)stream));
+  if (N == 0) return 0;
+  const int grid = (int)((N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048);
+  hipLaunchKernelGGL(contingency_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, target, N, K1, K2,
+                     (unsigned long long*)counts, (int*)bad);
   SLV_LAUNCH_CHECK();
   return 0;
 }
