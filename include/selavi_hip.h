@@ -207,6 +207,8 @@ int slv_maxpool_bwd(const float* dout, const uint8_t* idx, float* dy, int Bn, in
 int slv_sgd_step(const void* const* params, const void* const* grads, const void* const* bufs,
                  const int64_t* sizes, int n_tensors, float lr, float momentum, float weight_decay,
                  int first_step, slv_stream_t stream);
+/* out[i] = sum_s src[s][i], s ascending (weight gradients of batch slices, see ops.ConvPlan chunks) */
+int slv_sum_slices(const float* src, float* out, int slices, int64_t n, slv_stream_t stream);
 int slv_fill_f32(float* p, float value, int64_t n, slv_stream_t stream);
 
 /* ---------------------------------------------------------------- grouped heads + loss ---------

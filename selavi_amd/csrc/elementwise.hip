@@ -457,6 +457,18 @@ __global__ __launch_bounds__(256) void sgd_kernel(const SgdTable t, float lr, fl
   }
 }
 
+// out[i] = src[0][i] + src[1][i] + ... (fixed order): weight gradients of a batch that was convolved in slices
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ src, float* __restrict__ out,
+                                                         int slices, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n; i += stride) {
+    float v = src[i];
+    for (int s = 1; s < slices; ++s) v += src[(size_t)s * n + i];
+    out[i] = v;
+  }
+}
+
 __global__ void fill_kernel(float* __restrict__ p, float v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -695,6 +707,15 @@ int slv_sgd_step(const void* const* params, const void* const* grads, const void
                        first_step);
     SLV_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+int slv_sum_slices(const float* src, float* out, int slices, int64_t n, slv_stream_t stream) {
+  SLV_CHECK_ARG(src && out && slices > 0 && n >= 0, "bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sum_slices_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, src, out, slices,
+                     (size_t)n);
+  SLV_LAUNCH_CHECK();
   return 0;
 }
 

@@ -13,6 +13,12 @@ def _f32(*shape, device):
     return torch.empty(*shape, dtype=torch.float32, device=device)
 
 
+# The kernels address a tensor through one buffer descriptor with 32-bit byte offsets (csrc/conv_common.hpp:read_geom):
+# a conv whose input or output exceeds this many bytes is run in batch slices (ConvPlan.chunks).  BASELINE configs[4]
+# (128 clips x 32 frames per GPU: 7.4 GB layer-1 tensors) needs it; tests lower it to exercise the path on small tensors.
+CONV_BUF_LIMIT = int(os.environ.get("SELAVI_CONV_BUF_LIMIT", str(0xFFFFFFF0)))
+
+
 class ConvPlan:
     """Geometry + device tables of one convolution layer for a given input shape.
 
@@ -30,10 +36,31 @@ class ConvPlan:
         self.in_shape = (Bn, Cin, Ti, Hi, Wi)
         self.out_shape = (Bn, Cout, To, Ho, Wo)
         self.Cin, self.Cout, self.taps = Cin, Cout, kt * kh * kw
+        self.device = device
+        self.count = float(Bn * To * Ho * Wo)          # elements per channel of the output
+        self.P_out = To * Ho * Wo
+        self.P_in = Ti * Hi * Wi
+        self.chunks = None
+        per_clip = 4 * max(Cin * Ti * Hi * Wi, Cout * To * Ho * Wo)
+        if per_clip >= CONV_BUF_LIMIT:
+            raise ValueError(f"one clip of {per_clip} bytes exceeds the conv buffer limit {CONV_BUF_LIMIT}")
+        n_slices = -(-Bn // ((CONV_BUF_LIMIT - 1) // per_clip))
+        if n_slices > 1:                               # batch slices, each a plan of its own (clips are independent)
+            base, rem = divmod(Bn, n_slices)
+            self.chunks, b0 = [], 0
+            for i in range(n_slices):
+                sz = base + (1 if i < rem else 0)
+                self.chunks.append((b0, b0 + sz, ConvPlan.get((sz, Cin, Ti, Hi, Wi), Cout, k, stride, pad, device)))
+                b0 += sz
+            first = self.chunks[0][2]
+            self.gp, self.geom = first.gp, first.geom  # weight layouts do not depend on the batch size
+            self.wf_elems, self.wt_elems = first.wf_elems, first.wt_elems
+            self.nblk = sum(c[2].nblk for c in self.chunks)
+            self.cfg_fwd = self.cfg_dgrad = self.cfg_wgrad = 0
+            return
         self.geom = np.array([Bn, Cin, Ti, Hi, Wi, Cout, To, Ho, Wo, kt, kh, kw, st, sh, sw, pt, ph, pw],
                              dtype=np.int32)
         self.gp = self.geom.ctypes.data
-        self.device = device
         tf = np.empty(C.slv_conv_table_len(self.gp, 0), dtype=np.int32)
         C.slv_conv_table(self.gp, 0, tf.ctypes.data)
         td = np.empty(C.slv_conv_table_len(self.gp, 1), dtype=np.int32)
@@ -42,9 +69,6 @@ class ConvPlan:
         self.tab_dgrad = torch.from_numpy(td).to(device)
         self.wf_elems = C.slv_conv_wf_elems(self.gp)   # > 0: the forward conv reads tap-major weights
         self.wt_elems = C.slv_conv_wt_elems(self.gp)
-        self.count = float(Bn * To * Ho * Wo)          # elements per channel of the output
-        self.P_out = To * Ho * Wo
-        self.P_in = Ti * Hi * Wi
         self.set_configs(0, 0, 0)
         if benchmark:
             key = ",".join(str(int(v)) for v in self.geom)
@@ -58,6 +82,8 @@ class ConvPlan:
 
     def set_configs(self, cfg_fwd, cfg_dgrad, cfg_wgrad):
         """Launch configurations (0 = built-in heuristic) and the scratch sizes that follow from them."""
+        if self.chunks is not None:
+            raise ValueError("a sliced plan has no launch configuration of its own: configure its slices")
         self.cfg_fwd, self.cfg_dgrad, self.cfg_wgrad = int(cfg_fwd), int(cfg_dgrad), int(cfg_wgrad)
         self.nblk = C.slv_conv_fwd_nblk(self.gp, self.cfg_fwd)
         if self.nblk <= 0:
@@ -68,6 +94,8 @@ class ConvPlan:
         self.ws_bytes = C.slv_conv_wgrad_ws_bytes(self.gp, self.cfg_wgrad)
 
     def candidates(self, op):
+        if self.chunks is not None:
+            return []
         buf = np.empty(128, dtype=np.int32)
         n = C.slv_conv_configs(self.gp, op, buf.ctypes.data, buf.size)
         return [int(v) for v in buf[:n]]
@@ -188,12 +216,20 @@ def workspace(nbytes, device):
     return t
 
 
-def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True, wf=None):
+def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True, wf=None, out=None):
     """y = conv(relu?(x*s+h)); returns (y, stat_sum, stat_sq) with stats [Cout][nblk] partials.
     wf: tap-major forward weights from conv_w_transform (made on the fly when the layer needs them)."""
     if plan.wf_elems and wf is None:
         wf, _ = conv_w_transform(plan, w, need_wt=False)
-    y = _f32(*plan.out_shape, device=x.device)
+    if plan.chunks is not None:
+        y = _f32(*plan.out_shape, device=x.device)
+        parts = []
+        for b0, b1, sub in plan.chunks:
+            parts.append(conv_fwd(sub, x[b0:b1], w, in_ss, in_relu, want_stats, wf, out=y[b0:b1]))
+        if not want_stats:
+            return y, None, None
+        return y, torch.cat([p_[1] for p_ in parts], 1), torch.cat([p_[2] for p_ in parts], 1)   # [Cout][sum nblk]
+    y = out if out is not None else _f32(*plan.out_shape, device=x.device)
     ssum = ssq = None
     if want_stats:
         ssum = _f32(plan.Cout, plan.nblk, device=x.device)
@@ -224,6 +260,13 @@ def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out
     dx = out if out is not None else _f32(*plan.in_shape, device=dy.device)
     if bwd5 is not None:     # BN backward of the conv's own output: materialised, then a plain dgrad
         dy = bn_bwd_apply(dy, x_out, bwd5, relu, out=torch.empty_like(dy))
+    if plan.chunks is not None:
+        parts = []
+        for b0, b1, sub in plan.chunks:
+            r = conv_dgrad(sub, dy[b0:b1], wt, addend=None if addend is None else addend[b0:b1], out=dx[b0:b1],
+                           bnr=None if bnr is None else (bnr[0][b0:b1], bnr[1], bnr[2]))
+            parts.append(r[1] if bnr is not None else None)
+        return dx if bnr is None else (dx, torch.cat(parts, 1))                    # [Cin][sum slots][2]
     ws = workspace(plan.ws_dgrad, dy.device) if plan.ws_dgrad else None
     part = rx = rss = rmi = None
     if bnr is not None:
@@ -236,9 +279,16 @@ def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out
 
 def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, in_relu=False, out=None):
     dw = out if out is not None else _f32(plan.Cout, plan.Cin * plan.taps, device=dy.device)
-    ws = workspace(plan.ws_bytes, dy.device) if plan.ws_bytes else None
     if bwd5 is not None:
         dy = bn_bwd_apply(dy, x_out, bwd5, a_relu, out=torch.empty_like(dy))
+    if plan.chunks is not None:
+        n = len(plan.chunks)
+        slices = _f32(n, plan.Cout, plan.Cin * plan.taps, device=dy.device)
+        for i, (b0, b1, sub) in enumerate(plan.chunks):
+            conv_wgrad(sub, dy[b0:b1], x_in[b0:b1], in_ss=in_ss, in_relu=in_relu, out=slices[i])
+        C.slv_sum_slices(ptr(slices), ptr(dw), n, dw.numel(), stream())
+        return dw
+    ws = workspace(plan.ws_bytes, dy.device) if plan.ws_bytes else None
     C.slv_conv_wgrad(plan.gp, ptr(dy), ptr(x_in), ptr(in_ss), int(in_relu), ptr(plan.tab_fwd), ptr(dw),
                      ptr(ws), plan.ws_bytes, plan.cfg_wgrad, stream())
     return dw

@@ -432,3 +432,36 @@ def test_full_size_gradients_within_reference_noise(golden_dir):
     loss.backward()
     np.testing.assert_allclose(loss.item(), float(g["loss64"]), rtol=1e-5)
     _check_all_grads(m, golden_dir, "grads_cfg2_full.npz")
+
+
+@pytest.mark.gpu
+def test_training_step_with_batch_sliced_convs(monkeypatch):
+    """The whole step with every large conv forced into batch slices (the path BASELINE configs[4]'s 128 x 32-frame
+    per-GPU batch takes) against the same step unsliced: logits to 1e-4, loss to 1e-5, the update stays finite and close."""
+    from selavi_amd import model as smodel, ops, optim, train
+
+    def run(limit):
+        monkeypatch.setattr(ops, "CONV_BUF_LIMIT", limit)
+        monkeypatch.setattr(ops.ConvPlan, "_cache", {})
+        torch.manual_seed(5)
+        m = smodel.load_model(vid_base_arch="r2plus1d_18", aud_base_arch="resnet9", use_mlp=True, num_classes=12,
+                              pretrained=False, norm_feat=False, use_max_pool=False, headcount=2).cuda()
+        opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        video = torch.randn(6, 3, 8, 48, 48, device="cuda", generator=g)
+        audio = torch.randn(6, 1, 40, 60, device="cuda", generator=g)
+        labels = torch.randint(0, 12, (64, 2), device="cuda", generator=g)
+        sel = torch.arange(6, device="cuda")
+        m.train()
+        fv, fa = m(video, audio)
+        logits = torch.stack(fv + fa).detach().clone()
+        loss = train.train_step(m, opt, video, audio, labels, sel, 2)
+        sliced = sum(p.chunks is not None for p in ops.ConvPlan._cache.values())
+        return logits, float(loss), torch.cat([p.detach().flatten() for p in m.parameters()]), sliced
+
+    l0, loss0, w0, n0 = run(0xFFFFFFF0)
+    l1, loss1, w1, n1 = run(3 * 1024 * 1024)                       # layer-1 tensors are 5-13 MB here: 2-5 slices
+    assert n0 == 0 and n1 >= 8
+    assert (l0 - l1).abs().max().item() <= 1e-4 * max(1.0, l0.abs().max().item())
+    assert abs(loss0 - loss1) <= 1e-5 * max(1.0, abs(loss0))
+    assert torch.isfinite(w1).all() and (w0 - w1).norm().item() <= 1e-3 * w0.norm().item()

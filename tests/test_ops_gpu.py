@@ -334,3 +334,45 @@ def test_full_size_adjoint_identities(name, geo, tuned):
     y2, _, _ = ops.conv_fwd(plan, x2, w, wf=wf, want_stats=False)
     err = float(((y12.double() - (y.double() + 2 * y2.double())).norm()) / y12.double().norm())
     assert err <= 2e-6, err
+
+
+@pytest.mark.parametrize("geo", [(7, 20, 4, 12, 12, 24, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+                                 (5, 16, 6, 10, 10, 40, (3, 1, 1), (2, 1, 1), (1, 0, 0)),
+                                 (6, 8, 4, 12, 12, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0))])
+def test_batch_sliced_conv_equals_unsliced(geo, monkeypatch):
+    """Tensors beyond the 32-bit buffer range (BASELINE configs[4]: 128 clips x 32 frames per GPU) are convolved
+    in batch slices (ops.ConvPlan.chunks).  Forced here on small tensors: clips are independent, so the forward and
+    the data gradient are bit-identical to the unsliced launch; the statistics and the weight gradient differ only
+    in summation order."""
+    from selavi_amd import ops
+    Bn, Cin, T, H, W, Cout, k, st, pd = geo
+    dev = torch.device("cuda")
+    x, w = _mk((Bn, Cin, T, H, W), 21).to(dev), _mk((Cout, Cin) + k, 22, scale=0.1).to(dev)
+    ss = torch.stack([_mk((Cin,), 23).abs() + 0.5, _mk((Cin,), 24) * 0.3]).to(dev).contiguous()
+    mi = torch.stack([_mk((Cin,), 25) * 0.2, _mk((Cin,), 26).abs() + 0.5]).to(dev).contiguous()
+    whole = ops.ConvPlan(Bn, Cin, T, H, W, Cout, k, st, pd, dev)
+    assert whole.chunks is None
+    per_clip = 4 * max(x[0].numel(), whole.out_shape[1] * whole.P_out)
+    monkeypatch.setattr(ops, "CONV_BUF_LIMIT", 2 * per_clip + 64)             # at most two clips per slice
+    sliced = ops.ConvPlan(Bn, Cin, T, H, W, Cout, k, st, pd, dev)
+    assert sliced.chunks is not None and len(sliced.chunks) == -(-Bn // 2)
+    assert [c[1] - c[0] for c in sliced.chunks] == sorted([c[1] - c[0] for c in sliced.chunks], reverse=True)
+    dy, add, xp = _mk(whole.out_shape, 27).to(dev), _mk(tuple(x.shape), 28).to(dev), _mk(tuple(x.shape), 29).to(dev)
+    wf, wt = ops.conv_w_transform(whole, w)
+    y0, s0, q0 = ops.conv_fwd(whole, x, w, in_ss=ss, in_relu=True, wf=wf)
+    y1, s1, q1 = ops.conv_fwd(sliced, x, w, in_ss=ss, in_relu=True, wf=wf)
+    assert torch.equal(y0, y1) and s1.shape[0] == Cout
+    _close(s1.double().sum(1), s0.double().sum(1).cpu(), rtol=1e-5)
+    _close(q1.double().sum(1), q0.double().sum(1).cpu(), rtol=1e-6)
+    (d0, p0), (d1, p1) = (ops.conv_dgrad(pl, dy, wt, addend=add, bnr=(xp, ss, mi)) for pl in (whole, sliced))
+    assert torch.equal(d0, d1)
+    _close(p1.double().sum(1), p0.double().sum(1).cpu(), rtol=1e-5)
+    assert torch.equal(ops.conv_dgrad(sliced, dy, wt), ops.conv_dgrad(whole, dy, wt))
+    g0 = ops.conv_wgrad(whole, dy, x, in_ss=ss, in_relu=True)
+    g1 = ops.conv_wgrad(sliced, dy, x, in_ss=ss, in_relu=True)
+    _close_l2(g1, g0.double().cpu(), rtol=2e-6)
+    with pytest.raises(ValueError):
+        sliced.set_configs(0, 0, 0)
+    monkeypatch.setattr(ops, "CONV_BUF_LIMIT", per_clip // 2)
+    with pytest.raises(ValueError):
+        ops.ConvPlan(Bn, Cin, T, H, W, Cout, k, st, pd, dev)
