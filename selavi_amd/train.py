@@ -26,3 +26,23 @@ def sk_schedule(epochs, n_batches, nopts=100, schedulepower=1.5):
     """main.py:168-170 (popped from the end: first SK at iteration 0)."""
     sched = (epochs * n_batches * (np.linspace(0, 1, nopts) ** schedulepower)[::-1]).tolist()
     return [(epochs + 2) * n_batches] + sched
+
+
+def wrap_ddp(model, device_ids, **kw):
+    """DistributedDataParallel (main.py:156-160) with the settings this model allows -- measured on one MI355X with
+    every collective going through RCCL on a world of one rank (tools/dist_overhead.py): default DDP costs 4.8 ms on
+    the 44.8 ms SyncBN step, this configuration 2.2 ms.
+
+    * broadcast_buffers=False: the default re-broadcasts ~200 BatchNorm buffers before every forward.  Under SyncBN
+      every rank finalises the same all-reduced sums with the same kernel, so the running statistics are
+      bit-identical on all ranks by construction (tests/test_cluster_gpu.py asserts it) -- nothing to broadcast.
+    * gradient_as_bucket_view=True: .grad tensors live inside the all-reduce buckets (no grad <-> bucket copies).
+
+    static_graph=True would save another 1.8 ms but is NOT used: in the two-rank test the ranks' conv weights then
+    diverge from the first step on (DDP's first-iteration bookkeeping leaves those gradients un-reduced;
+    tests/diag/ddp_lockstep.py bisects the options).
+    """
+    import torch
+    opts = dict(broadcast_buffers=False, gradient_as_bucket_view=True)
+    opts.update(kw)
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, **opts)

@@ -89,7 +89,7 @@ def test_cluster_round_matches_oracle_reenactment(hc, K):
         assert agree == 1.0, f"head {h}: {agree:.3f} agreement with the oracle"
 
 
-def _ddp_worker(rank, world, port, ret):
+def _ddp_worker(rank, world, port, ret, wrap=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -101,13 +101,25 @@ def _ddp_worker(rank, world, port, ret):
         portable_init_(m, seed=31)
         step_ref.set_dropout_p(m, 0.0)
         m = m.cuda().train()
-        net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)
+        if wrap:
+            net = train.wrap_ddp(m, [0])
+        else:
+            net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)
         opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
         video = portable_fill_(torch.empty(4, 3, 4, 32, 32), 5)[rank * 2:(rank + 1) * 2].cuda()
         audio = portable_fill_(torch.empty(4, 1, 40, 36), 6)[rank * 2:(rank + 1) * 2].cuda()
         sl = torch.from_numpy((np.arange(64 * hc).reshape(64, hc) * 7919 % K).astype(np.int64)).cuda()
         sel = torch.tensor([3, 17, 42, 63])[rank * 2:(rank + 1) * 2].cuda()
         loss = train.train_step(net, opt, video, audio, sl, sel, hc)
+        if wrap:      # several steps (DDP rebuilds its buckets after the first), then hash the whole state
+            first = float(loss)
+            for _ in range(2):
+                loss = train.train_step(net, opt, video, audio, sl, sel, hc)
+            import hashlib
+            hs = {k: hashlib.sha256(v.detach().cpu().numpy().tobytes()).hexdigest()[:16]
+                  for k, v in sorted(m.state_dict().items())}
+            ret[rank] = (first, float(loss), hs)
+            return
         sd = m.state_dict()
         ret[rank] = (float(loss), {k: sd[k].flatten()[:32].cpu().numpy().copy() for k in (
             "video_network.base.layer2.0.conv1.0.0.weight", "video_network.base.stem.1.running_var",
@@ -143,3 +155,61 @@ def test_two_rank_ddp_syncbn_equals_single_process_large_batch():
     for k in w0:
         np.testing.assert_array_equal(w0[k], w1[k])             # ranks stay in lock-step
         np.testing.assert_allclose(w0[k], sd[k].flatten()[:32].cpu().numpy(), rtol=5e-3, atol=2e-4)
+
+
+def test_two_rank_wrap_ddp_keeps_parameters_and_buffers_bit_identical():
+    """train.wrap_ddp (no buffer broadcast, gradients as bucket views): after three steps every parameter AND every
+    BatchNorm buffer is bit-identical on both ranks (SyncBN finalises the same all-reduced sums everywhere), and the
+    first step's loss equals the reference-style DDP's."""
+    import torch.multiprocessing as mp
+    ret, ret_ref = mp.Manager().dict(), mp.Manager().dict()
+    mp.spawn(_ddp_worker, args=(2, 29100 + os.getpid() % 200, ret, True), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, 29500 + os.getpid() % 200, ret_ref), nprocs=2, join=True)
+    diverged = [k for k in ret[0][2] if ret[0][2][k] != ret[1][2][k]]
+    assert not diverged, f"{len(diverged)} of {len(ret[0][2])} tensors differ between the ranks: {diverged[:8]}"
+    assert np.isfinite([ret[0][1], ret[1][1]]).all()
+    for r in (0, 1):
+        assert abs(ret[r][0] - ret_ref[r][0]) <= 1e-6 * abs(ret_ref[r][0])
+
+
+def _nccl_worker(rank, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from selavi_amd import model as smodel, optim, train
+        hc, K = 2, 7
+        out = []
+        for distributed in (False, True):
+            m = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
+            portable_init_(m, seed=31)
+            step_ref.set_dropout_p(m, 0.0)
+            m = m.cuda().train()
+            net = m
+            if distributed:       # SyncBN all-reduces + DDP buckets go through RCCL (streams, events, side streams)
+                m.set_sync_bn(True)
+                net = train.wrap_ddp(m, [0])
+            opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+            video = portable_fill_(torch.empty(4, 3, 4, 32, 32), 5).cuda()
+            audio = portable_fill_(torch.empty(4, 1, 40, 36), 6).cuda()
+            sl = torch.from_numpy((np.arange(64 * hc).reshape(64, hc) * 7919 % K).astype(np.int64)).cuda()
+            sel = torch.tensor([3, 17, 42, 63]).cuda()
+            losses = [float(train.train_step(net, opt, video, audio, sl, sel, hc)) for _ in range(3)]
+            out.append((losses, torch.cat([p.detach().flatten() for p in m.parameters()]).cpu().numpy()))
+        ret["plain"], ret["rccl"] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_syncbn_ddp_world1_equals_plain_step():
+    """The RCCL code path (SyncBN all-reduces issued from the trunk / weight-gradient side streams and autograd's
+    thread, DDP gradient buckets) on a world of one rank: sums over one rank are the identity, so three steps must
+    reproduce the non-distributed run -- a stream-ordering bug around the collectives would show up here."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_nccl_worker, args=(29900 + os.getpid() % 90, ret), nprocs=1, join=True)
+    (l0, w0), (l1, w1) = ret["plain"], ret["rccl"]
+    assert np.isfinite(l1).all() and np.isfinite(w1).all()
+    np.testing.assert_allclose(l1, l0, rtol=2e-5)
+    assert np.linalg.norm(w1 - w0) <= 1e-4 * np.linalg.norm(w0)
