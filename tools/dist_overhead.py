@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--modes", default="", help="comma-separated subset of the modes")
     a = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29777")
@@ -39,8 +40,11 @@ def main():
               "ddp-nobcast-view": dict(broadcast_buffers=False, gradient_as_bucket_view=True),
               "ddp-nobcast-view-100MB": dict(broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=100),
               "ddp-nobcast-view-static": dict(broadcast_buffers=False, gradient_as_bucket_view=True, static_graph=True)}
-    for mode in ("plain", "syncbn", "syncbn+ddp", "syncbn+ddp-nobcast", "syncbn+ddp-nobcast-view",
-                 "syncbn+ddp-nobcast-view-100MB", "syncbn+ddp-nobcast-view-static", "plain"):
+    modes = ("plain", "syncbn", "syncbn+ddp", "syncbn+ddp-nobcast", "syncbn+ddp-nobcast-view",
+             "syncbn+ddp-nobcast-view-100MB", "syncbn+ddp-nobcast-view-static", "plain")
+    if a.modes:
+        modes = tuple(a.modes.split(","))
+    for mode in modes:
         torch.manual_seed(31)
         m = smodel.load_model(vid_base_arch="r2plus1d_18", aud_base_arch="resnet9", use_mlp=True, num_classes=K,
                               pretrained=False, norm_feat=False, use_max_pool=False, headcount=hc).to(dev).train()
