@@ -170,18 +170,18 @@ def cfg1_fixture(ref_model, ref_utils):
     print("cfg1 full-size fixture: loss", loss.item())
 
 
-def cfg2_fixture(ref_model, ref_utils):
+def cfg2_fixture(ref_model, ref_utils, hc=10, K=309, B=16, T=16, fname="cfg2_full.npz"):
     """BASELINE configs[1] at FULL size (the configuration the metric is quoted on): bs=16, 16x112x112
     clips, 1x129x100 log-mel, K=309, headcount=10.  Train-mode (batch statistics) trunk features, the
-    logits of heads 0 and 9 of both modalities and the loss of main.py:284-293 from the executed reference."""
-    hc, K, B = 10, 309, 16
+    logits of heads 0 and 9 of both modalities and the loss of main.py:284-293 from the executed reference.
+    Also used for configs[3] (Kinetics-400 shape: 30 frames -> odd temporal sizes 30/15/8/4, K=400)."""
     m = ref_model.load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', use_mlp=True, num_classes=K,
                              pretrained=False, norm_feat=False, use_max_pool=False, headcount=hc)
     portable_init_(m, seed=31)
     for mod in m.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
-    video = portable_fill_(torch.empty(B, 3, 16, 112, 112), 55, kind="normal")
+    video = portable_fill_(torch.empty(B, 3, T, 112, 112), 55, kind="normal")
     audio = portable_fill_(torch.empty(B, 1, 129, 100), 56, kind="normal")
     selflabels = torch.from_numpy((np.arange(1024 * hc).reshape(1024, hc) * 7919 % K).astype(np.int64))
     selected = torch.arange(B) * 61
@@ -197,9 +197,9 @@ def cfg2_fixture(ref_model, ref_utils):
     with torch.no_grad():
         gv, ga = m(video, audio)       # eval-mode features with the running statistics of ONE train-mode forward
     out["feat_v"], out["feat_a"] = gv.numpy(), ga.numpy()
-    np.savez_compressed(os.path.join(OUT, "cfg2_full.npz"), hc=hc, K=K, B=B, selflabels=selflabels.numpy(),
+    np.savez_compressed(os.path.join(OUT, fname), hc=hc, K=K, B=B, T=T, selflabels=selflabels.numpy(),
                         selected=selected.numpy(), **out)
-    print("cfg2 full-size fixture: loss", loss.item())
+    print(fname, "full-size fixture: loss", loss.item())
 
 
 def main():
@@ -207,6 +207,11 @@ def main():
         ref_model, ref_utils, ref_sk = import_reference()
         torch.set_num_threads(os.cpu_count())
         (cfg1_fixture if "--only-cfg1" in sys.argv else cfg2_fixture)(ref_model, ref_utils)
+        return
+    if "--only-cfg4" in sys.argv:             # configs[3]: 30-frame clips, K=400, hc=10 (per-GPU bs 16 as in scripts/master.sh:82; ~2 min of CPU)
+        ref_model, ref_utils, ref_sk = import_reference()
+        torch.set_num_threads(os.cpu_count())
+        cfg2_fixture(ref_model, ref_utils, hc=10, K=400, B=16, T=30, fname="cfg4_full.npz")
         return
     if "--only-cfg2-grads" in sys.argv:       # full-size (bs 16, 16x112x112) fp64 + fp32 gradients: ~10 min of CPU
         ref_model, ref_utils, ref_sk = import_reference()

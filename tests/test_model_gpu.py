@@ -410,6 +410,32 @@ def test_cfg2_full_size_forward_matches_executed_reference(golden_dir):
     np.testing.assert_allclose(ga.cpu().numpy(), g["feat_a"], rtol=1e-3, atol=1e-3)
 
 
+def test_cfg4_full_size_forward_matches_executed_reference(golden_dir):
+    """BASELINE configs[3] (Kinetics-400 shape) at full per-GPU size: bs=16, 30x112x112 clips (temporal sizes
+    30/15/8/4: every stride-2 temporal conv sees an odd or non-power-of-two length), 1x129x100 log-mel, K=400, hc=10.
+    Train-mode logits, loss and eval features against tests/golden/cfg4_full.npz from the executed reference."""
+    from selavi_amd.utils import get_loss
+    g = np.load(os.path.join(golden_dir, "cfg4_full.npz"))
+    hc, K, B, T = int(g["hc"]), int(g["K"]), int(g["B"]), int(g["T"])
+    assert (hc, K, B, T) == (10, 400, 16, 30)
+    m = _build(hc, K, True).train()
+    video = portable_fill_(torch.empty(B, 3, T, 112, 112), 55).cuda()
+    audio = portable_fill_(torch.empty(B, 1, 129, 100), 56).cuda()
+    with torch.no_grad():
+        fv, fa = m(video, audio)
+        labels = torch.from_numpy(g["selflabels"]).cuda()[torch.from_numpy(g["selected"]).cuda(), :]
+        loss = 0.5 * get_loss(fv, labels, hc) + 0.5 * get_loss(fa, labels, hc)
+    for got, key in ((fv[0], "train_v0"), (fv[9], "train_v9"), (fa[0], "train_a0"), (fa[9], "train_a9")):
+        np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-4)
+    m.eval()
+    m.return_features = True
+    with torch.no_grad():
+        gv, ga = m(video, audio)
+    np.testing.assert_allclose(gv.cpu().numpy(), g["feat_v"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(ga.cpu().numpy(), g["feat_a"], rtol=1e-3, atol=1e-3)
+
+
 def test_full_size_gradients_within_reference_noise(golden_dir):
     """Backward at the headline configuration's FULL input size (bs 16, 16x112x112 video, 1x129x100 log-mel;
     hc=1, K=28 heads): all 190 parameter gradients against the reference's fp64 run
