@@ -143,6 +143,43 @@ def sk_bench(rank, world, dev, iters=50):
                               traffic=_pmc_traffic("sk_pass") if world == 1 else None))
 
 
+def sk_round_estimate(m, dev, world, step_clips_per_s, sk):
+    """What one Sinkhorn-Knopp round costs next to the training it interleaves with (BASELINE metric: "clips/sec
+    (video+audio fwd/bwd+SK)").  Measured here: the eval-mode feature pass of sk_utils.py:137-233 at its batch size
+    (64, :168) on this GPU.  Derived with the reference's defaults (opt.py:71,88,102: 100 epochs, nopts=100 rounds,
+    ind_groups=1) at the VGG-Sound size: round = N / (W x feature-pass rate) + hc heads x 200 SK iterations at the
+    measured it/s (71-271 iterations to converge), against the epochs x N / nopts clips trained between
+    two rounds."""
+    B = 64
+    g = torch.Generator(device=dev).manual_seed(77)
+    video = torch.randn(B, 3, CFG2["T"], CFG2["S"], CFG2["S"], device=dev, generator=g)
+    audio = torch.randn(B, 1, CFG2["F"], CFG2["Tp"], device=dev, generator=g)
+    m.eval()
+    m.return_features = True
+    try:
+        with torch.no_grad():
+            m(video, audio)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                m(video, audio)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
+    finally:
+        m.return_features = False
+        m.train()
+    rate = B / ms * 1e3
+    N, hc, epochs, rounds, its = CFG2["N"], CFG2["hc"], 100, 100, 200
+    t_feat = N / (rate * world)
+    t_sk = hc * its / sk["iters_per_s"] if sk else float("nan")
+    t_train = epochs * N / rounds / step_clips_per_s
+    return {"feature_pass_clips_per_s_per_gpu": rate, "feature_pass_batch": B, "feature_pass_s": t_feat,
+            "sk_solve_s": t_sk, "round_s": t_feat + t_sk, "training_between_rounds_s": t_train,
+            "fraction_of_wall_clock": (t_feat + t_sk) / (t_feat + t_sk + t_train),
+            "clips_per_s_including_sk": step_clips_per_s * t_train / (t_feat + t_sk + t_train),
+            "assumes": f"N={N}, hc={hc}, {rounds} rounds over {epochs} epochs, ind_groups=1, {its} SK iterations per head"}
+
+
 def cpu_baseline(batch):
     """The oracle (oracle/step_ref.py: torch CPU restatement of main.py:284-302, validated against
     the executed reference) timed on this host's cores, on a bounded sample: cfg2-shaped step at a
@@ -234,6 +271,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss_v = float(loss.item())
+    peak_hbm = torch.cuda.max_memory_allocated(dev)      # of the training step; the measurements below allocate more
     ms_step = dt / a.steps * 1e3
     clips = world * B * a.steps / dt
 
@@ -250,6 +288,7 @@ def main():
         fwd_ms = (time.perf_counter() - tf0) / 5 * 1e3
     hot = hot_conv_roofline(B, dev)
     sk = None if a.no_sk else sk_bench(rank, world, dev)
+    sk_round = sk_round_estimate(m, dev, world, clips, sk) if sk else None
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.cpu_batch)
@@ -265,7 +304,7 @@ def main():
                                    "log-mel, K=309, headcount=10, SGD(m=0.9, wd=1e-5), fp32" % B,
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "sync_bn": world > 1, "loss_last_step": loss_v,
-                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
+                       "peak_hbm_gb": round(peak_hbm / 2 ** 30, 2)},
             "roofline": {"bound": "mfma", "achieved": hot["tflops"], "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
                          "frac": hot["tflops"] / PEAK_FP32_MFMA_TF,
                          # HBM bytes per launch of this kernel at B=16 from rocprofv3 PMC passes
@@ -283,6 +322,7 @@ def main():
                                 "note": "algorithmic fused-forward bytes (SURVEY 8d: 518.1 + 3.4 MB/clip); the fp32 "
                                         "forward is MFMA-bound, its compute ceiling is 12.5 % of the HBM roofline"}},
             "sk": sk,
+            "sk_round": sk_round,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
