@@ -236,8 +236,9 @@ static void plan_conv(int M, long long ncols, int Kd, int* mt_out, int* nt_out, 
   const long long blocks = (long long)((M + mt * 16 - 1) / (mt * 16)) * ((ncols + nt * 64 - 1) / (nt * 64));
   if (blocks > 0 && blocks < 768) {
     const int chunks = (Kd + 15) / 16;
-    static const int target = getenv("SLV_SPLIT_TARGET") ? atoi(getenv("SLV_SPLIT_TARGET")) : 1536;
-    static const int minch = getenv("SLV_SPLIT_MINCH") ? atoi(getenv("SLV_SPLIT_MINCH")) : 32;
+    // tuning overrides for experiments; clamped so that a bad value cannot divide by zero
+    static const int target = getenv("SLV_SPLIT_TARGET") ? (atoi(getenv("SLV_SPLIT_TARGET")) > 0 ? atoi(getenv("SLV_SPLIT_TARGET")) : 1) : 1536;
+    static const int minch = getenv("SLV_SPLIT_MINCH") ? (atoi(getenv("SLV_SPLIT_MINCH")) > 0 ? atoi(getenv("SLV_SPLIT_MINCH")) : 1) : 32;
     long long sp = (target + blocks - 1) / blocks;
     if (sp > chunks / minch) sp = chunks / minch;   // >= 32 chunks (512 k) per slice
     if (sp > conv_max_splits()) sp = conv_max_splits();
