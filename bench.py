@@ -242,7 +242,7 @@ def main():
     m.train()
     net = m
     if world > 1:
-        net = train.wrap_ddp(m, [local])      # main.py:156-160, with the DDP options this model allows
+        net = train.data_parallel(m, [local])     # main.py:156-160; SELAVI_DP=ddp selects torch DDP instead
     opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)       # main.py:132-137
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     video = torch.randn(B, 3, CFG2["T"], CFG2["S"], CFG2["S"], device=dev, generator=g)

@@ -76,7 +76,7 @@ def main(argv=None):
     optimizer = optim.SGD(model.parameters(), lr=args.base_lr, momentum=0.9, weight_decay=args.wd)   # :132-137
     net = model
     if args.world_size > 1:
-        net = train.wrap_ddp(model, [local])                                                # :156-160
+        net = train.data_parallel(model, [local])                                           # :156-160
 
     n_dl, N = len(loader), len(dataset)
     selflabels = torch.zeros((N, args.headcount), dtype=torch.long, device="cuda")           # :166

@@ -54,7 +54,13 @@ class Ctx:
         self.training = training
         self.sync = sync            # (process_group, world_size) for SyncBN or None
         self.grads = {}             # id(param) -> grad tensor
+        self.grad_out = None        # id(param) -> preallocated gradient view (parallel.GradSink), or None
         self.side = None            # HIP stream carrying this pass' weight-gradient launches, if any
+
+    def grad_like(self, p):
+        """Where the gradient of parameter p is written: the data-parallel bucket view if there is one."""
+        v = self.grad_out.get(id(p)) if self.grad_out is not None else None
+        return torch.empty_like(p) if v is None else v
 
 
 def _as5d(t):
@@ -113,6 +119,10 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
         bnr = (src.y, src.ss, src.mi) if fuse_bn else None
         return ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out, bnr=bnr)
 
+    w = r.conv.weight
+    dw_out = ctx.grad_out.get(id(w)) if ctx.grad_out is not None else None     # persistent bucket view (parallel.py)
+    if dw_out is not None:
+        dw_out = dw_out.view(w.shape[0], -1)
     if WGRAD_SIDE_STREAM:
         # the backward-data conv is on the critical path: it is enqueued first; the weight gradient starts on
         # the side stream as soon as dXout exists (event recorded before the dgrad launch)
@@ -122,14 +132,15 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
         res = dgrad() if need_dx else None
         side.wait_event(ready)
         with torch.cuda.stream(side):
-            dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None)
+            dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None, out=dw_out)
         for t in (dxo, xin, in_ss):                 # allocated on `cur`, read on `side`
             if t is not None:
                 t.record_stream(side)
-        dw.record_stream(cur)                       # allocated on `side`, consumed by the optimizer on `cur`
+        if dw_out is None:
+            dw.record_stream(cur)                   # allocated on `side`, consumed by the optimizer on `cur`
         ctx.side = side
     else:
-        dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None)
+        dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None, out=dw_out)
         res = dgrad() if need_dx else None
     ctx.grads[id(r.conv.weight)] = dw.view_as(r.conv.weight)
     return res
@@ -138,7 +149,7 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
 def bn_bwd_own(ctx, r, g, part=None):
     """BN backward coefficients for Raw r consumed through relu(bn(.)) with upstream gradient g
     (part: the partial sums, when the dgrad that produced g already formed them)."""
-    dg, db = torch.empty_like(r.bn.weight), torch.empty_like(r.bn.bias)
+    dg, db = ctx.grad_like(r.bn.weight), ctx.grad_like(r.bn.bias)
     b5, _, _ = ops.bn_bwd(g, r.y, r.mi, r.bn.weight, ss_mask=r.ss, sync=ctx.sync, dgamma=dg, dbeta=db, part=part)
     ctx.grads[id(r.bn.weight)] = dg
     ctx.grads[id(r.bn.bias)] = db
@@ -168,9 +179,9 @@ def block_bwd(ctx, rec, dv, need_du=True):
     """dv: gradient w.r.t. the block output.  Returns gradient w.r.t. the block input."""
     last = rec.chain[-1]
     ds = rec.ds
-    dg, db = torch.empty_like(last.bn.weight), torch.empty_like(last.bn.bias)
+    dg, db = ctx.grad_like(last.bn.weight), ctx.grad_like(last.bn.bias)
     if ds is not None:
-        dg2, db2 = torch.empty_like(ds.bn.weight), torch.empty_like(ds.bn.bias)
+        dg2, db2 = ctx.grad_like(ds.bn.weight), ctx.grad_like(ds.bn.bias)
         b5, b5ds, dz = ops.bn_bwd(dv, last.y, last.mi, last.bn.weight, v_mask=rec.v, x2=ds.y, mi2=ds.mi,
                                   gamma2=ds.bn.weight, sync=ctx.sync, dgamma=dg, dbeta=db, dgamma2=dg2, dbeta2=db2)
         ctx.grads[id(ds.bn.weight)] = dg2

@@ -86,6 +86,13 @@ class AVModel(nn.Module):             # model.py:169-252
         for h in self._heads():
             h.sync = sync
 
+    def set_grad_sink(self, sink):
+        """parallel.DataParallel: parameter gradients are written into the sink's flat buffers and all-reduced per
+        autograd node (None: gradients are returned to autograd as usual)."""
+        self._grad_sink = sink
+        self.video_network.base.grad_sink = sink
+        self.audio_network.base.grad_sink = sink
+
     @staticmethod
     def _side_stream(device):
         st = _SIDE_STREAMS.get(device)
@@ -125,7 +132,7 @@ class AVModel(nn.Module):             # model.py:169-252
         heads = self._heads()
         spec_ = snn.HeadSpec(heads, self.hc, False, self.use_mlp, self.training,
                              snn._sync_of(self.video_network.base) if self.training else None,
-                             masks=self._dropout_masks)
+                             masks=self._dropout_masks, grad_sink=getattr(self, "_grad_sink", None))
         logits = snn.HeadsFunction.apply(spec_, img_features.contiguous(), aud_features.contiguous(),
                                          *snn.head_params(heads))
         if self.norm_feat:

@@ -220,10 +220,17 @@ class TrunkFunction(torch.autograd.Function):
         if not fctx.need:
             raise RuntimeError("selavi_amd: backward through a trunk that ran in eval / no_grad mode")
         ectx = engine.Ctx(True, sync=fctx.sync)
+        params = _trunk_params(fctx.trunk)
+        sink = getattr(fctx.trunk, "grad_sink", None)          # parallel.GradSink: gradients go to its flat buffer
+        if sink is not None:
+            ectx.grad_out = sink.views((fctx.kind,), params)
         bwd = engine.video_backward if fctx.kind == "video" else engine.audio_backward
         bwd(ectx, fctx.saved_rec, dfeat)
         fctx.saved_rec = None
-        grads = [ectx.grads.get(id(p)) for p in _trunk_params(fctx.trunk)]
+        if sink is not None:
+            sink.deliver((fctx.kind,), params)                 # .grad = bucket views, all-reduce launched
+            return (None, None, None) + (None,) * len(params)
+        grads = [ectx.grads.get(id(p)) for p in params]
         return (None, None, None) + tuple(grads)
 
 
@@ -246,10 +253,18 @@ class VideoStageFunction(torch.autograd.Function):
         if not fctx.need:
             raise RuntimeError("selavi_amd: backward through a trunk that ran in eval / no_grad mode")
         ectx = engine.Ctx(True, sync=fctx.sync)
+        params = _stage_params(fctx.trunk, fctx.stage)
+        sink = getattr(fctx.trunk, "grad_sink", None)
+        if sink is not None:
+            ectx.grad_out = sink.views(("video", fctx.stage), params)
         din = engine.video_stage_backward(ectx, fctx.stage, fctx.saved_rec, dout.contiguous())
         fctx.saved_rec = None
-        grads = [ectx.grads.get(id(p)) for p in _stage_params(fctx.trunk, fctx.stage)]
-        return (None, None, din if fctx.needs_input_grad[2] else None) + tuple(grads)
+        din = din if fctx.needs_input_grad[2] else None
+        if sink is not None:
+            sink.deliver(("video", fctx.stage), params)
+            return (None, None, din) + (None,) * len(params)
+        grads = [ectx.grads.get(id(p)) for p in params]
+        return (None, None, din) + tuple(grads)
 
 
 # ------------------------------------------------------------------------------------------ heads
@@ -292,9 +307,9 @@ class LinearHead(nn.Linear):
 
 
 class HeadSpec:
-    def __init__(self, heads, hc, single, has_hidden, training, sync, masks=None):
+    def __init__(self, heads, hc, single, has_hidden, training, sync, masks=None, grad_sink=None):
         self.heads, self.hc, self.single, self.has_hidden = heads, hc, single, has_hidden
-        self.training, self.sync, self.masks = training, sync, masks
+        self.training, self.sync, self.masks, self.grad_sink = training, sync, masks, grad_sink
 
 
 def _lin_of(head, idx):
@@ -445,7 +460,13 @@ class HeadsFunction(torch.autograd.Function):
             dX = f32(2, B, dxg.shape[2])
             C.slv_heads_sum_groups(ptr(dxg), ptr(dX), hcg, B * dxg.shape[2], st)
             dfv, dfa = dX[0], dX[1]
-        pg = [grads.get(id(p)) for p in head_params(heads)]
+        hp = head_params(heads)
+        if spec.grad_sink is not None:        # the grouped gradient tensors are the buckets: one all-reduce each
+            for p in hp:
+                p.grad = grads[id(p)]
+            spec.grad_sink.reduce([dW1, dga, dbe, dW2, db2] if spec.has_hidden else [dW, db])
+            return (None, dfv, dfa) + (None,) * len(hp)
+        pg = [grads.get(id(p)) for p in hp]
         return (None, dfv, dfa) + tuple(pg)
 
 

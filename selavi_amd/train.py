@@ -46,3 +46,14 @@ def wrap_ddp(model, device_ids, **kw):
     opts = dict(broadcast_buffers=False, gradient_as_bucket_view=True)
     opts.update(kw)
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, **opts)
+
+
+def data_parallel(model, device_ids, group=None, kind=None):
+    """The data-parallel wrapper of a training run: ``parallel.DataParallel`` (flat per-node gradient buckets written
+    by the kernels, 7 all-reduces per step) unless ``kind``/SELAVI_DP says "ddp" (torch DDP through wrap_ddp)."""
+    import os
+    kind = kind or os.environ.get("SELAVI_DP", "native")
+    if kind == "ddp":
+        return wrap_ddp(model, device_ids, process_group=group)
+    from .parallel import DataParallel
+    return DataParallel(model, group=group)

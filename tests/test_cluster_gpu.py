@@ -101,7 +101,9 @@ def _ddp_worker(rank, world, port, ret, wrap=False):
         portable_init_(m, seed=31)
         step_ref.set_dropout_p(m, 0.0)
         m = m.cuda().train()
-        if wrap:
+        if wrap == "native":
+            net = train.data_parallel(m, [0], kind="native")
+        elif wrap:
             net = train.wrap_ddp(m, [0])
         else:
             net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)
@@ -172,6 +174,21 @@ def test_two_rank_wrap_ddp_keeps_parameters_and_buffers_bit_identical():
         assert abs(ret[r][0] - ret_ref[r][0]) <= 1e-6 * abs(ret_ref[r][0])
 
 
+def test_two_rank_native_data_parallel_is_bit_identical_to_ddp():
+    """parallel.DataParallel (gradients written by the kernels into flat per-node buckets, one all-reduce per node)
+    against torch DDP on the same two ranks: three steps, every parameter and buffer bit-identical (both average
+    the same two addends; scaling by 1/2 commutes with the sum), ranks in lock-step."""
+    import torch.multiprocessing as mp
+    ret, ret_ddp = mp.Manager().dict(), mp.Manager().dict()
+    mp.spawn(_ddp_worker, args=(2, 29300 + os.getpid() % 150, ret, "native"), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, 29700 + os.getpid() % 150, ret_ddp, True), nprocs=2, join=True)
+    diverged = [k for k in ret[0][2] if ret[0][2][k] != ret[1][2][k]]
+    assert not diverged, f"ranks diverged in {len(diverged)} tensors: {diverged[:6]}"
+    differs = [k for k in ret[0][2] if ret[0][2][k] != ret_ddp[0][2][k]]
+    assert not differs, f"{len(differs)} of {len(ret[0][2])} tensors differ from DDP: {differs[:6]}"
+    assert ret[0][0] == ret_ddp[0][0] and ret[0][1] == ret_ddp[0][1]
+
+
 def _nccl_worker(rank, port, ret):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -181,13 +198,15 @@ def _nccl_worker(rank, port, ret):
         from selavi_amd import model as smodel, optim, train
         hc, K = 2, 7
         out = []
-        for distributed in (False, True):
+        for distributed in (False, True, "native"):
             m = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
             portable_init_(m, seed=31)
             step_ref.set_dropout_p(m, 0.0)
             m = m.cuda().train()
             net = m
-            if distributed:       # SyncBN all-reduces + DDP buckets go through RCCL (streams, events, side streams)
+            if distributed == "native":   # flat buckets, ReduceOp.AVG on RCCL's stream, final-callback wait
+                net = train.data_parallel(m, [0], kind="native")
+            elif distributed:     # SyncBN all-reduces + DDP buckets go through RCCL (streams, events, side streams)
                 m.set_sync_bn(True)
                 net = train.wrap_ddp(m, [0])
             opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
@@ -197,7 +216,7 @@ def _nccl_worker(rank, port, ret):
             sel = torch.tensor([3, 17, 42, 63]).cuda()
             losses = [float(train.train_step(net, opt, video, audio, sl, sel, hc)) for _ in range(3)]
             out.append((losses, torch.cat([p.detach().flatten() for p in m.parameters()]).cpu().numpy()))
-        ret["plain"], ret["rccl"] = out
+        ret["plain"], ret["rccl"], ret["native"] = out
     finally:
         dist.destroy_process_group()
 
@@ -209,7 +228,9 @@ def test_rccl_syncbn_ddp_world1_equals_plain_step():
     import torch.multiprocessing as mp
     ret = mp.Manager().dict()
     mp.spawn(_nccl_worker, args=(29900 + os.getpid() % 90, ret), nprocs=1, join=True)
-    (l0, w0), (l1, w1) = ret["plain"], ret["rccl"]
-    assert np.isfinite(l1).all() and np.isfinite(w1).all()
-    np.testing.assert_allclose(l1, l0, rtol=2e-5)
-    assert np.linalg.norm(w1 - w0) <= 1e-4 * np.linalg.norm(w0)
+    (l0, w0) = ret["plain"]
+    for key in ("rccl", "native"):
+        l1, w1 = ret[key]
+        assert np.isfinite(l1).all() and np.isfinite(w1).all(), key
+        np.testing.assert_allclose(l1, l0, rtol=2e-5, err_msg=key)
+        assert np.linalg.norm(w1 - w0) <= 1e-4 * np.linalg.norm(w0), key

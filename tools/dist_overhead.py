@@ -40,8 +40,7 @@ def main():
               "ddp-nobcast-view": dict(broadcast_buffers=False, gradient_as_bucket_view=True),
               "ddp-nobcast-view-100MB": dict(broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=100),
               "ddp-nobcast-view-static": dict(broadcast_buffers=False, gradient_as_bucket_view=True, static_graph=True)}
-    modes = ("plain", "syncbn", "syncbn+ddp", "syncbn+ddp-nobcast", "syncbn+ddp-nobcast-view",
-             "syncbn+ddp-nobcast-view-100MB", "syncbn+ddp-nobcast-view-static", "plain")
+    modes = ("plain", "syncbn", "syncbn+ddp", "syncbn+ddp-nobcast", "syncbn+ddp-nobcast-view", "native", "plain")
     if a.modes:
         modes = tuple(a.modes.split(","))
     for mode in modes:
@@ -50,7 +49,9 @@ def main():
                               pretrained=False, norm_feat=False, use_max_pool=False, headcount=hc).to(dev).train()
         net = m
         m.set_sync_bn(mode != "plain")
-        if "+" in mode:
+        if mode == "native":
+            net = train.data_parallel(m, [0], kind="native")
+        elif "+" in mode:
             net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], **ddp_kw[mode.split("+")[1]])
         opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
         for _ in range(4):
