@@ -321,6 +321,34 @@ def test_single_head_forward_on_feature_bank():
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("hc,use_mlp,norm_feat", [(1, True, False), (3, True, True), (2, False, False)])
+def test_single_clip_batch_keeps_the_reference_shapes(hc, use_mlp, norm_feat):
+    """B == 1 (model.py:223-231): `.squeeze()` drops the batch dimension of the trunk features, `return_features`
+    hands those 1-D tensors out as they are, the head path re-adds the dimension.  Eval mode, against the oracle."""
+    from selavi_amd import model as smodel
+    m = smodel.load_model(use_mlp=use_mlp, num_classes=12, norm_feat=norm_feat, headcount=hc)
+    o = model_ref.load_model(use_mlp=use_mlp, num_classes=12, norm_feat=norm_feat, headcount=hc)
+    portable_init_(m, seed=31), portable_init_(o, seed=31)
+    m = m.cuda().eval()
+    o.eval()
+    video = portable_fill_(torch.empty(1, 3, 4, 32, 32), 5)
+    audio = portable_fill_(torch.empty(1, 1, 40, 36), 6)
+    with torch.no_grad():
+        gv, ga = m(video.cuda(), audio.cuda())
+        wv, wa = o(video, audio)
+        got = [gv, ga] if hc == 1 else list(gv) + list(ga)
+        want = [wv, wa] if hc == 1 else list(wv) + list(wa)
+        for g_, w_ in zip(got, want):
+            assert tuple(g_.shape) == tuple(w_.shape) == (1, 12)
+            np.testing.assert_allclose(g_.cpu().numpy(), w_.numpy(), rtol=1e-3, atol=1e-3)
+        m.return_features = o.return_features = True
+        fv, fa = m(video.cuda(), audio.cuda())
+        rv, ra = o(video, audio)
+        assert tuple(fv.shape) == tuple(rv.shape) == (512,) and tuple(fa.shape) == tuple(ra.shape) == (512,)
+        np.testing.assert_allclose(fv.cpu().numpy(), rv.numpy(), rtol=1e-3, atol=1e-3)
+
+
 def test_full_cfg2_step_reproducible_and_learning():
     """BASELINE cfg2 size (B=16, 16x112x112 video, 129x100 log-mel, K=309, hc=10), where the CPU oracle
     is unaffordable: (1) two runs of 6 steps from the same state are bit-identical (benchmark-mode
