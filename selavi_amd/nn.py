@@ -419,7 +419,12 @@ class HeadsFunction(torch.autograd.Function):
             bns = [hd.block_forward[4] for hd in heads]
             lin2 = [_lin_of(hd, 8) for hd in heads]
             IN, HID, K = lin1[0].weight.shape[1], lin1[0].weight.shape[0], lin2[0].weight.shape[0]
-            dW2, db2 = f32(G, K, HID), f32(G, K)
+            sink = spec.grad_sink
+            if sink is not None:          # data parallel: the grouped gradients live in one flat all-reduce buffer
+                gflat, (dW2, db2, dga, dbe, dW1) = sink.carve(("heads", G, K, HID, IN), [(G, K, HID), (G, K), (G, HID),
+                                                                                          (G, HID), (G, HID, IN)])
+            else:
+                dW2, db2, dga, dbe, dW1 = f32(G, K, HID), f32(G, K), f32(G, HID), f32(G, HID), f32(G, HID, IN)
             C.slv_heads_linear_bwd_w(ptr(dlogits), ptr(a), 0, hcg, 0, 1.0, ptr(dW2), ptr(db2), G, B, HID, K, st)
             W2 = ops.PtrArray([l.weight for l in lin2])
             da = f32(G, B, HID)
@@ -429,10 +434,9 @@ class HeadsFunction(torch.autograd.Function):
             C.slv_heads_bn_bwd_stats(ptr(da), ptr(h), ptr(mi), ga.p, be.p, ptr(m2), msc, ptr(sums), G, B, HID, st)
             if spec.sync is not None:
                 ops._allreduce(sums, spec.sync[0])
-            dh, dga, dbe = f32(G, B, HID), f32(G, HID), f32(G, HID)
+            dh = f32(G, B, HID)
             C.slv_heads_bn_bwd_apply(ptr(da), ptr(h), ptr(mi), ga.p, be.p, ptr(m2), msc, ptr(sums), count, ptr(dh),
                                      ptr(dga), ptr(dbe), G, B, HID, st)
-            dW1 = f32(G, HID, IN)
             C.slv_heads_linear_bwd_w(ptr(dh), ptr(X), 1, hcg, ptr(m1), msc, ptr(dW1), 0, G, B, IN, HID, st)
             W1 = ops.PtrArray([l.weight for l in lin1])
             dxg = f32(G, B, IN)
@@ -446,7 +450,11 @@ class HeadsFunction(torch.autograd.Function):
         else:
             lin = [_lin_of(hd, 2) for hd in heads]
             IN, K = lin[0].weight.shape[1], lin[0].weight.shape[0]
-            dW, db = f32(G, K, IN), f32(G, K)
+            sink = spec.grad_sink
+            if sink is not None:
+                gflat, (dW, db) = sink.carve(("heads", G, K, IN), [(G, K, IN), (G, K)])
+            else:
+                dW, db = f32(G, K, IN), f32(G, K)
             C.slv_heads_linear_bwd_w(ptr(dlogits), ptr(X), 1, hcg, ptr(m1), msc, ptr(dW), ptr(db), G, B, IN, K, st)
             W = ops.PtrArray([l.weight for l in lin])
             dxg = f32(G, B, IN)
@@ -461,10 +469,10 @@ class HeadsFunction(torch.autograd.Function):
             C.slv_heads_sum_groups(ptr(dxg), ptr(dX), hcg, B * dxg.shape[2], st)
             dfv, dfa = dX[0], dX[1]
         hp = head_params(heads)
-        if spec.grad_sink is not None:        # the grouped gradient tensors are the buckets: one all-reduce each
+        if spec.grad_sink is not None:        # the grouped gradient tensors are views of one bucket: one all-reduce
             for p in hp:
                 p.grad = grads[id(p)]
-            spec.grad_sink.reduce([dW1, dga, dbe, dW2, db2] if spec.has_hidden else [dW, db])
+            spec.grad_sink.reduce([gflat])
             return (None, dfv, dfa) + (None,) * len(hp)
         pg = [grads.get(id(p)) for p in hp]
         return (None, dfv, dfa) + tuple(pg)

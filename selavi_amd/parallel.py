@@ -42,6 +42,27 @@ class GradSink:
             ent = self.flat[key] = (flat, {id(p): flat[o:o + p.numel()].view_as(p) for p, o in zip(params, offs)})
         return ent[1]
 
+    def carve(self, key, shapes):
+        """One flat buffer for a group of tensors the caller's kernels will write (the heads' grouped gradients)."""
+        ent = self.flat.get(key)
+        if ent is None:
+            offs, n = [], 0
+            for shp in shapes:
+                offs.append(n)
+                cnt = 1
+                for d in shp:
+                    cnt *= d
+                n += (cnt + _ALIGN - 1) // _ALIGN * _ALIGN
+            flat = torch.zeros(n, dtype=torch.float32, device=torch.cuda.current_device())
+            views = []
+            for shp, o in zip(shapes, offs):
+                cnt = 1
+                for d in shp:
+                    cnt *= d
+                views.append(flat[o:o + cnt].view(*shp))
+            ent = self.flat[key] = (flat, views)
+        return ent
+
     def deliver(self, key, params):
         """The node's kernels have written every view: publish them as .grad and start the node's all-reduce."""
         flat, views = self.flat[key]
