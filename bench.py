@@ -138,7 +138,9 @@ def sk_bench(rank, world, dev, iters=50):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = t.item()
     gbs = n * K * 8 / ms / 1e6      # per-GPU algorithmic bytes (one read of the fp64 shard) / time
-    return dict(iters_per_s=1e3 / ms, us_per_iter=ms * 1e3, N=N, K=K, rows_per_gpu=n, grid=grid,
+    note = None if world == 1 else ("rows sharded over %d GPUs: the pass over a shard takes ~%.0f us, each iteration is then bound by "
+                                    "the latency of its K-vector all-reduce and three host-enqueued launches" % (world, 76.0 / world))
+    return dict(iters_per_s=1e3 / ms, us_per_iter=ms * 1e3, N=N, K=K, rows_per_gpu=n, grid=grid, note=note,
                 roofline=dict(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
                               traffic=_pmc_traffic("sk_pass") if world == 1 else None))
 
