@@ -56,4 +56,10 @@ def data_parallel(model, device_ids, group=None, kind=None):
     if kind == "ddp":
         return wrap_ddp(model, device_ids, process_group=group)
     from .parallel import DataParallel
-    return DataParallel(model, group=group)
+    try:
+        return DataParallel(model, group=group)
+    except (AttributeError, TypeError, NotImplementedError) as e:      # a torch build without an API used there:
+        import warnings                                                 # deterministic, so every rank falls back alike
+        warnings.warn(f"selavi_amd.parallel.DataParallel unavailable ({e!r}); using torch DDP")
+        model.set_grad_sink(None)
+        return wrap_ddp(model, device_ids, process_group=group)
