@@ -100,3 +100,61 @@ def test_hill_climb_replays_reference_match_order(golden_dir):
     np.testing.assert_array_equal(g["w_after"], g["w_before"][perm])
     np.testing.assert_array_equal(g["b_after"], g["b_before"][perm])
     assert next(it, None) is None          # consumed exactly the recorded stream
+
+
+# ---- parallel.GradSink: flat per-node gradient buckets + asynchronous all-reduce (host logic, no kernels) ------------
+class _Node(torch.autograd.Function):
+    """Stand-in for one autograd node of the model: writes 'gradients' into the sink's views like the HIP kernels do."""
+
+    @staticmethod
+    def forward(ctx, x, sink, key, params, scale):
+        ctx.sink, ctx.key, ctx.params, ctx.scale = sink, key, params, scale
+        return x * 1.0
+
+    @staticmethod
+    def backward(ctx, g):
+        views = ctx.sink.views(ctx.key, ctx.params)
+        for i, p in enumerate(ctx.params):
+            views[id(p)].copy_(torch.full_like(p, ctx.scale * (i + 1)) * g.sum())
+        ctx.sink.deliver(ctx.key, ctx.params)
+        return g, None, None, None, None
+
+
+def _sink_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from selavi_amd.parallel import GradSink
+        sink = GradSink()
+        pa = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7))]
+        pb = [torch.nn.Parameter(torch.zeros(130))]
+        out = []
+        for step in range(2):                                  # the buffers persist; a second backward overwrites them
+            x = torch.ones(2, requires_grad=True)
+            y = _Node.apply(_Node.apply(x, sink, ("a",), pa, float(rank + 1)), sink, ("b",), pb, 10.0 * (rank + 1))
+            (y.sum() * (step + 1)).backward()
+            assert not sink.pending                             # the final callback waited for both collectives
+            out.append([p.grad.clone() for p in pa + pb])
+            for p in pa + pb:
+                p.grad = None
+        flat_a, views_a = sink.flat[("a",)]
+        aligned = all(v.data_ptr() % 256 == flat_a.data_ptr() % 256 for v in views_a.values())
+        ret[rank] = ([[g.numpy() for g in o] for o in out], aligned, pa[0].grad is None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_sink_averages_flat_buckets_across_ranks():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sink_worker, args=(2, 27500 + (os.getpid() % 2000), ret), nprocs=2, join=True)
+    for rank in range(2):
+        outs, aligned, cleared = ret[rank]
+        assert aligned and cleared
+        for step, o in enumerate(outs):
+            s = 2.0 * (step + 1)                                # g.sum() of the upstream gradient
+            # node "a": rank r wrote (r+1)*(i+1)*s -> mean over ranks 1.5*(i+1)*s ; node "b": 10*(r+1)*s -> 15*s
+            assert np.allclose(o[0], 1.5 * 1 * s) and o[0].shape == (3, 5)
+            assert np.allclose(o[1], 1.5 * 2 * s) and o[1].shape == (7,)
+            assert np.allclose(o[2], 15.0 * s) and o[2].shape == (130,)
+    assert all(np.array_equal(a, b) for a, b in zip(ret[0][0][1], ret[1][0][1]))      # ranks hold identical gradients
