@@ -63,3 +63,55 @@ def data_parallel(model, device_ids, group=None, kind=None):
         warnings.warn(f"selavi_amd.parallel.DataParallel unavailable ({e!r}); using torch DDP")
         model.set_grad_sink(None)
         return wrap_ddp(model, device_ids, process_group=group)
+
+
+def _join_package_streams():
+    """The current stream waits for every side stream this package created (audio trunk, weight gradients)."""
+    import torch
+    from . import engine, model
+    cur = torch.cuda.current_stream()
+    for st in list(model._SIDE_STREAMS.values()) + list(engine._WGRAD_STREAMS.values()):
+        if st.device == cur.device:
+            cur.wait_stream(st)
+
+
+class GraphedStep:
+    """The whole training step (forward, loss, backward, SGD) captured once into a HIP graph and replayed.
+
+    For shapes where the ~700 kernel launches of a step cost more host time than GPU time (BASELINE configs[0]: bs 4,
+    8 frames) the step is bound by Python/ctypes enqueue; a graph replay is one launch.  Every kernel of this package
+    is capturable as is (no allocation, synchronisation or host copy inside libselavi_hip.so; pointer tables travel in
+    kernel arguments; the trunk / weight-gradient side streams fork from and join the capturing stream with events).
+    Inputs are static buffers: copy the next batch into ``video / audio / selected`` (and update ``selflabels`` in
+    place) before ``replay()``.  Single process only (collectives are not captured); BatchNorm's
+    ``num_batches_tracked`` advances per replay."""
+
+    def __init__(self, model, optimizer, video, audio, selflabels, selected, headcount, warmup=3):
+        import torch
+        self.model, self.video, self.audio, self.selflabels, self.selected = model, video, audio, selflabels, selected
+        self._bns = [m for m in model.modules() if hasattr(m, "note_batch")]
+        # the audio trunk stays on the capturing stream: capturing its backward on the side stream (autograd's own
+        # cross-stream hand-over of the incoming gradient) segfaults in hipStreamEndCapture on ROCm 7.0
+        # (tests/diag/graph_capture_stages.py); the weight-gradient side streams capture fine
+        core = model.module if hasattr(model, "module") else model
+        core.overlap_audio = False
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                  # plans, tuning, momentum buffers, side streams: all before capture
+            for _ in range(warmup):
+                train_step(model, optimizer, video, audio, selflabels, selected, headcount)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = train_step(model, optimizer, video, audio, selflabels, selected, headcount)
+            _join_package_streams()                    # a capture may only end with every forked stream joined
+        for b in self._bns:                            # the captured call counted one batch without running it
+            b._pending -= 1
+
+    def replay(self):
+        self.graph.replay()
+        for b in self._bns:
+            b.note_batch()
+        return self.loss

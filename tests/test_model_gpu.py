@@ -519,3 +519,34 @@ def test_training_step_with_batch_sliced_convs(monkeypatch):
     assert (l0 - l1).abs().max().item() <= 1e-4 * max(1.0, l0.abs().max().item())
     assert abs(loss0 - loss1) <= 1e-5 * max(1.0, abs(loss0))
     assert torch.isfinite(w1).all() and (w0 - w1).norm().item() <= 1e-3 * w0.norm().item()
+
+
+@pytest.mark.gpu
+def test_graphed_step_replays_bit_identically_to_eager():
+    """train.GraphedStep: the whole step (forward, loss, backward with the weight-gradient side streams, SGD) captured
+    into one HIP graph; two replays leave exactly the weights two eager steps leave."""
+    from selavi_amd import model as smodel, optim, train
+
+    def make():
+        m = smodel.load_model(use_mlp=True, num_classes=12, norm_feat=False, headcount=2)
+        portable_init_(m, seed=31)
+        step_ref.set_dropout_p(m, 0.0)
+        m = m.cuda().train()
+        m.overlap_audio = False                    # same stream assignment as the captured step
+        return m, optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+
+    video = portable_fill_(torch.empty(4, 3, 4, 32, 32), 5).cuda()
+    audio = portable_fill_(torch.empty(4, 1, 40, 36), 6).cuda()
+    sl = torch.from_numpy((np.arange(64 * 2).reshape(64, 2) * 7919 % 12).astype(np.int64)).cuda()
+    sel = torch.tensor([3, 17, 42, 63]).cuda()
+    m0, o0 = make()
+    for _ in range(5):
+        l0 = train.train_step(m0, o0, video, audio, sl, sel, 2)
+    m1, o1 = make()
+    gs = train.GraphedStep(m1, o1, video, audio, sl, sel, 2, warmup=3)
+    for _ in range(2):
+        l1 = gs.replay()
+    torch.cuda.synchronize()
+    assert float(l0) == float(l1)
+    for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
+        assert torch.equal(a, b), k
