@@ -17,4 +17,9 @@ Parity status
   0.4.2, which is NOT vendored in the reference and not installed here -> this part is
   "parity unpinned" by the reference; it is pinned instead by the documented parameter
   counts (31 505 325 / 11 689 512) and state-dict key layout, see tests/test_oracle.py.
+* ``input_ref.clip_augmentation_ref`` : pinned against the reference's own
+  ``datasets/video_transforms.clip_augmentation`` executed in the build container
+  (``tests/golden/make_input_golden.py`` -> ``clip_aug.npz``), bit-identical at production sizes.
+* ``input_ref.logfbank_ref`` : restates python_speech_features 0.6 (absent) -> "parity unpinned" by
+  reference outputs; the arithmetic underneath is numpy.fft.rfft.
 """
