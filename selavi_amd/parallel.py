@@ -29,7 +29,6 @@ class GradSink:
         self.avg = backend == "nccl"              # RCCL averages in the collective; gloo: sum, then one scale per buffer
         self.flat = {}                            # key -> (flat buffer, {id(param): view})
         self.pending = []
-        self._queued = False
 
     def views(self, key, params):
         ent = self.flat.get(key)
@@ -74,17 +73,16 @@ class GradSink:
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         for t in tensors:
             self.pending.append((dist.all_reduce(t, op=op, group=self.group, async_op=True), t))
-        if not self._queued:                      # we are inside backward: hold the caller until the buffers landed
-            self._queued = True
-            torch.autograd.Variable._execution_engine.queue_callback(self.finalize)
+        # we are inside backward: hold its caller until the buffers have landed.  One callback per node (the first to run
+        # waits for everything launched so far, the others find nothing): no state survives an interrupted backward
+        torch.autograd.Variable._execution_engine.queue_callback(self.finalize)
 
     def finalize(self):
-        for work, t in self.pending:
+        pending, self.pending = self.pending, []
+        for work, t in pending:
             work.wait()
             if not self.avg:
                 t.mul_(1.0 / self.world)
-        self.pending = []
-        self._queued = False
 
 
 class DataParallel(torch.nn.Module):
