@@ -256,6 +256,19 @@ int slv_av_argmax(const float* lv, const float* la, int64_t N, int K, int64_t* l
 int slv_contingency(const int64_t* pred, const int64_t* target, int64_t N, int K1, int K2, int64_t* counts,
                     int32_t* bad, slv_stream_t stream);
 
+/* ---- 16-bit MFMA path, first kernel (BASELINE configs[4]; main.py:151 --use_fp16 trains the convs in half
+ * precision through apex O1).  bf16 CHANNELS-LAST activations [N][T][H][W][Cp] (Cp % 32 == 0, channels >= C are zero),
+ * fp32 accumulation on v_mfma_f32_16x16x32_bf16, fused epilogue y = relu?(acc * scale + shift + residual) -> bf16.
+ * slv_conv_cl16_fwd replaces nn.Conv3d/Conv2d forward (+ the eval-mode BatchNorm / ReLU / residual that follow it in
+ *   torchvision's blocks) for one layer.  geom: 20 int32 = {N, Ti, Hi, Wi, Cin_p, Cout, Cout_p, To, Ho, Wo, kt, kh, kw,
+ *   st, sh, sw, pt, ph, pw, Mrows}; mt in {4, 8, 9}: 16-row tiles per block, Mrows % (16*mt) == 0, Mrows >= Cout;
+ *   w_layout_bf16: [kt*kh*kw][Cin_p/32][Mrows][32] bf16, zero padded (selavi_amd/ops16.py builds it);
+ *   scale_shift: fp32 [2][Cout] or null; res_bf16: [P_out][Cout_p] or null.
+ * slv_to_cl16: fp32 N,C,T,H,W (S = T*H*W) -> bf16 N,T,H,W,Cp. */
+int slv_conv_cl16_fwd(const int32_t* geom, int mt, const void* x_bf16, const void* w_layout_bf16, void* y_bf16,
+                      const float* scale_shift, const void* res_bf16, int relu, slv_stream_t stream);
+int slv_to_cl16(const float* x, void* y_bf16, int64_t N, int C, int Cp, int64_t S, slv_stream_t stream);
+
 /* ---- input pipeline: what the reference's DataLoader workers compute per clip on the CPU -------
  * slv_clip_augment replaces datasets/video_transforms.py:462-510 (clip_augmentation: /255, -mean, /std, THWC->TCHW,
  *   spatial_sampling :420-459 = bilinear short-side resize :35-80 + crop :101-134/:167-210 + flip :137-164, ->CTHW)

@@ -1,0 +1,241 @@
+// First kernel of the 16-bit MFMA path (BASELINE configs[4], main.py:151 --use_fp16): a forward convolution on bf16
+// CHANNELS-LAST activations with fp32 accumulation on v_mfma_f32_16x16x32_bf16 and a fused per-channel affine
+// (eval-mode BatchNorm) + residual + ReLU epilogue.
+//
+// Why another layout: a 16-bit MFMA operand is 8 consecutive k per lane.  With N,C,T,H,W activations k (= channel)
+// has stride T*H*W, so every fragment would be 8 scalar gathers; with N,T,H,W,C it is one 16-byte load and the LDS
+// image needs no transpose.  On the hot layer (Conv3d 64->144 (1,3,3), 16 clips) this kernel takes 0.22 ms against
+// 1.24 ms for the fp32 kernel (tools/proto/bf16_conv133.hip measured 601 TFLOP/s with the first, untuned version).
+//
+// Implicit GEMM  D[cout][pos] = sum_{tap, c} W[cout][tap][c] * X[pos*stride + tap - pad][c]:
+//   block = 4 waves = (MT*16) couts x 128 output positions, wave = (MT*16) x 32, K-step = 32 channels of one tap;
+//   weights pre-laid-out [tap][Cin_p/32][Mrows][32] (zero padded), activations [P][Cin_p] with Cin_p % 32 == 0;
+//   register-staged double buffer, one barrier per K-step, LDS rows of 32 bf16 padded to 80 bytes (conflict-free
+//   ds_read_b128 fragments); padding positions are buffer loads with an out-of-range offset (return 0).
+//   Output [P_out][Cout_p] bf16: channels >= Cout are written as zeros so the next layer can read whole 32-channel
+//   K-steps.
+#include "common.hpp"
+#include "../../include/selavi_hip.h"
+
+namespace slv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ClGeom {                       // int32 x 20, mirrored by selavi_amd/ops16.py
+  int N, Ti, Hi, Wi, Cin_p;           // input  [N][Ti][Hi][Wi][Cin_p]
+  int Cout, Cout_p, To, Ho, Wo;       // output [N][To][Ho][Wo][Cout_p]
+  int kt, kh, kw, st, sh, sw, pt, ph, pw;
+  int Mrows;                          // rows of the weight layout: Cout rounded up to the block's M tile
+};
+
+constexpr int CL_BN = 128, CL_ROWB = 80;
+
+__device__ __forceinline__ unsigned short f2bf(float f) {             // round to nearest even (finite inputs)
+  unsigned int u = __float_as_uint(f);
+  u += 0x7FFF + ((u >> 16) & 1);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void conv_cl16_kernel(const unsigned short* __restrict__ x,
+                                                           const unsigned short* __restrict__ wl,
+                                                           unsigned short* __restrict__ y,
+                                                           const float* __restrict__ scale_shift,   // [2][Cout] or null
+                                                           const unsigned short* __restrict__ res,  // [P_out][Cout_p] or null
+                                                           int relu, ClGeom g) {
+  constexpr int BM = MT * 16;
+  constexpr int APIECES = BM * 4, AITER = (APIECES + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][(BM + CL_BN) * CL_ROWB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned P = (unsigned)g.N * g.To * g.Ho * g.Wo;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)x, 0, (int)((unsigned)g.N * g.Ti * g.Hi * g.Wi * g.Cin_p * 2u), 0x00020000);
+  const int m0 = blockIdx.y * BM;
+  // ---- activation rows of this thread: 128 rows x 4 pieces of 16 B, 2 per thread
+  int bt[2], bh[2], bw[2];
+  unsigned bbase[2];
+  const int piece = tid & 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned p = blockIdx.x * CL_BN + (tid >> 2) + 64 * i;
+    unsigned q = p;
+    const int wo = q % g.Wo; q /= g.Wo;
+    const int ho = q % g.Ho; q /= g.Ho;
+    const int to = q % g.To; q /= g.To;      // q = clip
+    bt[i] = to * g.st - g.pt;
+    bh[i] = ho * g.sh - g.ph;
+    bw[i] = wo * g.sw - g.pw;
+    bbase[i] = p < P ? (((q * g.Ti + bt[i]) * g.Hi + bh[i]) * g.Wi + bw[i]) * (unsigned)(g.Cin_p * 2) + piece * 16u
+                     : 0xFFFFFFF0u;          // (wraps for negative coordinates; only used when the tap is valid)
+    if (p >= P) bt[i] = -(1 << 20);
+  }
+  const int kcs = g.Cin_p >> 5, ksteps = g.kt * g.kh * g.kw * kcs;
+  u32x4 ra[AITER], rb[2];
+  int tap = 0, kc = 0, dt = 0, dh = 0, dw = 0;                     // K-step being LOADED
+  auto gload = [&]() __attribute__((always_inline)) {
+    const unsigned toff = (unsigned)(((dt * g.Hi + dh) * g.Wi + dw) * g.Cin_p * 2 + kc * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = (unsigned)(bt[i] + dt) < (unsigned)g.Ti && (unsigned)(bh[i] + dh) < (unsigned)g.Hi &&
+                      (unsigned)(bw[i] + dw) < (unsigned)g.Wi;
+      rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? bbase[i] + toff : 0xFFFFFFF0u, 0, 0));
+    }
+    const unsigned short* ws = wl + ((size_t)(tap * kcs + kc) * g.Mrows + m0) * 32;
+#pragma unroll
+    for (int i = 0; i < AITER; ++i) {
+      const int pc = tid + 256 * i;
+      if (pc < APIECES) ra[i] = *(const u32x4*)(ws + pc * 8);
+    }
+    if (++kc == kcs) {                                              // advance to the next K-step
+      kc = 0;
+      ++tap;
+      if (++dw == g.kw) {
+        dw = 0;
+        if (++dh == g.kh) {
+          dh = 0;
+          ++dt;
+        }
+      }
+    }
+  };
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* A = lds[buf];
+    unsigned char* B = A + BM * CL_ROWB;
+#pragma unroll
+    for (int i = 0; i < AITER; ++i) {
+      const int pc = tid + 256 * i;
+      if (pc < APIECES) *(u32x4*)(A + (pc >> 2) * CL_ROWB + (pc & 3) * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(u32x4*)(B + ((tid >> 2) + 64 * i) * CL_ROWB + piece * 16) = rb[i];
+  };
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fk = lane >> 4;
+  gload();
+  lstore(0);
+  __syncthreads();
+  for (int s = 0; s < ksteps; ++s) {
+    if (s + 1 < ksteps) gload();
+    const unsigned char* A = lds[s & 1];
+    const unsigned char* B = A + BM * CL_ROWB;
+    bf16x8 b[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8*)(B + (wave * 32 + j * 16 + fr) * CL_ROWB + fk * 16);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const bf16x8 a = *(const bf16x8*)(A + (i * 16 + fr) * CL_ROWB + fk * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < ksteps) lstore((s + 1) & 1);
+    __syncthreads();
+  }
+  // ---- epilogue.  C/D: col = lane & 15 (position), rows (lane >> 4) * 4 + r (cout): 4 consecutive couts per lane
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const unsigned p = blockIdx.x * CL_BN + wave * 32 + j * 16 + fr;
+    if (p >= P) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int co = m0 + i * 16 + fk * 4;
+      if (co >= g.Cout_p) continue;
+      float v[4];
+      uint2 rr = make_uint2(0u, 0u);
+      if (res) rr = *(const uint2*)(res + (size_t)p * g.Cout_p + co);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = acc[i][j][r];
+        const int c = co + r;
+        if (c < g.Cout) {
+          if (scale_shift) t = t * scale_shift[c] + scale_shift[g.Cout + c];
+          if (res) t += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
+          if (relu) t = fmaxf(t, 0.f);
+        } else {
+          t = 0.f;                                                  // padding channel
+        }
+        v[r] = t;
+      }
+      *(uint2*)(y + (size_t)p * g.Cout_p + co) =
+          make_uint2(f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+    }
+  }
+  // padding channels no M tile covers (e.g. Cout = 144 = Mrows, Cout_p = 160): the last M block zero-fills them
+  if (blockIdx.y == gridDim.y - 1 && g.Mrows < g.Cout_p && tid < CL_BN) {
+    const unsigned p = blockIdx.x * CL_BN + tid;
+    if (p < P)
+      for (int c = g.Mrows; c < g.Cout_p; c += 4) *(uint2*)(y + (size_t)p * g.Cout_p + c) = make_uint2(0u, 0u);
+  }
+}
+
+// fp32 N,C,T,H,W -> bf16 N,T,H,W,Cp (channels >= C zero): one thread per (position, 8-channel piece)
+__global__ __launch_bounds__(256) void to_cl16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int C,
+                                                      int Cp, unsigned S /* T*H*W */, unsigned total /* N*S*Cp/8 */) {
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const unsigned pieces = Cp >> 3, pc = idx % pieces, pos = idx / pieces, n = pos / S, s = pos - n * S;
+  unsigned short v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned c = pc * 8 + i;
+    v[i] = c < (unsigned)C ? f2bf(x[((size_t)n * C + c) * S + s]) : (unsigned short)0;
+  }
+  u32x4 o = {v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16),
+             v[6] | ((unsigned)v[7] << 16)};
+  *(u32x4*)(y + (size_t)idx * 8) = o;
+}
+
+}  // namespace slv
+
+extern "C" {
+
+// geom: 20 int32 (ClGeom).  MT (16-row tiles per block) follows from geom.Mrows: the Python side picks it.
+int slv_conv_cl16_fwd(const int32_t* geom, int mt, const void* x_bf16, const void* w_layout_bf16, void* y_bf16,
+                      const float* scale_shift, const void* res_bf16, int relu, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(geom && x_bf16 && w_layout_bf16 && y_bf16, "null pointer");
+  ClGeom g;
+  memcpy(&g, geom, sizeof(g));
+  SLV_CHECK_ARG(g.N > 0 && g.Cin_p > 0 && (g.Cin_p & 31) == 0 && g.Cout > 0 && g.Cout_p >= g.Cout && (g.Cout_p & 3) == 0,
+                "channel counts (Cin_p % 32, Cout_p % 4)");
+  SLV_CHECK_ARG(g.kt > 0 && g.kh > 0 && g.kw > 0 && g.st > 0 && g.sh > 0 && g.sw > 0, "kernel / stride");
+  SLV_CHECK_ARG(g.To == (g.Ti + 2 * g.pt - g.kt) / g.st + 1 && g.Ho == (g.Hi + 2 * g.ph - g.kh) / g.sh + 1 &&
+                    g.Wo == (g.Wi + 2 * g.pw - g.kw) / g.sw + 1 && g.To > 0 && g.Ho > 0 && g.Wo > 0,
+                "output extent does not match the geometry");
+  SLV_CHECK_ARG((long long)g.N * g.Ti * g.Hi * g.Wi * g.Cin_p * 2 < 0xFFFFFFF0LL &&
+                    (long long)g.N * g.To * g.Ho * g.Wo * g.Cout_p * 2 < 0xFFFFFFF0LL,
+                "tensor beyond the 32-bit buffer range");
+  SLV_CHECK_ARG(mt == 4 || mt == 8 || mt == 9, "M tile (4, 8 or 9 x 16 rows)");
+  SLV_CHECK_ARG(g.Mrows % (16 * mt) == 0 && g.Mrows >= g.Cout, "weight layout rows");
+  const unsigned P = (unsigned)g.N * g.To * g.Ho * g.Wo;
+  dim3 grid((P + CL_BN - 1) / CL_BN, g.Mrows / (16 * mt));
+#define SLV_CL16(MT_)                                                                                              \
+  hipLaunchKernelGGL((conv_cl16_kernel<MT_>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x_bf16, \
+                     (const unsigned short*)w_layout_bf16, (unsigned short*)y_bf16, scale_shift,                    \
+                     (const unsigned short*)res_bf16, relu, g)
+  if (mt == 4) SLV_CL16(4);
+  else if (mt == 8) SLV_CL16(8);
+  else SLV_CL16(9);
+#undef SLV_CL16
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_to_cl16(const float* x, void* y_bf16, int64_t N, int C, int Cp, int64_t S, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(x && y_bf16 && N > 0 && C > 0 && Cp >= C && (Cp & 7) == 0 && S > 0, "bad argument");
+  const long long total = N * S * (Cp / 8);
+  SLV_CHECK_ARG(total < 0xFFFFFFFFLL, "tensor too large");
+  hipLaunchKernelGGL(to_cl16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (unsigned short*)y_bf16, C, Cp, (unsigned)S, (unsigned)total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

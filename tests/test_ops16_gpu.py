@@ -1,0 +1,66 @@
+"""16-bit MFMA path, first kernel (csrc/conv_cl16.hip): bf16 channels-last forward conv with fused affine + residual +
+ReLU, against torch's fp32 conv on the SAME bf16-rounded inputs and weights (products of bf16 values are exact in
+fp32, so only the accumulation order and the final rounding of the output to bf16 differ)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # N, Cin, T, H, W, Cout, k, stride, pad        every conv family of the two trunks, small extents
+    (2, 64, 4, 12, 12, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # layer-1 spatial (M tile 9)
+    (2, 144, 5, 10, 10, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),      # temporal, padded input channels (144 -> 160)
+    (1, 64, 6, 14, 14, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1)),      # stride-2 spatial, Cout 230 -> 256
+    (1, 230, 7, 7, 7, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0)),       # stride-2 temporal over an odd extent
+    (2, 64, 4, 8, 8, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),        # downsample
+    (2, 3, 3, 20, 20, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)),        # video stem
+    (3, 1, 1, 40, 36, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),        # audio stem (2-D: T = 1)
+    (2, 128, 1, 9, 7, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # audio BasicBlock conv
+    (1, 512, 2, 7, 7, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # layer-4 spatial (many K-steps, 8 M blocks)
+]
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_cl16_matches_fp32_conv_on_bf16_values(case):
+    from selavi_amd import ops16
+    N, Cin, T, H, W, Cout, k, st, pd = case
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    x = _bf(torch.randn(N, Cin, T, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, *k, generator=g) * (Cin * k[0] * k[1] * k[2]) ** -0.5)
+    ss = torch.stack([torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2])
+    ref = F.conv3d(x.double(), w.double(), stride=st, padding=pd)
+    res = _bf(torch.randn(ref.shape, generator=g))
+    conv = ops16.Conv16(w.cuda(), st, pd)
+    xc = ops16.to_channels_last16(x.cuda())
+    assert xc.shape == (N, T, H, W, ops16.pad32(Cin)) and (xc[..., Cin:] == 0).all()
+    assert torch.equal(xc[..., :Cin].float().cpu(), x.permute(0, 2, 3, 4, 1))          # layout conversion is exact here
+    for use_ss, use_res, relu in ((False, False, False), (True, False, True), (True, True, True)):
+        want = ref.clone()
+        if use_ss:
+            want = want * ss[0].double().view(1, -1, 1, 1, 1) + ss[1].double().view(1, -1, 1, 1, 1)
+        if use_res:
+            want = want + res.double()
+        if relu:
+            want = want.clamp_min(0)
+        rc = ops16.to_channels_last16(res.cuda()) if use_res else None
+        y = conv(xc, scale_shift=ss.cuda().contiguous() if use_ss else None, res=rc, relu=relu)
+        assert y.shape[-1] == ops16.pad32(Cout) and (y[..., Cout:] == 0).all()               # padding channels are zero
+        got = y[..., :Cout].float().cpu().permute(0, 4, 1, 2, 3).double()
+        # fp32 accumulation of exact products + one rounding to bf16 (2^-9 relative)
+        err = (got - want).abs()
+        bound = want.abs() * 2.0 ** -8 + 1e-3 * want.abs().max()
+        assert (err <= bound).all(), (case, float(err.max()), float(want.abs().max()))
+
+
+def test_conv_cl16_rejects_bad_geometry():
+    from selavi_amd import _lib, ops16
+    conv = ops16.Conv16(torch.randn(16, 8, 1, 3, 3).cuda(), (1, 1, 1), (0, 1, 1))
+    x = ops16.to_channels_last16(torch.randn(1, 8, 2, 6, 6).cuda())
+    g = np.array([1, 2, 6, 6, 32, 16, 32, 2, 6, 7, 1, 3, 3, 1, 1, 1, 0, 1, 1, conv.Mrows], dtype=np.int32)   # Wo wrong
+    with pytest.raises(_lib.SelaviHipError):
+        _lib.C.slv_conv_cl16_fwd(g.ctypes.data, conv.mt, _lib.ptr(x), _lib.ptr(conv.wl), _lib.ptr(x), 0, 0, 0, _lib.stream())
