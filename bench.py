@@ -167,6 +167,22 @@ def sk_round_estimate(m, dev, world, step_clips_per_s, sk):
                 m(video, audio)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / 3 * 1e3
+        # opt-in alternative (NOT the bit-exact path): the same pass in bf16 on the channels-last MFMA kernels
+        rate16 = None
+        try:
+            from selavi_amd import infer16
+            eng = infer16.Engine(m)
+            eng.features(video, audio)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                eng.features(video, audio)
+            torch.cuda.synchronize()
+            rate16 = B / ((time.perf_counter() - t0) / 3)
+            del eng
+        except Exception as e:                     # experimental path: never take the bench line down with it
+            rate16 = None
+            print(f"bf16 feature pass not measured: {e!r}", file=sys.stderr)
     finally:
         m.return_features = False
         m.train()
@@ -179,7 +195,13 @@ def sk_round_estimate(m, dev, world, step_clips_per_s, sk):
             "sk_solve_s": t_sk, "round_s": t_feat + t_sk, "training_between_rounds_s": t_train,
             "fraction_of_wall_clock": (t_feat + t_sk) / (t_feat + t_sk + t_train),
             "clips_per_s_including_sk": step_clips_per_s * t_train / (t_feat + t_sk + t_train),
-            "assumes": f"N={N}, hc={hc}, {rounds} rounds over {epochs} epochs, ind_groups=1, {its} SK iterations per head"}
+            "assumes": f"N={N}, hc={hc}, {rounds} rounds over {epochs} epochs, ind_groups=1, {its} SK iterations per head",
+            "bf16_feature_pass_opt_in": None if rate16 is None else {
+                "feature_pass_clips_per_s_per_gpu": rate16,
+                "hbm_roofline_frac": rate16 * FWD_MB_PER_CLIP / 2 / 1e3 / PEAK_HBM_GBS,
+                "clips_per_s_including_sk": step_clips_per_s * t_train / (N / (rate16 * world) + t_sk + t_train),
+                "note": "SELAVI_FEATURE_PASS=bf16 / args.feature_pass: eval forward on bf16 channels-last activations "
+                        "(selavi_amd/infer16.py); features within ~5e-3 of fp32, labels not bit-exact; off by default"}}
 
 
 def cpu_baseline(batch):

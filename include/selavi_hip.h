@@ -268,6 +268,9 @@ int slv_contingency(const int64_t* pred, const int64_t* target, int64_t N, int K
 int slv_conv_cl16_fwd(const int32_t* geom, int mt, const void* x_bf16, const void* w_layout_bf16, void* y_bf16,
                       const float* scale_shift, const void* res_bf16, int relu, slv_stream_t stream);
 int slv_to_cl16(const float* x, void* y_bf16, int64_t N, int C, int Cp, int64_t S, slv_stream_t stream);
+/* MaxPool2d(3, 2, 1) on [N][H][W][Cp] bf16; AdaptiveAvgPool(1)+flatten: [N][S][Cp] bf16 -> fp32 [N][C] */
+int slv_maxpool_cl16(const void* x_bf16, void* y_bf16, int64_t N, int H, int W, int Cp, slv_stream_t stream);
+int slv_avgpool_cl16(const void* x_bf16, float* y, int64_t N, int64_t S, int C, int Cp, slv_stream_t stream);
 
 /* ---- input pipeline: what the reference's DataLoader workers compute per clip on the CPU -------
  * slv_clip_augment replaces datasets/video_transforms.py:462-510 (clip_augmentation: /255, -mean, /std, THWC->TCHW,

@@ -191,6 +191,48 @@ __global__ __launch_bounds__(256) void to_cl16_kernel(const float* __restrict__ 
   *(u32x4*)(y + (size_t)idx * 8) = o;
 }
 
+
+// MaxPool2d(3, stride 2, pad 1) on bf16 channels-last [N][H][W][Cp] (audio trunk, model.py:114 -> torchvision ResNet):
+// one thread per (output position, 8-channel piece)
+__global__ __launch_bounds__(256) void maxpool_cl16_kernel(const unsigned short* __restrict__ x,
+                                                           unsigned short* __restrict__ y, int H, int W, int Ho, int Wo,
+                                                           int Cp, unsigned total) {
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const unsigned pieces = Cp >> 3, pc = idx % pieces;
+  unsigned q = idx / pieces;
+  const int wo = q % Wo; q /= Wo;
+  const int ho = q % Ho; q /= Ho;                 // q = image
+  float m[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+  for (int dh = 0; dh < 3; ++dh)
+    for (int dw = 0; dw < 3; ++dw) {
+      const int h = ho * 2 - 1 + dh, w = wo * 2 - 1 + dw;
+      if ((unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) continue;
+      const u32x4 v = *(const u32x4*)(x + (((size_t)q * H + h) * W + w) * Cp + pc * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        m[2 * i] = fmaxf(m[2 * i], bf2f((unsigned short)(v[i] & 0xFFFF)));
+        m[2 * i + 1] = fmaxf(m[2 * i + 1], bf2f((unsigned short)(v[i] >> 16)));
+      }
+    }
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = f2bf(m[2 * i]) | ((unsigned)f2bf(m[2 * i + 1]) << 16);
+  *(u32x4*)(y + (size_t)idx * 8) = o;
+}
+
+// AdaptiveAvgPool(1) + flatten: bf16 [N][S][Cp] -> fp32 [N][C]; one wave per (clip, 64 channels), fixed order
+__global__ __launch_bounds__(64) void avgpool_cl16_kernel(const unsigned short* __restrict__ x, float* __restrict__ y,
+                                                          int S, int C, int Cp) {
+  const int n = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += bf2f(x[((size_t)n * S + s) * Cp + c]);
+  y[(size_t)n * C + c] = acc / (float)S;
+}
+
 }  // namespace slv
 
 extern "C" {
@@ -234,6 +276,27 @@ int slv_to_cl16(const float* x, void* y_bf16, int64_t N, int C, int Cp, int64_t 
   SLV_CHECK_ARG(total < 0xFFFFFFFFLL, "tensor too large");
   hipLaunchKernelGGL(to_cl16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
                      (unsigned short*)y_bf16, C, Cp, (unsigned)S, (unsigned)total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_maxpool_cl16(const void* x_bf16, void* y_bf16, int64_t N, int H, int W, int Cp, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(x_bf16 && y_bf16 && N > 0 && H > 0 && W > 0 && Cp > 0 && (Cp & 7) == 0, "bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long total = N * Ho * Wo * (Cp / 8);
+  SLV_CHECK_ARG(total < 0xFFFFFFFFLL, "tensor too large");
+  hipLaunchKernelGGL(maxpool_cl16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x_bf16, (unsigned short*)y_bf16, H, W, Ho, Wo, Cp, (unsigned)total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_avgpool_cl16(const void* x_bf16, float* y, int64_t N, int64_t S, int C, int Cp, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(x_bf16 && y && N > 0 && N <= 65535 && S > 0 && C > 0 && Cp >= C, "bad argument");
+  hipLaunchKernelGGL(avgpool_cl16_kernel, dim3((C + 63) / 64, (unsigned)N), dim3(64), 0, (hipStream_t)stream,
+                     (const unsigned short*)x_bf16, y, (int)S, C, Cp);
   SLV_LAUNCH_CHECK();
   return 0;
 }

@@ -14,6 +14,7 @@ sharded over the ranks of that process group: one all-reduce of
 iteration over RCCL, labels stay local to the shard.
 """
 import math
+import os
 import time
 
 import torch
@@ -335,6 +336,12 @@ def get_cluster_assignments_gpu(args, dataset, model, logger=None, writer=None, 
     np.random.shuffle(order_heads)                                                     # :191-192
     bs = 64                                                                            # :168
     idx_local = torch.arange(lo, lo + local_n)
+    # opt-in: the feature pass in bf16 on the channels-last MFMA kernels (selavi_amd/infer16.py, ~3x faster; the
+    # features are NOT the bit-exact fp32 ones -- the default stays fp32).  args.feature_pass or SELAVI_FEATURE_PASS
+    engine16 = None
+    if (getattr(args, "feature_pass", None) or os.environ.get("SELAVI_FEATURE_PASS", "fp32")) == "bf16":
+        from . import infer16
+        engine16 = infer16.Engine(net)
     for hd_grp_idx in range(args.ind_groups):                                          # :194
         # 1. feature pass over this rank's slice (every head group re-runs it: "decorrelated heads")
         order = idx_local[torch.randperm(local_n)] if getattr(args, "shuffle_sk_pass", True) else idx_local
@@ -347,7 +354,15 @@ def get_cluster_assignments_gpu(args, dataset, model, logger=None, writer=None, 
             video = torch.stack([b[0] for b in batch]).to(dev, non_blocking=True)
             audio = torch.stack([b[1] for b in batch]).to(dev, non_blocking=True)
             idx = torch.as_tensor([int(b[3]) for b in batch], device=dev)
-            feat_v, feat_a = model(video, audio)                                       # :206
+            if engine16 is None:
+                feat_v, feat_a = model(video, audio)                                   # :206
+            else:
+                feat_v, feat_a = engine16.features(video, audio)
+                if hc == 1:                                                            # :207-211: the bank holds logits
+                    feat_v, feat_a = net.mlp_v.forward(feat_v), net.mlp_a.forward(feat_a)
+                    if net.norm_feat:                                                  # model.py:236-239
+                        feat_v = torch.nn.functional.normalize(feat_v, p=2, dim=1)
+                        feat_a = torch.nn.functional.normalize(feat_a, p=2, dim=1)
             if feat_v.dim() == 1:
                 feat_v, feat_a = feat_v.unsqueeze(0), feat_a.unsqueeze(0)
             if bank_v is None:
