@@ -40,7 +40,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {             // round t
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
 template <int MT>
-__global__ __launch_bounds__(256, 2) void conv_cl16_kernel(const unsigned short* __restrict__ x,
+__global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const unsigned short* __restrict__ x,
                                                            const unsigned short* __restrict__ wl,
                                                            unsigned short* __restrict__ y,
                                                            const float* __restrict__ scale_shift,   // [2][Cout] or null

@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--only16", action="store_true", help="skip the fp32 leg (for profiling)")
     a = ap.parse_args()
     from selavi_amd import infer16, model as smodel, ops
     ops.set_benchmark(True)
@@ -40,7 +41,7 @@ def main():
             torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3
 
-    ms32 = timeit(lambda: m(video, audio))
+    ms32 = float('nan') if a.only16 else timeit(lambda: m(video, audio))
     ms16 = timeit(lambda: eng.features(video, audio))
     msv = timeit(lambda: eng.video_features(video))
     gf, mb = (81.04 * a.frames / 16 + 0.506) * a.batch, (518.1 * a.frames / 16 + 3.38) / 2 * a.batch   # bf16: half the bytes
