@@ -192,6 +192,29 @@ __global__ __launch_bounds__(256) void to_cl16_kernel(const float* __restrict__ 
 }
 
 
+// Stem input: fp32 N,C,T,H,W -> bf16 [N][T][H][Wo][32] where the 32 "channels" of an output column wo are the
+// kw x C input values of its receptive row (index dw*C + c, zero beyond kw*C and outside the image).  A (1,kh,kw)
+// stem conv over C = 3 (or 1) channels then runs as a (1,kh,1) conv over 32 channels: kh K-steps instead of kh*kw with
+// 3 of 32 channels used, and the converted input is half the size of a 32-channel padded copy.
+__global__ __launch_bounds__(256) void to_cl16_wpatch_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
+                                                             int C, unsigned TH, int W, int Wo, int kw, int sw, int pw,
+                                                             unsigned total /* N*TH*Wo*4 pieces */) {
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const unsigned pc = idx & 3, q = idx >> 2, wo = q % Wo, row = q / Wo, n = row / TH, th = row - n * TH;
+  unsigned short v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = pc * 8 + i, dw = k / C, c = k - dw * C, w = (int)wo * sw - pw + dw;
+    float f = 0.f;
+    if (dw < kw && (unsigned)w < (unsigned)W) f = x[(((size_t)n * C + c) * TH + th) * W + w];
+    v[i] = f2bf(f);
+  }
+  u32x4 o = {v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16),
+             v[6] | ((unsigned)v[7] << 16)};
+  *(u32x4*)(y + (size_t)idx * 8) = o;
+}
+
 // MaxPool2d(3, stride 2, pad 1) on bf16 channels-last [N][H][W][Cp] (audio trunk, model.py:114 -> torchvision ResNet):
 // one thread per (output position, 8-channel piece)
 __global__ __launch_bounds__(256) void maxpool_cl16_kernel(const unsigned short* __restrict__ x,
@@ -297,6 +320,20 @@ int slv_avgpool_cl16(const void* x_bf16, float* y, int64_t N, int64_t S, int C, 
   SLV_CHECK_ARG(x_bf16 && y && N > 0 && N <= 65535 && S > 0 && C > 0 && Cp >= C, "bad argument");
   hipLaunchKernelGGL(avgpool_cl16_kernel, dim3((C + 63) / 64, (unsigned)N), dim3(64), 0, (hipStream_t)stream,
                      (const unsigned short*)x_bf16, y, (int)S, C, Cp);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_to_cl16_wpatch(const float* x, void* y_bf16, int64_t N, int C, int64_t TH, int W, int kw, int sw, int pw,
+                       slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(x && y_bf16 && N > 0 && C > 0 && TH > 0 && W > 0 && kw > 0 && sw > 0 && kw * C <= 32,
+                "bad argument (kw * C must fit 32)");
+  const int Wo = (W + 2 * pw - kw) / sw + 1;
+  const long long total = N * TH * Wo * 4;
+  SLV_CHECK_ARG(Wo > 0 && total < 0xFFFFFFFFLL && TH < 0x7FFFFFFFLL, "tensor too large");
+  hipLaunchKernelGGL(to_cl16_wpatch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (unsigned short*)y_bf16, C, (unsigned)TH, W, Wo, kw, sw, pw, (unsigned)total);
   SLV_LAUNCH_CHECK();
   return 0;
 }

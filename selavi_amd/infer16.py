@@ -32,12 +32,21 @@ class _Layer:
         return self.conv(x, scale_shift=self.ss, res=res, relu=relu)
 
 
+class _Stem:
+    def __init__(self, conv, bn):
+        self.conv = ops16.StemConv16(conv.weight.detach(), conv.stride3, conv.padding3)
+        self.ss = _affine(bn)
+
+    def __call__(self, x):
+        return self.conv(x, scale_shift=self.ss, relu=True)
+
+
 class Engine:
     def __init__(self, model):
         m = model.module if hasattr(model, "module") else model
         v, a = m.video_network.base, m.audio_network.base
         with torch.no_grad():
-            self.v_stem = [_Layer(v.stem[0], v.stem[1]), _Layer(v.stem[3], v.stem[4])]
+            self.v_stem = [_Stem(v.stem[0], v.stem[1]), _Layer(v.stem[3], v.stem[4])]
             self.v_blocks = []
             for li in range(1, 5):
                 for blk in getattr(v, f"layer{li}"):
@@ -46,7 +55,7 @@ class Engine:
                              _Layer(c2[0][0], c2[0][1]), _Layer(c2[0][3], c2[1])]
                     ds = _Layer(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
                     self.v_blocks.append((chain, ds))
-            self.a_stem = _Layer(a.conv1, a.bn1)
+            self.a_stem = _Stem(a.conv1, a.bn1)
             self.a_blocks = []
             for li in range(1, 5):
                 for blk in getattr(a, f"layer{li}"):
@@ -62,9 +71,7 @@ class Engine:
 
     @torch.no_grad()
     def video_features(self, video):
-        x = ops16.to_channels_last16(video)
-        for l in self.v_stem:
-            x = l(x)
+        x = self.v_stem[1](self.v_stem[0](video))               # the stem's first conv converts the fp32 clip itself
         for chain, ds in self.v_blocks:
             y = x
             for l in chain[:-1]:
@@ -75,7 +82,7 @@ class Engine:
 
     @torch.no_grad()
     def audio_features(self, spec):
-        x = self.a_stem(ops16.to_channels_last16(spec))
+        x = self.a_stem(spec)
         N, _, H, W, Cp = x.shape
         y = torch.empty((N, 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cp), dtype=torch.bfloat16, device=x.device)
         C.slv_maxpool_cl16(ptr(x), ptr(y), N, H, W, Cp, stream())

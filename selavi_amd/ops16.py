@@ -69,3 +69,31 @@ class Conv16:
         C.slv_conv_cl16_fwd(g.ctypes.data, self.mt, ptr(x), ptr(self.wl), ptr(y), ptr(scale_shift), ptr(res), int(relu),
                             stream())
         return y
+
+
+class StemConv16:
+    """A (1, kh, kw) stem conv over C <= 4 input channels (video: 3 -> 45, (1,7,7); audio: 1 -> 64, 7x7) as a
+    (1, kh, 1) conv over the 32-channel W-patch layout of slv_to_cl16_wpatch: kh K-steps instead of kh*kw."""
+
+    def __init__(self, w, stride, pad):
+        if w.dim() == 4:
+            w = w.unsqueeze(2)
+        Cout, Cin, kt, kh, kw = w.shape
+        assert kt == 1 and stride[0] == 1 and pad[0] == 0 and kw * Cin <= 32
+        self.Cin, self.kw, self.sw, self.pw = Cin, kw, stride[2], pad[2]
+        w2 = torch.zeros((Cout, 32, 1, kh, 1), dtype=torch.float32, device=w.device)
+        # patch channel dw*Cin + c  <-  w[:, c, 0, :, dw]
+        w2[:, :kw * Cin, 0, :, 0] = w[:, :, 0].permute(0, 3, 1, 2).reshape(Cout, kw * Cin, kh)
+        self.conv = Conv16(w2, (1, stride[1], 1), (0, pad[1], 0))
+
+    def __call__(self, x, scale_shift=None, relu=False):
+        """x: fp32 N,C,T,H,W (or N,C,H,W)."""
+        if x.dim() == 4:
+            x = x.unsqueeze(2)
+        x = x.contiguous()
+        N, Cc, T, H, W = x.shape
+        assert Cc == self.Cin
+        Wo = (W + 2 * self.pw - self.kw) // self.sw + 1
+        p = torch.empty((N, T, H, Wo, 32), dtype=torch.bfloat16, device=x.device)
+        C.slv_to_cl16_wpatch(ptr(x), ptr(p), N, Cc, T * H, W, self.kw, self.sw, self.pw, stream())
+        return self.conv(p, scale_shift=scale_shift, relu=relu)

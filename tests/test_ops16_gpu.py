@@ -64,3 +64,21 @@ def test_conv_cl16_rejects_bad_geometry():
     g = np.array([1, 2, 6, 6, 32, 16, 32, 2, 6, 7, 1, 3, 3, 1, 1, 1, 0, 1, 1, conv.Mrows], dtype=np.int32)   # Wo wrong
     with pytest.raises(_lib.SelaviHipError):
         _lib.C.slv_conv_cl16_fwd(g.ctypes.data, conv.mt, _lib.ptr(x), _lib.ptr(conv.wl), _lib.ptr(x), 0, 0, 0, _lib.stream())
+
+
+@pytest.mark.parametrize("case", [(2, 3, 3, 20, 22, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
+                                  (3, 1, 1, 40, 37, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3))])
+def test_stem_conv_on_the_w_patch_layout(case):
+    """StemConv16: the 7x7 stems (3 or 1 input channels) as a (1,7,1) conv over the 32-channel W-patch layout."""
+    from selavi_amd import ops16
+    N, Cin, T, H, W, Cout, k, st, pd = case
+    g = torch.Generator().manual_seed(7)
+    x = _bf(torch.randn(N, Cin, T, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, *k, generator=g) * 0.1)
+    ss = torch.stack([torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2])
+    want = F.conv3d(x.double(), w.double(), stride=st, padding=pd)
+    want = (want * ss[0].double().view(1, -1, 1, 1, 1) + ss[1].double().view(1, -1, 1, 1, 1)).clamp_min(0)
+    y = ops16.StemConv16(w.cuda(), st, pd)(x.cuda(), scale_shift=ss.cuda().contiguous(), relu=True)
+    got = y[..., :Cout].float().cpu().permute(0, 4, 1, 2, 3).double()
+    assert got.shape == want.shape and (y[..., Cout:] == 0).all()
+    assert ((got - want).abs() <= want.abs() * 2.0 ** -8 + 1e-3 * want.abs().max()).all()
