@@ -54,7 +54,11 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
                                                            int relu, ClGeom g) {
   constexpr int BM = MT * 16;
   constexpr int APIECES = BM * 4, AITER = (APIECES + 255) / 256;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][(BM + CL_BN) * CL_ROWB];
+  constexpr int OROW = BM * 2 + 16;                   // bytes per position row of the transposed output tile (+16: banks)
+  constexpr int STAGE = (BM + CL_BN) * CL_ROWB;
+  constexpr int LDSB = 2 * STAGE > CL_BN * OROW + 2 * BM * 4 ? 2 * STAGE : CL_BN * OROW + 2 * BM * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDSB];
+  unsigned char(*lds)[STAGE] = (unsigned char(*)[STAGE])lds_raw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned P = (unsigned)g.N * g.To * g.Ho * g.Wo;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -144,10 +148,13 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
     if (s + 1 < ksteps) lstore((s + 1) & 1);
     __syncthreads();
   }
-  // ---- epilogue.  C/D: col = lane & 15 (position), rows (lane >> 4) * 4 + r (cout): 4 consecutive couts per lane.
-  // The block's scale / shift rows go through LDS once (the K loop is done with it): two ds_read_b128 per M tile
-  // instead of eight global loads per accumulator.
-  float* ssl = (float*)lds[0];                          // [2][BM]
+  // ---- epilogue.  C/D: col = lane & 15 (position), rows (lane >> 4) * 4 + r (cout): 4 consecutive couts per lane, i.e.
+  // 8-byte pieces 320 bytes apart across lanes -- stored like that they cost a quarter of the forward (ablation).  The
+  // tile is transposed through LDS instead: [position][cout] rows, then 16-byte stores that run along a position's
+  // channels (288 contiguous bytes per row for the 144-channel tile).  scale / shift also come through LDS.
+  __syncthreads();                                      // the K loop's last fragment reads are done
+  unsigned char* ot = lds_raw;                          // [CL_BN][OROW]
+  float* ssl = (float*)(lds_raw + CL_BN * OROW);        // [2][BM]
   if (scale_shift) {
     for (int i = tid; i < 2 * BM; i += 256) {
       const int c = m0 + (i % BM);
@@ -158,7 +165,6 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int co = m0 + i * 16 + fk * 4;
-    if (co >= g.Cout_p) continue;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (scale_shift) {
       sc = *(const f32x4*)(ssl + i * 16 + fk * 4);
@@ -166,10 +172,10 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const unsigned p = blockIdx.x * CL_BN + wave * 32 + j * 16 + fr;
-      if (p >= P) continue;
+      const int pl = wave * 32 + j * 16 + fr;             // position inside the block
+      const unsigned p = blockIdx.x * CL_BN + pl;
       uint2 rr = make_uint2(0u, 0u);
-      if (res) rr = *(const uint2*)(res + (size_t)p * g.Cout_p + co);
+      if (res && p < P && co < g.Cout_p) rr = *(const uint2*)(res + (size_t)p * g.Cout_p + co);
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -178,15 +184,23 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
         if (relu) t = fmaxf(t, 0.f);
         v[r] = (co + r < g.Cout) ? t : 0.f;                         // padding channels stay zero
       }
-      *(uint2*)(y + (size_t)p * g.Cout_p + co) =
+      *(uint2*)(ot + pl * OROW + (i * 16 + fk * 4) * 2) =
           make_uint2(f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
     }
   }
-  // padding channels no M tile covers (e.g. Cout = 144 = Mrows, Cout_p = 160): the last M block zero-fills them
-  if (blockIdx.y == gridDim.y - 1 && g.Mrows < g.Cout_p && tid < CL_BN) {
-    const unsigned p = blockIdx.x * CL_BN + tid;
-    if (p < P)
-      for (int c = g.Mrows; c < g.Cout_p; c += 4) *(uint2*)(y + (size_t)p * g.Cout_p + c) = make_uint2(0u, 0u);
+  __syncthreads();
+  // rows of this block in the output: channels [m0, m0 + BM) clipped to Cout_p; the last M block also zero-fills the
+  // padding channels no M tile covers (Mrows < Cout_p)
+  const int c_lo = m0, c_hi = min(m0 + BM, g.Cout_p);
+  const int c_end = (blockIdx.y == gridDim.y - 1) ? g.Cout_p : c_hi;
+  const int pieces = (c_end - c_lo) >> 3;                 // 16-byte pieces per position (channel counts are multiples of 8)
+  for (int idx = tid; idx < CL_BN * pieces; idx += 256) {
+    const int pl = idx / pieces, pc = idx - pl * pieces;
+    const unsigned p = blockIdx.x * CL_BN + pl;
+    if (p >= P) continue;
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (c_lo + pc * 8 < c_hi) val = *(const u32x4*)(ot + pl * OROW + pc * 16);
+    *(u32x4*)(y + (size_t)p * g.Cout_p + c_lo + pc * 8) = val;
   }
 }
 
@@ -283,8 +297,8 @@ int slv_conv_cl16_fwd(const int32_t* geom, int mt, const void* x_bf16, const voi
   SLV_CHECK_ARG(geom && x_bf16 && w_layout_bf16 && y_bf16, "null pointer");
   ClGeom g;
   memcpy(&g, geom, sizeof(g));
-  SLV_CHECK_ARG(g.N > 0 && g.Cin_p > 0 && (g.Cin_p & 31) == 0 && g.Cout > 0 && g.Cout_p >= g.Cout && (g.Cout_p & 3) == 0,
-                "channel counts (Cin_p % 32, Cout_p % 4)");
+  SLV_CHECK_ARG(g.N > 0 && g.Cin_p > 0 && (g.Cin_p & 31) == 0 && g.Cout > 0 && g.Cout_p >= g.Cout && (g.Cout_p & 7) == 0,
+                "channel counts (Cin_p % 32, Cout_p % 8)");
   SLV_CHECK_ARG(g.kt > 0 && g.kh > 0 && g.kw > 0 && g.st > 0 && g.sh > 0 && g.sw > 0, "kernel / stride");
   SLV_CHECK_ARG(g.To == (g.Ti + 2 * g.pt - g.kt) / g.st + 1 && g.Ho == (g.Hi + 2 * g.ph - g.kh) / g.sh + 1 &&
                     g.Wo == (g.Wi + 2 * g.pw - g.kw) / g.sw + 1 && g.To > 0 && g.Ho > 0 && g.Wo > 0,
