@@ -29,10 +29,21 @@ def get_cluster_assignments_gpu(args, dataset, model, logger=None, device="cuda"
     if hc > 1:
         m.return_features = True                                              # :92-94
     fv, fa, lab = [], [], []
+    engine16 = None                                                           # opt-in bf16 forward (infer16.py), as in cluster()
+    if (getattr(args, "feature_pass", None) or os.environ.get("SELAVI_FEATURE_PASS", "fp32")) == "bf16":
+        from . import infer16
+        engine16 = infer16.Engine(m)
     try:
         for batch in loader:
             video, audio, label = batch[0].cuda(non_blocking=True), batch[1].cuda(non_blocking=True), batch[2].cuda()
-            v, a = model(video, audio)
+            if engine16 is None:
+                v, a = model(video, audio)
+            else:
+                v, a = engine16.features(video, audio)
+                if hc == 1:
+                    v, a = m.mlp_v.forward(v), m.mlp_a.forward(a)
+                    if m.norm_feat:
+                        v, a = torch.nn.functional.normalize(v, p=2, dim=1), torch.nn.functional.normalize(a, p=2, dim=1)
             if hc == 1:
                 v, a = v.double(), a.double()                                 # the reference's DoubleTensor bank (:95-96)
             fv.append(v), fa.append(a), lab.append(label.long())

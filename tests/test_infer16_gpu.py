@@ -91,3 +91,26 @@ def test_cluster_round_with_bf16_feature_pass(hc):
     print(f"hc={hc}: SK pseudo-label agreement bf16 vs fp32 feature pass: {agree:.3f}")
     assert l16.shape == (128, hc) and agree >= 0.9
     assert m.training
+
+
+def test_eval_dump_with_bf16_feature_pass(tmp_path):
+    """get_clusters.get_cluster_assignments_gpu honours args.feature_pass too: head logits from bf16 features track the
+    fp32 dump."""
+    import argparse
+    from selavi_amd import get_clusters
+    from selavi_amd.data import SyntheticAVDataset
+    ds = SyntheticAVDataset(n=16, T=4, S=32, F=40, Tp=36, n_classes=6)
+    m = _model(hc=2, K=6).train()
+    with torch.no_grad():
+        for _ in range(2):
+            m(torch.stack([ds[i][0] for i in range(8)]).cuda(), torch.stack([ds[i][1] for i in range(8)]).cuda())
+
+    def dump(fp):
+        a = argparse.Namespace(world_size=1, rank=0, batch_size=8, workers=0, headcount=2, output_dir=None, exp_desc="x",
+                               feature_pass=fp)
+        return get_clusters.get_cluster_assignments_gpu(a, ds, m)
+    p32, p16 = dump(None), dump("bf16")
+    for h in range(2):
+        rel = ((p16[0][h] - p32[0][h]).norm() / p32[0][h].norm()).item()
+        assert rel <= 3e-2, rel
+    assert torch.equal(p16[1], p32[1])
