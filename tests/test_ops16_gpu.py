@@ -82,3 +82,33 @@ def test_stem_conv_on_the_w_patch_layout(case):
     got = y[..., :Cout].float().cpu().permute(0, 4, 1, 2, 3).double()
     assert got.shape == want.shape and (y[..., Cout:] == 0).all()
     assert ((got - want).abs() <= want.abs() * 2.0 ** -8 + 1e-3 * want.abs().max()).all()
+
+
+def test_conv_cl16_random_geometries():
+    """Property sweep: random shapes (ragged position counts, every M tile, channel counts that pad differently on the
+    input and output side, strides 1/2, kernels up to 3x3x3) against torch's fp32 conv on the same bf16 values."""
+    from selavi_amd import ops16
+    rng = np.random.RandomState(20)
+    n_done = 0
+    while n_done < 24:
+        k = tuple(int(v) for v in rng.choice([1, 3], size=3))
+        st = tuple(int(v) for v in rng.choice([1, 2], size=3))
+        pd = tuple(int(rng.randint(0, kk // 2 + 1)) for kk in k)
+        N, T, H, W = int(rng.randint(1, 4)), int(rng.randint(1, 6)), int(rng.randint(3, 15)), int(rng.randint(3, 15))
+        if any((d + 2 * p - kk) // s + 1 <= 0 or d + 2 * p < kk for d, p, kk, s in zip((T, H, W), pd, k, st)):
+            continue
+        Cin = int(rng.choice([1, 3, 16, 45, 64, 144, 230]))
+        Cout = int(rng.choice([8, 45, 64, 128, 144, 230, 300]))
+        g = torch.Generator().manual_seed(n_done)
+        x = _bf(torch.randn(N, Cin, T, H, W, generator=g))
+        w = _bf(torch.randn(Cout, Cin, *k, generator=g) * (Cin * k[0] * k[1] * k[2]) ** -0.5)
+        ss = torch.stack([torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2])
+        want = F.conv3d(x.double(), w.double(), stride=st, padding=pd)
+        want = (want * ss[0].double().view(1, -1, 1, 1, 1) + ss[1].double().view(1, -1, 1, 1, 1)).clamp_min(0)
+        y = ops16.Conv16(w.cuda(), st, pd)(ops16.to_channels_last16(x.cuda()), scale_shift=ss.cuda().contiguous(), relu=True)
+        got = y[..., :Cout].float().cpu().permute(0, 4, 1, 2, 3).double()
+        assert got.shape == want.shape, (k, st, pd, N, T, H, W, Cin, Cout)
+        assert (y[..., Cout:] == 0).all()
+        err = (got - want).abs()
+        assert (err <= want.abs() * 2.0 ** -8 + 1e-3 * want.abs().max() + 1e-6).all(), (k, st, pd, N, T, H, W, Cin, Cout, float(err.max()))
+        n_done += 1
