@@ -113,10 +113,10 @@ def sk_bench(rank, world, dev, iters=50):
         if world == 1:
             be.iterate(P, beta, r, 0.0, 10 ** 9, k, ws, grid)
         else:
+            sv = be.s_view(ws, K, grid)
             for _ in range(k):
-                be.pass_(P, N, beta, ws, grid)
-                be.local_reduce(K, ws, grid)
-                dist.all_reduce(be.s_view(ws, K, grid), group=grp)
+                be.pass_reduce(P, N, beta, ws, grid)
+                dist.all_reduce(sv, group=grp)
                 be.update(r, K, 0.0, 10 ** 9, False, ws, grid)
     be.begin(P, N, beta, ws, grid)
     be.local_reduce(K, ws, grid)

@@ -70,6 +70,9 @@ int slv_sk_begin(const double* P, int64_t N_local, int64_t N_global, int K, doub
 int slv_sk_pass(const double* P, int64_t N_local, int64_t N_global, int K, double* beta,
                 void* ws, int grid, slv_stream_t stream);
 int slv_sk_local_reduce(int K, void* ws, int grid, slv_stream_t stream);
+/* slv_sk_pass followed by slv_sk_local_reduce in one call (the sharded multi-GPU loop is host-enqueue bound) */
+int slv_sk_pass_reduce(const double* P, int64_t N_local, int64_t N_global, int K, double* beta, void* ws,
+                       int grid, slv_stream_t stream);
 int slv_sk_update(const double* r /* K, normalised */, int K, double tol, int max_iter,
                   int first /* 1: right after slv_sk_begin (no counter++) */, void* ws, int grid,
                   slv_stream_t stream);

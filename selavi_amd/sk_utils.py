@@ -68,6 +68,10 @@ class HipSkBackend:
     def local_reduce(self, K, ws, grid):
         C.slv_sk_local_reduce(K, ptr(ws), grid, stream())
 
+    def pass_reduce(self, P, N_global, beta, ws, grid):
+        N, K = P.shape
+        C.slv_sk_pass_reduce(ptr(P), N, N_global, K, ptr(beta), ptr(ws), grid, stream())
+
     def update(self, r, K, tol, max_iter, first, ws, grid):
         C.slv_sk_update(ptr(r), K, float(tol), int(max_iter), int(first), ptr(ws), grid, stream())
 
@@ -154,10 +158,15 @@ def sinkhorn(P, r, lamb, N_global=None, group=None, backend=None, tol=1e-1, max_
             if group is None:
                 be.iterate(P, beta, r, tol, max_iter, batch, ws, grid)
             else:
+                fused = getattr(be, "pass_reduce", None)        # one host call instead of two (optional in a backend)
+                sv = be.s_view(ws, K, grid)
                 for _ in range(batch):
-                    be.pass_(P, N_global, beta, ws, grid)
-                    be.local_reduce(K, ws, grid)
-                    _allreduce(be.s_view(ws, K, grid), group)  # K col sums + err in one message
+                    if fused is not None:
+                        fused(P, N_global, beta, ws, grid)
+                    else:
+                        be.pass_(P, N_global, beta, ws, grid)
+                        be.local_reduce(K, ws, grid)
+                    _allreduce(sv, group)                       # K col sums + err in one message
                     be.update(r, K, tol, max_iter, False, ws, grid)
             n_enq += batch
             hb = host[(n_enq // batch) % 2]
