@@ -60,6 +60,17 @@ class BatchNorm(nn.Module):
             self._pending = 0
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        self._pending = 0           # the loaded counter already includes whatever was pending when it was saved
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def flush_batches(self):
+        """Fold the lazily counted batches into ``num_batches_tracked`` (call before reading the buffer directly)."""
+        if self._pending:
+            self.num_batches_tracked += self._pending
+            self._pending = 0
+        return self.num_batches_tracked
+
 
 class BatchNorm3d(BatchNorm):
     pass

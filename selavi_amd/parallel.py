@@ -22,10 +22,20 @@ _ALIGN = 64          # floats: every gradient view starts on a 256-byte boundary
 class GradSink:
     """Flat gradient buffers per autograd node + their asynchronous all-reduce."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, own_group=None):
+        """own_group (default on, SELAVI_DP_OWN_GROUP=0 switches it off): the buckets travel on a process group of
+        their own -- a second RCCL communicator and stream.  Collectives on one communicator serialise, and the
+        SyncBN exchanges of the layers still running backward (tiny, on the critical path) would otherwise queue
+        behind layer4's 100 MB bucket."""
+        import os
+        if own_group is None:
+            own_group = os.environ.get("SELAVI_DP_OWN_GROUP", "1") == "1"
+        backend = dist.get_backend(group)
+        if own_group and dist.get_world_size(group) > 1:
+            ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
+            group = dist.new_group(ranks=ranks, backend=backend)       # collective over the default group's ranks
         self.group = group
         self.world = dist.get_world_size(group)
-        backend = dist.get_backend(group)
         self.avg = backend == "nccl"              # RCCL averages in the collective; gloo: sum, then one scale per buffer
         self.flat = {}                            # key -> (flat buffer, {id(param): view})
         self.pending = []

@@ -207,8 +207,7 @@ def optimize_L_sk_gpu(args, PS, hc, logger=None, group=None, N_global=None, back
                     if group is not None:
                         import torch.distributed as dist
                         for d in _K_dists:
-                            dist.broadcast(d, src=dist.get_global_rank(group, 0)
-                                           if hasattr(dist, "get_global_rank") else 0, group=group)
+                            dist.broadcast(d, src=_group_src(group), group=group)
                     args.dist = _K_dists
                     _K_dist = _K_dists[hc]
                 else:
@@ -217,7 +216,7 @@ def optimize_L_sk_gpu(args, PS, hc, logger=None, group=None, N_global=None, back
                     _K_dist = torch.clamp(_K_dist, min=1)                              # :378
                     if group is not None:
                         import torch.distributed as dist
-                        dist.broadcast(_K_dist, src=0, group=group)
+                        dist.broadcast(_K_dist, src=_group_src(group), group=group)
                     args.dist = _K_dist
             if getattr(args, "rank", 0) == 0 and logger is not None:
                 logger.info(f"distribution used: {_K_dist}")
@@ -258,6 +257,14 @@ def l1_cost_matrix(emb1, emb2, group=None, backend=None):
     return out
 
 
+def _group_src(group):
+    """Global rank of rank 0 of ``group`` (the ``src`` torch.distributed.broadcast wants)."""
+    import torch.distributed as dist
+    if group is None or group is dist.group.WORLD or not hasattr(dist, "get_global_rank"):
+        return 0
+    return dist.get_global_rank(group, 0)
+
+
 def _hill_climb(Cm, steps, restarts, logger=None):
     """The random pair-swap search of sk_utils.py:436-461 on the K x K column-distance table (host).
     Consumes ``np.random.choice(K, 2, replace=False)`` exactly like the reference."""
@@ -296,18 +303,33 @@ def match_order(args, emb1, emb2_in, W2, steps=50000, restarts=2, logger=None, g
     K = emb1.shape[1]
     Cm = l1_cost_matrix(emb1, emb2_in, group=group)
     fin_perm = torch.arange(0, K, device=emb1.device)
-    distributed = dist.is_available() and dist.is_initialized()
-    if getattr(args, "rank", 0) == 0:
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    # the searching rank is rank 0 OF THE GROUP the shards live in (the reference searches on global rank 0, :431)
+    searcher = dist.get_rank(group) == 0 if distributed else True
+    if searcher:
         assert type(W2) == torch.nn.modules.linear.Linear or isinstance(W2, torch.nn.Linear)
         perm, best = _hill_climb(Cm.cpu().numpy(), steps, restarts, logger)
         fin_perm = torch.from_numpy(perm).to(emb1.device)
         if logger is not None:
             logger.info(f"final cost: {best:.2f}")
-    if distributed and dist.get_world_size() > 1:
-        dist.broadcast(fin_perm, 0)
+    if distributed:
+        dist.broadcast(fin_perm, src=_group_src(group), group=group)
     W2.bias.data = W2.bias.data[fin_perm]
     W2.weight.data = W2.weight.data[fin_perm]
     return fin_perm
+
+
+class _SubsetSequentialSampler(torch.utils.data.Sampler):
+    """The indices of a rank's slice in order (the deterministic counterpart of SubsetRandomSampler)."""
+
+    def __init__(self, indices):
+        self.indices = indices
+
+    def __iter__(self):
+        return iter(int(i) for i in self.indices)
+
+    def __len__(self):
+        return len(self.indices)
 
 
 def _unwrap(model):
@@ -325,10 +347,10 @@ def get_cluster_assignments_gpu(args, dataset, model, logger=None, writer=None, 
     Returns L: N x headcount int64 on the device (rows beyond W*(N//W) stay zero, as in the reference)."""
     import numpy as np
     import torch.distributed as dist
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    world = dist.get_world_size() if distributed else 1
-    rank = dist.get_rank() if distributed else 0
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     grp = (group if group is not None else dist.group.WORLD) if distributed else None
+    world = dist.get_world_size(grp) if distributed else 1
+    rank = dist.get_rank(grp) if distributed else 0
     net = _unwrap(model)
     was_training = model.training
     model.eval()                                                                       # :150
@@ -343,11 +365,27 @@ def get_cluster_assignments_gpu(args, dataset, model, logger=None, writer=None, 
     L = torch.zeros((N, hc), dtype=torch.long, device=dev)
     order_heads = list(range(hc))
     np.random.shuffle(order_heads)                                                     # :191-192
+    if distributed:
+        # The reference shuffles on every rank too, but there only rank 0's order matters (rank 0 alone solves SK,
+        # :287-329).  Here every rank solves its row shard of the SAME head, and the ranks' numpy streams diverge
+        # (only the searching rank draws match_order's np.random.choice; dataset augmentation draws differ per
+        # shard), so the order is rank 0's, broadcast.
+        oh = torch.tensor(order_heads, dtype=torch.long, device=dev)
+        dist.broadcast(oh, src=_group_src(grp), group=grp)
+        order_heads = [int(h) for h in oh.tolist()]
     # :168 hard-codes 64.  Eval-mode outputs do not depend on the batch they are computed in, so a larger one only fills
     # the late layers better (bf16 pass: 5.8 k clips/s at 64, 6.5 k at 256); launch configurations -- and with them the
     # fp32 summation order -- follow the shape, so the default stays at the reference's value
     bs = int(getattr(args, "sk_batch_size", None) or os.environ.get("SELAVI_SK_BATCH", 64))
     idx_local = torch.arange(lo, lo + local_n)
+    # :157-175: this rank's contiguous slice through a DataLoader (SubsetRandomSampler, args.workers decode workers,
+    # pinned staging) so that a real decoding dataset does not serialise on the main process; shuffle_sk_pass=False
+    # (tests) walks the slice in order instead
+    shuffle = getattr(args, "shuffle_sk_pass", True)
+    sampler = torch.utils.data.SubsetRandomSampler(idx_local) if shuffle else _SubsetSequentialSampler(idx_local)
+    dataloader = torch.utils.data.DataLoader(dataset, batch_size=bs, sampler=sampler,
+                                             num_workers=int(getattr(args, "workers", 0) or 0),
+                                             pin_memory=dev.type == "cuda", collate_fn=None)
     # opt-in: the feature pass in bf16 on the channels-last MFMA kernels (selavi_amd/infer16.py, ~3x faster; the
     # features are NOT the bit-exact fp32 ones -- the default stays fp32).  args.feature_pass or SELAVI_FEATURE_PASS
     engine16 = None
@@ -356,16 +394,14 @@ def get_cluster_assignments_gpu(args, dataset, model, logger=None, writer=None, 
         engine16 = infer16.Engine(net)
     for hd_grp_idx in range(args.ind_groups):                                          # :194
         # 1. feature pass over this rank's slice (every head group re-runs it: "decorrelated heads")
-        order = idx_local[torch.randperm(local_n)] if getattr(args, "shuffle_sk_pass", True) else idx_local
         bank_v = bank_a = None
         indices = torch.empty(local_n, dtype=torch.long, device=dev)
         fr = 0
-        for b0 in range(0, local_n, bs):
-            ids = order[b0:b0 + bs]
-            batch = [dataset[int(i)] for i in ids]
-            video = torch.stack([b[0] for b in batch]).to(dev, non_blocking=True)
-            audio = torch.stack([b[1] for b in batch]).to(dev, non_blocking=True)
-            idx = torch.as_tensor([int(b[3]) for b in batch], device=dev)
+        for batch in dataloader:                                                       # :196
+            video, audio, idx = batch[0], batch[1], batch[3]                           # :198
+            video = video.to(dev, non_blocking=True)                                   # :201-203
+            audio = audio.to(dev, non_blocking=True)
+            idx = idx.to(dev, non_blocking=True).long()
             if engine16 is None:
                 feat_v, feat_a = model(video, audio)                                   # :206
             else:

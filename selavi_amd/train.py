@@ -55,14 +55,10 @@ def data_parallel(model, device_ids, group=None, kind=None):
     kind = kind or os.environ.get("SELAVI_DP", "native")
     if kind == "ddp":
         return wrap_ddp(model, device_ids, process_group=group)
+    if kind != "native":
+        raise ValueError(f"unknown data-parallel kind {kind!r} (native | ddp)")
     from .parallel import DataParallel
-    try:
-        return DataParallel(model, group=group)
-    except (AttributeError, TypeError, NotImplementedError) as e:      # a torch build without an API used there:
-        import warnings                                                 # deterministic, so every rank falls back alike
-        warnings.warn(f"selavi_amd.parallel.DataParallel unavailable ({e!r}); using torch DDP")
-        model.set_grad_sink(None)
-        return wrap_ddp(model, device_ids, process_group=group)
+    return DataParallel(model, group=group)      # errors propagate: no silent change of the wrapper
 
 
 def _join_package_streams():

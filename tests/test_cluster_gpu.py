@@ -234,3 +234,55 @@ def test_rccl_syncbn_ddp_world1_equals_plain_step():
         assert np.isfinite(l1).all() and np.isfinite(w1).all(), key
         np.testing.assert_allclose(l1, l0, rtol=2e-5, err_msg=key)
         assert np.linalg.norm(w1 - w0) <= 1e-4 * np.linalg.norm(w0), key
+
+
+# ---- the SK round on two ranks with the HIP kernels: sharded feature pass + sharded solve + match_order, two rounds
+def _cluster_worker(rank, world, port, hc, K, ret):
+    import torch.distributed as dist
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from selavi_amd import model as smodel, sk_utils
+        from selavi_amd.data import SyntheticAVDataset
+        from selavi_amd.utils import warmup_batchnorm
+        torch.cuda.set_device(0)
+        ds = SyntheticAVDataset(n=192, T=4, S=32, F=40, Tp=36, n_classes=K)
+        m = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
+        portable_init_(m, seed=31)
+        m = m.cuda().train()
+        m.set_sync_bn(False)          # identical BN statistics on every rank: all ranks warm up on the same batches
+        loader = [(torch.stack([ds[i][0] for i in range(b, b + 16)]), torch.stack([ds[i][1] for i in range(b, b + 16)]))
+                  for b in range(0, 64, 16)]
+        warmup_batchnorm(Args(), m, loader, batches=4)
+        args = Args(headcount=hc, rank=rank, match=True, ind_groups=2, distribution='gauss')
+        np.random.seed(31)            # utils.py:277-283 seeds every rank alike; the streams diverge inside round 1
+        torch.manual_seed(31)         # (only the searching rank draws match_order's pairs)
+        labels = torch.zeros(192, hc, dtype=torch.long, device="cuda")
+        out = []
+        for it in (0, 1):
+            labels = sk_utils.cluster(args, labels, ds, m, it, None, None, None, it)
+            out.append(labels.cpu().numpy().copy())
+        w = torch.cat([getattr(m, f"mlp_a{h}").block_forward[8].weight.flatten() for h in range(hc)])
+        ret[rank] = (out, w.detach().cpu().numpy().copy(), float(np.random.rand()))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_two_rank_cluster_rounds_match_single_process():
+    """sk_utils.cluster on two ranks (row-sharded feature pass + HIP sharded Sinkhorn-Knopp + match_order, gauss
+    marginals, two head groups, hc = 3) over TWO rounds: both ranks return the same labels and hold the same permuted
+    audio heads although their numpy streams have diverged by the second round (the head order is rank 0's), and the
+    labels equal a single process's."""
+    import torch.multiprocessing as mp
+    ret, ret1 = mp.Manager().dict(), mp.Manager().dict()
+    mp.spawn(_cluster_worker, args=(2, 28100 + os.getpid() % 150, 3, 8, ret), nprocs=2, join=True)
+    mp.spawn(_cluster_worker, args=(1, 0, 3, 8, ret1), nprocs=1, join=True)
+    assert ret[0][2] != ret[1][2], "the ranks' numpy streams were expected to diverge (match_order draws on rank 0)"
+    for rnd in (0, 1):
+        np.testing.assert_array_equal(ret[0][0][rnd], ret[1][0][rnd])
+        assert (ret[0][0][rnd] == ret1[0][0][rnd]).mean() == 1.0
+        assert len(np.unique(ret[0][0][rnd][:, 0])) > 1
+    np.testing.assert_array_equal(ret[0][1], ret[1][1])
+    np.testing.assert_array_equal(ret[0][1], ret1[0][1])
