@@ -33,6 +33,27 @@ int32_t slv_version(void);                /* ABI version, bumps on any signature
 const char* slv_last_error(void);      /* thread-local, valid until the next failing call      */
 int slv_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len);
 
+/* ---------------------------------------------------------------- communicator (RCCL over xGMI) -
+ * Replaces the NCCL process group of utils.py:133-146 for the hot path's exchanges.  librccl is resolved at run time
+ * (dlopen; slv_comm_load(path) names a copy, NULL/"" = the one already in the process, then the system's).  One
+ * communicator per process; slv_comm_init is COLLECTIVE over the ranks sharing the 128-byte id of
+ * slv_comm_unique_id (rank 0 makes it, the host side distributes it).  Every collective is enqueued on `stream`
+ * in order with the kernels around it; buffers are device pointers, in place. */
+typedef void* slv_comm_t;
+int slv_comm_load(const char* librccl_path /* nullable */);
+const char* slv_comm_library(void);               /* what was loaded ("" before the first use)           */
+int slv_comm_unique_id(void* id_out_128 /* host, 128 bytes */);
+int slv_comm_init(slv_comm_t* comm_out /* host */, const void* unique_id_128 /* host */, int rank, int world);
+int slv_comm_destroy(slv_comm_t comm);
+int32_t slv_comm_rank(slv_comm_t comm);
+int32_t slv_comm_world(slv_comm_t comm);
+int slv_comm_allreduce_f64(slv_comm_t comm, double* buf, int64_t n, slv_stream_t stream);              /* sum */
+int slv_comm_allreduce_f32(slv_comm_t comm, float* buf, int64_t n, int average, slv_stream_t stream);  /* sum / mean */
+int slv_comm_allreduce_i64(slv_comm_t comm, int64_t* buf, int64_t n, slv_stream_t stream);             /* sum */
+int slv_comm_allgather(slv_comm_t comm, const void* send, void* recv /* world * bytes_per_rank */,
+                       int64_t bytes_per_rank, slv_stream_t stream);
+int slv_comm_broadcast(slv_comm_t comm, void* buf, int64_t bytes, int root, slv_stream_t stream);
+
 /* ---------------------------------------------------------------- Sinkhorn-Knopp ------------
  * Replaces the torch fp64 ops of src/sk_utils.py:
  *   slv_sk_prepare      <- softmax(dtype=float64) x2, torch.mul(out=), PS.pow_()  (:309-315,:391)
@@ -79,6 +100,10 @@ int slv_sk_update(const double* r /* K, normalised */, int K, double tol, int ma
 /* single-GPU convenience: n_iters x (pass, local_reduce, update) enqueued back to back        */
 int slv_sk_iterate(const double* P, int64_t N, int K, double* beta, const double* r, double tol,
                    int max_iter, int n_iters, void* ws, int grid, slv_stream_t stream);
+/* multi-GPU: n_iters x (pass, local_reduce, all-reduce of the K+1 doubles over `comm`, update), one host call */
+int slv_sk_iterate_sharded(slv_comm_t comm, const double* P, int64_t N_local, int64_t N_global, int K, double* beta,
+                           const double* r, double tol, int max_iter, int n_iters, void* ws, int grid,
+                           slv_stream_t stream);
 /* host_out: 4 doubles {counter, done, err, reserved} in (pinned) host memory                 */
 int slv_sk_status(void* ws, int K, int grid, double* host_out, slv_stream_t stream);
 /* match_order (sk_utils.py:424-467): out[i][j] = sum_n |e1[n][i] - e2[n][j]|; partial = nsplit*K*K doubles */
@@ -171,6 +196,15 @@ int slv_bn_stats_finalize(const float* psum, const float* psq, int nblk, double 
                           const float* beta, float* running_mean /* nullable */, float* running_var,
                           float momentum, float eps, float* mean_invstd, float* scale_shift, int C,
                           slv_stream_t stream);
+/* SyncBN in one call on one stream: partials -> fp64 sums (sums_scratch, 2C doubles) -> all-reduce over `comm` ->
+ * finalize with count_local * world.  The backward twin folds slv_bn_bwd_sums + all-reduce + slv_bn_bwd_finalize. */
+int slv_bn_sync_finalize(slv_comm_t comm, const float* psum, const float* psq, int nblk, double count_local,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                         float eps, float* mean_invstd, float* scale_shift, int C, double* sums_scratch,
+                         slv_stream_t stream);
+int slv_bn_bwd_sync_finalize(slv_comm_t comm, const float* partial, int nsplit, double count_local, const float* gamma,
+                             const float* mean_invstd, const float* scale_shift, float* bwd5, float* dgamma,
+                             float* dbeta, int accumulate, int C, double* sums_scratch, slv_stream_t stream);
 int slv_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* mean_invstd /* nullable */,
                        float* scale_shift, int C, slv_stream_t stream);
@@ -278,6 +312,51 @@ int slv_to_cl16_wpatch(const float* x, void* y_bf16, int64_t N, int C, int64_t T
 /* MaxPool2d(3, 2, 1) on [N][H][W][Cp] bf16; AdaptiveAvgPool(1)+flatten: [N][S][Cp] bf16 -> fp32 [N][C] */
 int slv_maxpool_cl16(const void* x_bf16, void* y_bf16, int64_t N, int H, int W, int Cp, slv_stream_t stream);
 int slv_avgpool_cl16(const void* x_bf16, float* y, int64_t N, int64_t S, int C, int Cp, slv_stream_t stream);
+
+/* ---- 16-bit MFMA path, training (BASELINE configs[4]; main.py:151-153 apex.amp O1, :296-299 scaled-loss backward --
+ * bf16 needs no loss scaling).  fp32 master weights / BatchNorm parameters / statistics, bf16 channels-last activations
+ * and activation gradients, fp32 accumulation, fp32 weight gradients in the reference layout.
+ *
+ * slv_cl16_conv: the general launch of the bf16 implicit-GEMM kernel.  clconv: slv_cl16_conv_words() int32 =
+ *   {N, Ti, Hi, Wi, Cin_p, Cin, Lt, Lh, Lw, bmt, bmh, bmw, bot, boh, bow, To, Ho, Wo, Cout, Cout_p, omt, omh, omw, oot,
+ *    ooh, oow, Mrows, ntaps, tap[27]}: the block enumerates the lattice Lt x Lh x Lw per clip; activation rows are read
+ *   at lattice*bm + bo + tap offset, the output row is lattice*om + oo; tap = (dt+8) | (dh+8) << 4 | (dw+8) << 8 |
+ *   weight slab << 12.  Forward conv: lattice = output, bm = stride, bo = -pad; backward data: one launch per
+ *   stride-parity class of the input positions (selavi_amd/ops16.py builds the tables).
+ *   in_scale_shift [2][Cin] (nullable): rows are read as relu(x*s + h), zero padding after the affine (train-mode
+ *     BatchNorm + ReLU of the producing layer applied on load);
+ *   stat_sum/stat_sq [Cout][slv_cl16_conv_nblk()] (nullable, together): per-channel partial sum / sum of squares of the
+ *     bf16-rounded output -- the input of slv_bn_stats_finalize / slv_bn_partials_to_sums;
+ *   otherwise as slv_conv_cl16_fwd (scale_shift / res / relu epilogue; res doubles as the backward-data addend).
+ * slv_cl16_w_transform: fp32 [Cout][Cin][taps] -> forward layout [taps][Cin_p/32][mrows_fwd][32] and backward-data
+ *   layout [taps][Cout_p/32][mrows_dgrad][32] (either nullable); patch_kw > 0: forward layout of the stem's W-patch conv.
+ * slv_cl16_wgrad: dw[Cout][Cin][taps] (fp32, reference layout) = sum_pos dy[pos][co] * act(x)[pos*stride+tap-pad][ci];
+ *   clw: slv_cl16_wgrad_words() int32 = {N, Ti, Hi, Wi, Cin_p, Cin, To, Ho, Wo, Cout_p, st, sh, sw, pt, ph, pw, kt, kh, kw,
+ *   Ncols, mtiles, ntiles, kslices, kper}; tile = (32*wm) x (32*wn), wm, wn in 2..5; deterministic split-K through `ws`.
+ * slv_cl16_bn_*: channels-last bf16 versions of slv_bn_act / slv_bn_bwd_reduce / slv_bn_bwd_apply on [P][Cp]. */
+int32_t slv_cl16_conv_words(void);
+int32_t slv_cl16_conv_nblk(const int32_t* clconv);
+int slv_cl16_conv(const int32_t* clconv, int mt, const void* x_bf16, const void* w_layout_bf16, void* y_bf16,
+                  const float* in_scale_shift, const float* scale_shift, const void* res_bf16, int relu,
+                  float* stat_sum, float* stat_sq, slv_stream_t stream);
+int slv_cl16_w_transform(const float* w, void* wf_bf16, void* wt_bf16, int Cout, int Cin, int taps, int Cin_p,
+                         int Cout_p, int mrows_fwd, int mrows_dgrad, int patch_kw, slv_stream_t stream);
+int32_t slv_cl16_wgrad_words(void);
+size_t slv_cl16_wgrad_ws_bytes(const int32_t* clw, int wm, int wn);
+int slv_cl16_wgrad(const int32_t* clw, int wm, int wn, const void* dy_bf16, const void* x_bf16,
+                   const float* in_scale_shift, float* dw, int Cout, int patch_kw, void* ws, size_t ws_bytes,
+                   slv_stream_t stream);
+int slv_cl16_bn_act(const void* x_bf16, const float* scale_shift, const void* res_bf16, const float* res_scale_shift,
+                    int relu, void* out_bf16, int64_t P, int C, int Cp, slv_stream_t stream);
+int32_t slv_cl16_bn_bwd_nsplit(int64_t P, int Cp);
+int slv_cl16_bn_bwd_reduce(const void* g_bf16, const void* x_bf16, const float* mean_invstd, const float* scale_shift_mask,
+                           const void* v_mask_bf16, const void* x2_bf16, const float* mean_invstd2, void* g_out_bf16,
+                           float* partial, float* partial2, int64_t P, int C, int Cp, int nsplit, slv_stream_t stream);
+int slv_cl16_bn_bwd_apply(const void* g_bf16, const void* x_bf16, const float* bwd5, int relu, void* out_bf16, int64_t P,
+                          int C, int Cp, slv_stream_t stream);
+int slv_cl16_avgpool_bwd(const float* dout, void* dv_bf16, int64_t N, int64_t S, int C, int Cp, slv_stream_t stream);
+/* bf16 [N][S][Cp] -> fp32 N,C,S: the inverse of slv_to_cl16 (inspection, tests) */
+int slv_from_cl16(const void* x_bf16, float* y, int64_t N, int C, int Cp, int64_t S, slv_stream_t stream);
 
 /* ---- input pipeline: what the reference's DataLoader workers compute per clip on the CPU -------
  * slv_clip_augment replaces datasets/video_transforms.py:462-510 (clip_augmentation: /255, -mean, /std, THWC->TCHW,

@@ -20,6 +20,7 @@ class SelaviHipError(RuntimeError):
 _SCALARS = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t,
     "double": ctypes.c_double, "float": ctypes.c_float, "slv_stream_t": ctypes.c_void_p,
+    "slv_comm_t": ctypes.c_void_p,
     "unsigned": ctypes.c_uint, "uint64_t": ctypes.c_uint64,
 }
 

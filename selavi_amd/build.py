@@ -49,7 +49,7 @@ def build(force=False, verbose=True):
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError(f"hipcc failed on {s}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -68,6 +68,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// RCCL hooks for the fused SyncBN / sharded Sinkhorn-Knopp entry points (csrc/comm.cpp)
+int comm_allreduce_sum_f64(void* comm, double* buf, size_t n, hipStream_t st);
+int comm_world(void* comm);
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // exact unsigned division by a runtime constant (Granlund-Montgomery round-up form)

@@ -14,23 +14,34 @@
 //   ds_read_b128 fragments); padding positions are buffer loads with an out-of-range offset (return 0).
 //   Output [P_out][Cout_p] bf16: channels >= Cout are written as zeros so the next layer can read whole 32-channel
 //   K-steps.
-#include "common.hpp"
+#include "cl16.hpp"
 #include "../../include/selavi_hip.h"
 
 namespace slv {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-struct ClGeom {                       // int32 x 20, mirrored by selavi_amd/ops16.py
-  int N, Ti, Hi, Wi, Cin_p;           // input  [N][Ti][Hi][Wi][Cin_p]
-  int Cout, Cout_p, To, Ho, Wo;       // output [N][To][Ho][Wo][Cout_p]
-  int kt, kh, kw, st, sh, sw, pt, ph, pw;
-  int Mrows;                          // rows of the weight layout: Cout rounded up to the block's M tile
+// Geometry of one launch (int32 x CLC_WORDS, mirrored by selavi_amd/ops16.py).  The block enumerates a LATTICE of
+// positions; the B operand (activation rows) is read at  lattice * bm + bo + tap offset, the output is written at
+// lattice * om + oo:
+//   forward conv              lattice = output positions, bm = stride, bo = -pad, taps = kernel offsets, om = 1, oo = 0
+//   backward-data, stride 1   lattice = input positions,  bm = 1, bo = 0, taps = pad - j (weight slab j), om = 1
+//   backward-data, stride 2   one launch per parity class c of the input positions: lattice a <-> x = 2a + c,
+//                             taps j with (c + pad - j) even at offset (c + pad - j) / 2, om = 2, oo = c
+//                             (only that class' taps: no wasted MFMAs; a class without taps writes addend / zeros)
+struct ClConv {
+  int N;
+  int Ti, Hi, Wi, Cin_p, Cin;        // B-operand tensor [N][Ti][Hi][Wi][Cin_p]; Cin = channels the prologue table holds
+  int Lt, Lh, Lw;                    // lattice of this launch: P = N*Lt*Lh*Lw GEMM columns
+  int bmt, bmh, bmw, bot, boh, bow;
+  int To, Ho, Wo, Cout, Cout_p;      // output tensor [N][To][Ho][Wo][Cout_p]; Cout = valid GEMM rows
+  int omt, omh, omw, oot, ooh, oow;
+  int Mrows;                         // rows of the weight layout [slab][Cin_p/32][Mrows][32]
+  int ntaps;
+  int tap[27];                       // (dt + 8) | (dh + 8) << 4 | (dw + 8) << 8 | weight slab << 12
 };
+constexpr int CLC_WORDS = sizeof(ClConv) / 4;
 
 constexpr int CL_BN = 128, CL_ROWB = 64;
+constexpr int CL_PRO_MAXC = 1152;                       // widest layer input of the two trunks (prologue table in LDS)
 // LDS image: rows of 32 bf16 = 64 bytes, unpadded; the 16-byte slot of k-group q in row r is q ^ swz(r).  ds_read_b128
 // is serviced in lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md): with fragment lanes
 // (row = lane & 15, k-group = lane >> 4) a group holds rows 0-3 and 12-15 of one k-group and rows 4-11 of its
@@ -38,29 +49,41 @@ constexpr int CL_BN = 128, CL_ROWB = 64;
 // cycles).  swz(r) = (-(r >> 2)) & 3 makes the 16 slots of every group distinct.
 __device__ __forceinline__ int cl_swz(int row) { return (-(row >> 2)) & 3; }
 
-__device__ __forceinline__ unsigned short f2bf(float f) {             // round to nearest even (finite inputs)
-  unsigned int u = __float_as_uint(f);
-  u += 0x7FFF + ((u >> 16) & 1);
-  return (unsigned short)(u >> 16);
+// sum over the 16 lanes of a DPP row (all 16 end up with the total): xor 1, xor 2, half mirror, mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+  return v;
 }
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
-template <int MT>
+// PRO 0: B rows as stored.  PRO 1: B rows read as relu(x * s[c] + h[c]) (the producer's BatchNorm + ReLU applied on
+//        load, zero padding AFTER the affine), table in_ss [2][Cin].
+// EPI 0: y = relu?(acc * scale + shift + res) -> bf16 (eval-mode BatchNorm / residual; scale_shift, res nullable: plain
+//        store, and backward-data with its addend).
+// EPI 1: y = acc -> bf16 plus per-channel partial sums of y and y^2 over the block's positions, taken on the ROUNDED
+//        values the consumer will normalise: stat_sum / stat_sq [Cout][gridDim.x] (train-mode BatchNorm statistics).
+template <int MT, int PRO, int EPI>
 __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const unsigned short* __restrict__ x,
                                                            const unsigned short* __restrict__ wl,
                                                            unsigned short* __restrict__ y,
+                                                           const float* __restrict__ in_ss,         // PRO 1: [2][Cin]
                                                            const float* __restrict__ scale_shift,   // [2][Cout] or null
-                                                           const unsigned short* __restrict__ res,  // [P_out][Cout_p] or null
-                                                           int relu, ClGeom g) {
+                                                           const unsigned short* __restrict__ res,  // output-shaped or null
+                                                           int relu, float* __restrict__ stat_sum,
+                                                           float* __restrict__ stat_sq, ClConv g) {
   constexpr int BM = MT * 16;
   constexpr int APIECES = BM * 4, AITER = (APIECES + 255) / 256;
   constexpr int OROW = BM * 2 + 16;                   // bytes per position row of the transposed output tile (+16: banks)
   constexpr int STAGE = (BM + CL_BN) * CL_ROWB;
-  constexpr int LDSB = 2 * STAGE > CL_BN * OROW + 2 * BM * 4 ? 2 * STAGE : CL_BN * OROW + 2 * BM * 4;
+  constexpr int KLOOP = 2 * STAGE + (PRO ? 2 * CL_PRO_MAXC * 4 : 0);
+  constexpr int EPIB = CL_BN * OROW + 8 * BM * 4 + CL_BN * 4;
+  constexpr int LDSB = KLOOP > EPIB ? KLOOP : EPIB;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDSB];
   unsigned char(*lds)[STAGE] = (unsigned char(*)[STAGE])lds_raw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned P = (unsigned)g.N * g.To * g.Ho * g.Wo;
+  const unsigned P = (unsigned)g.N * g.Lt * g.Lh * g.Lw;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       (void*)x, 0, (int)((unsigned)g.N * g.Ti * g.Hi * g.Wi * g.Cin_p * 2u), 0x00020000);
   const int m0 = blockIdx.y * BM;
@@ -72,43 +95,47 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
   for (int i = 0; i < 2; ++i) {
     const unsigned p = blockIdx.x * CL_BN + (tid >> 2) + 64 * i;
     unsigned q = p;
-    const int wo = q % g.Wo; q /= g.Wo;
-    const int ho = q % g.Ho; q /= g.Ho;
-    const int to = q % g.To; q /= g.To;      // q = clip
-    bt[i] = to * g.st - g.pt;
-    bh[i] = ho * g.sh - g.ph;
-    bw[i] = wo * g.sw - g.pw;
-    bbase[i] = p < P ? (((q * g.Ti + bt[i]) * g.Hi + bh[i]) * g.Wi + bw[i]) * (unsigned)(g.Cin_p * 2) + piece * 16u
-                     : 0xFFFFFFF0u;          // (wraps for negative coordinates; only used when the tap is valid)
-    if (p >= P) bt[i] = -(1 << 20);
+    const int lw = q % g.Lw; q /= g.Lw;
+    const int lh = q % g.Lh; q /= g.Lh;
+    const int lt = q % g.Lt; q /= g.Lt;      // q = clip
+    bt[i] = lt * g.bmt + g.bot;
+    bh[i] = lh * g.bmh + g.boh;
+    bw[i] = lw * g.bmw + g.bow;
+    bbase[i] = (((q * g.Ti + bt[i]) * g.Hi + bh[i]) * g.Wi + bw[i]) * (unsigned)(g.Cin_p * 2) + piece * 16u;
+    if (p >= P) bt[i] = -(1 << 20);          // (bbase wraps for negative coordinates; only used when the tap is valid)
   }
-  const int kcs = g.Cin_p >> 5, ksteps = g.kt * g.kh * g.kw * kcs;
+  const int kcs = g.Cin_p >> 5, ksteps = g.ntaps * kcs;
+  float* pro = (float*)(lds_raw + 2 * STAGE);                      // PRO 1: [2][Cin_p] scale, shift (zero beyond Cin)
+  if constexpr (PRO == 1) {
+    for (int i = tid; i < 2 * g.Cin_p; i += 256) {
+      const int c = i % g.Cin_p, which = i / g.Cin_p;
+      pro[i] = c < g.Cin ? in_ss[which * g.Cin + c] : 0.f;
+    }
+  }
   u32x4 ra[AITER], rb[2];
-  int tap = 0, kc = 0, dt = 0, dh = 0, dw = 0;                     // K-step being LOADED
+  bool okl[2] = {false, false};
+  int tapi = 0, kc = 0, kc_ld = 0;                                 // K-step being LOADED
   auto gload = [&]() __attribute__((always_inline)) {
+    const int tp = g.tap[tapi];
+    const int dt = (tp & 15) - 8, dh = ((tp >> 4) & 15) - 8, dw = ((tp >> 8) & 15) - 8, slab = tp >> 12;
     const unsigned toff = (unsigned)(((dt * g.Hi + dh) * g.Wi + dw) * g.Cin_p * 2 + kc * 64);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool ok = (unsigned)(bt[i] + dt) < (unsigned)g.Ti && (unsigned)(bh[i] + dh) < (unsigned)g.Hi &&
                       (unsigned)(bw[i] + dw) < (unsigned)g.Wi;
+      okl[i] = ok;
       rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? bbase[i] + toff : 0xFFFFFFF0u, 0, 0));
     }
-    const unsigned short* ws = wl + ((size_t)(tap * kcs + kc) * g.Mrows + m0) * 32;
+    const unsigned short* ws = wl + ((size_t)(slab * kcs + kc) * g.Mrows + m0) * 32;
 #pragma unroll
     for (int i = 0; i < AITER; ++i) {
       const int pc = tid + 256 * i;
       if (pc < APIECES) ra[i] = *(const u32x4*)(ws + pc * 8);
     }
+    kc_ld = kc;
     if (++kc == kcs) {                                              // advance to the next K-step
       kc = 0;
-      ++tap;
-      if (++dw == g.kw) {
-        dw = 0;
-        if (++dh == g.kh) {
-          dh = 0;
-          ++dt;
-        }
-      }
+      ++tapi;
     }
   };
   auto lstore = [&](int buf) __attribute__((always_inline)) {
@@ -118,6 +145,19 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
     for (int i = 0; i < AITER; ++i) {
       const int pc = tid + 256 * i;
       if (pc < APIECES) *(u32x4*)(A + (pc >> 2) * CL_ROWB + (((pc & 3) ^ cl_swz(pc >> 2)) << 4)) = ra[i];
+    }
+    if constexpr (PRO == 1) {                                       // the prologue math sits at the LDS-write point
+      float s[8], h[8];
+      const float* sp = pro + kc_ld * 32 + piece * 8;
+      *(f32x4*)s = *(const f32x4*)sp;
+      *(f32x4*)(s + 4) = *(const f32x4*)(sp + 4);
+      *(f32x4*)h = *(const f32x4*)(sp + g.Cin_p);
+      *(f32x4*)(h + 4) = *(const f32x4*)(sp + g.Cin_p + 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x4 t = affine_relu8(rb[i], s, h);
+        rb[i] = okl[i] ? t : (u32x4){0u, 0u, 0u, 0u};
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -129,9 +169,12 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fk = lane >> 4, fsw = (fk ^ cl_swz(fr)) << 4;   // rows i*16+fr, wave*32+j*16+fr: same swz
-  gload();
-  lstore(0);
-  __syncthreads();
+  if (ksteps > 0) {
+    gload();
+    if constexpr (PRO == 1) __syncthreads();                         // the prologue table is complete
+    lstore(0);
+    __syncthreads();
+  }
   for (int s = 0; s < ksteps; ++s) {
     if (s + 1 < ksteps) gload();
     const unsigned char* A = lds[s & 1];
@@ -154,41 +197,84 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
   // channels (288 contiguous bytes per row for the 144-channel tile).  scale / shift also come through LDS.
   __syncthreads();                                      // the K loop's last fragment reads are done
   unsigned char* ot = lds_raw;                          // [CL_BN][OROW]
-  float* ssl = (float*)(lds_raw + CL_BN * OROW);        // [2][BM]
-  if (scale_shift) {
+  float* ssl = (float*)(lds_raw + CL_BN * OROW);        // EPI 0: [2][BM] scale, shift; EPI 1: [4 waves][2][BM] partials
+  unsigned* opos = (unsigned*)(lds_raw + CL_BN * OROW + 8 * BM * 4);   // [CL_BN] output position (row index) or ~0
+  if (tid < CL_BN) {
+    const unsigned p = blockIdx.x * CL_BN + tid;
+    unsigned q = p, o = 0xFFFFFFFFu;
+    if (p < P) {
+      const int lw = q % g.Lw; q /= g.Lw;
+      const int lh = q % g.Lh; q /= g.Lh;
+      const int lt = q % g.Lt; q /= g.Lt;
+      o = ((q * g.To + lt * g.omt + g.oot) * g.Ho + lh * g.omh + g.ooh) * g.Wo + lw * g.omw + g.oow;
+    }
+    opos[tid] = o;
+  }
+  if (EPI == 0 && scale_shift) {
     for (int i = tid; i < 2 * BM; i += 256) {
       const int c = m0 + (i % BM);
       ssl[i] = c < g.Cout ? scale_shift[(i / BM) * g.Cout + c] : 0.f;
     }
-    __syncthreads();
   }
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int co = m0 + i * 16 + fk * 4;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (scale_shift) {
+    if (EPI == 0 && scale_shift) {
       sc = *(const f32x4*)(ssl + i * 16 + fk * 4);
       sh = *(const f32x4*)(ssl + BM + i * 16 + fk * 4);
     }
+    float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int pl = wave * 32 + j * 16 + fr;             // position inside the block
-      const unsigned p = blockIdx.x * CL_BN + pl;
-      uint2 rr = make_uint2(0u, 0u);
-      if (res && p < P && co < g.Cout_p) rr = *(const uint2*)(res + (size_t)p * g.Cout_p + co);
       float v[4];
+      if constexpr (EPI == 0) {
+        const unsigned op = opos[pl];
+        uint2 rr = make_uint2(0u, 0u);
+        if (res && op != 0xFFFFFFFFu && co < g.Cout_p) rr = *(const uint2*)(res + (size_t)op * g.Cout_p + co);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = acc[i][j][r] * sc[r] + sh[r];
+          if (res) t += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
+          if (relu) t = fmaxf(t, 0.f);
+          v[r] = (co + r < g.Cout) ? t : 0.f;                         // padding channels stay zero
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];              // rows >= Cout: zero weights -> 0
+      }
+      const unsigned lo = pack_bf2(v[0], v[1]), hi = pack_bf2(v[2], v[3]);
+      *(uint2*)(ot + pl * OROW + (i * 16 + fk * 4) * 2) = make_uint2(lo, hi);
+      if constexpr (EPI == 1) {
+        const float r0 = bf_lo(lo), r1 = bf_hi(lo), r2 = bf_lo(hi), r3 = bf_hi(hi);
+        ps[0] += r0; ps[1] += r1; ps[2] += r2; ps[3] += r3;
+        pq[0] += r0 * r0; pq[1] += r1 * r1; pq[2] += r2 * r2; pq[3] += r3 * r3;
+      }
+    }
+    if constexpr (EPI == 1) {                            // 16 positions per lane group -> lane fr == 0 of each group
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float t = acc[i][j][r] * sc[r] + sh[r];
-        if (res) t += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
-        if (relu) t = fmaxf(t, 0.f);
-        v[r] = (co + r < g.Cout) ? t : 0.f;                         // padding channels stay zero
+        const float a = row16_sum(ps[r]), b = row16_sum(pq[r]);
+        if (fr == 0) {
+          ssl[(wave * 2 + 0) * BM + i * 16 + fk * 4 + r] = a;
+          ssl[(wave * 2 + 1) * BM + i * 16 + fk * 4 + r] = b;
+        }
       }
-      *(uint2*)(ot + pl * OROW + (i * 16 + fk * 4) * 2) =
-          make_uint2(f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
     }
   }
   __syncthreads();
+  if constexpr (EPI == 1) {                              // the 4 waves' partials in fixed order -> [Cout][gridDim.x]
+    for (int i = tid; i < 2 * BM; i += 256) {
+      const int c = i % BM, which = i / BM;
+      if (m0 + c < g.Cout) {
+        const float t = ((ssl[(0 * 2 + which) * BM + c] + ssl[(1 * 2 + which) * BM + c]) + ssl[(2 * 2 + which) * BM + c]) +
+                        ssl[(3 * 2 + which) * BM + c];
+        (which ? stat_sq : stat_sum)[(size_t)(m0 + c) * gridDim.x + blockIdx.x] = t;
+      }
+    }
+  }
   // rows of this block in the output: channels [m0, m0 + BM) clipped to Cout_p; the last M block also zero-fills the
   // padding channels no M tile covers (Mrows < Cout_p)
   const int c_lo = m0, c_hi = min(m0 + BM, g.Cout_p);
@@ -196,11 +282,11 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
   const int pieces = (c_end - c_lo) >> 3;                 // 16-byte pieces per position (channel counts are multiples of 8)
   for (int idx = tid; idx < CL_BN * pieces; idx += 256) {
     const int pl = idx / pieces, pc = idx - pl * pieces;
-    const unsigned p = blockIdx.x * CL_BN + pl;
-    if (p >= P) continue;
+    const unsigned op = opos[pl];
+    if (op == 0xFFFFFFFFu) continue;
     u32x4 val = {0u, 0u, 0u, 0u};
     if (c_lo + pc * 8 < c_hi) val = *(const u32x4*)(ot + pl * OROW + pc * 16);
-    *(u32x4*)(y + (size_t)p * g.Cout_p + c_lo + pc * 8) = val;
+    *(u32x4*)(y + (size_t)op * g.Cout_p + c_lo + pc * 8) = val;
   }
 }
 
@@ -290,36 +376,102 @@ __global__ __launch_bounds__(64) void avgpool_cl16_kernel(const unsigned short* 
 
 extern "C" {
 
-// geom: 20 int32 (ClGeom).  MT (16-row tiles per block) follows from geom.Mrows: the Python side picks it.
+static int cl16_launch(const slv::ClConv& g, int mt, const void* x, const void* wl, void* y, const float* in_ss,
+                       const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq,
+                       slv_stream_t stream, const char* fn) {
+  using namespace slv;
+  const unsigned P = (unsigned)g.N * g.Lt * g.Lh * g.Lw;
+  dim3 grid((P + CL_BN - 1) / CL_BN, g.Mrows / (16 * mt));
+  const int pro = in_ss ? 1 : 0, epi = stat_sum ? 1 : 0;
+#define SLV_CL16(MT_, PRO_, EPI_)                                                                                     \
+  hipLaunchKernelGGL((conv_cl16_kernel<MT_, PRO_, EPI_>), grid, dim3(256), 0, (hipStream_t)stream,                    \
+                     (const unsigned short*)x, (const unsigned short*)wl, (unsigned short*)y, in_ss, scale_shift,     \
+                     (const unsigned short*)res, relu, stat_sum, stat_sq, g)
+#define SLV_CL16_MT(MT_)                              \
+  do {                                                \
+    if (pro == 0 && epi == 0) SLV_CL16(MT_, 0, 0);    \
+    else if (pro == 1 && epi == 0) SLV_CL16(MT_, 1, 0); \
+    else if (pro == 0 && epi == 1) SLV_CL16(MT_, 0, 1); \
+    else SLV_CL16(MT_, 1, 1);                          \
+  } while (0)
+  if (mt == 4) SLV_CL16_MT(4);
+  else if (mt == 8) SLV_CL16_MT(8);
+  else SLV_CL16_MT(9);
+#undef SLV_CL16_MT
+#undef SLV_CL16
+  return ::slv::launch_check(fn);
+}
+
+// geom: 20 int32 = {N, Ti, Hi, Wi, Cin_p, Cout, Cout_p, To, Ho, Wo, kt, kh, kw, st, sh, sw, pt, ph, pw, Mrows}.
+// MT (16-row tiles per block) follows from geom.Mrows: the Python side picks it.
 int slv_conv_cl16_fwd(const int32_t* geom, int mt, const void* x_bf16, const void* w_layout_bf16, void* y_bf16,
                       const float* scale_shift, const void* res_bf16, int relu, slv_stream_t stream) {
   using namespace slv;
   SLV_CHECK_ARG(geom && x_bf16 && w_layout_bf16 && y_bf16, "null pointer");
-  ClGeom g;
-  memcpy(&g, geom, sizeof(g));
-  SLV_CHECK_ARG(g.N > 0 && g.Cin_p > 0 && (g.Cin_p & 31) == 0 && g.Cout > 0 && g.Cout_p >= g.Cout && (g.Cout_p & 7) == 0,
+  const int32_t* q = geom;
+  const int N = q[0], Ti = q[1], Hi = q[2], Wi = q[3], Cin_p = q[4], Cout = q[5], Cout_p = q[6], To = q[7], Ho = q[8],
+            Wo = q[9], kt = q[10], kh = q[11], kw = q[12], st = q[13], sh = q[14], sw = q[15], pt = q[16], ph = q[17],
+            pw = q[18], Mrows = q[19];
+  SLV_CHECK_ARG(N > 0 && Cin_p > 0 && (Cin_p & 31) == 0 && Cout > 0 && Cout_p >= Cout && (Cout_p & 7) == 0,
                 "channel counts (Cin_p % 32, Cout_p % 8)");
-  SLV_CHECK_ARG(g.kt > 0 && g.kh > 0 && g.kw > 0 && g.st > 0 && g.sh > 0 && g.sw > 0, "kernel / stride");
-  SLV_CHECK_ARG(g.To == (g.Ti + 2 * g.pt - g.kt) / g.st + 1 && g.Ho == (g.Hi + 2 * g.ph - g.kh) / g.sh + 1 &&
-                    g.Wo == (g.Wi + 2 * g.pw - g.kw) / g.sw + 1 && g.To > 0 && g.Ho > 0 && g.Wo > 0,
+  SLV_CHECK_ARG(kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0 && kt <= 8 && kh <= 8 && kw <= 8 &&
+                    kt * kh * kw <= 27, "kernel / stride");
+  SLV_CHECK_ARG(To == (Ti + 2 * pt - kt) / st + 1 && Ho == (Hi + 2 * ph - kh) / sh + 1 &&
+                    Wo == (Wi + 2 * pw - kw) / sw + 1 && To > 0 && Ho > 0 && Wo > 0,
                 "output extent does not match the geometry");
-  SLV_CHECK_ARG((long long)g.N * g.Ti * g.Hi * g.Wi * g.Cin_p * 2 < 0xFFFFFFF0LL &&
-                    (long long)g.N * g.To * g.Ho * g.Wo * g.Cout_p * 2 < 0xFFFFFFF0LL,
+  SLV_CHECK_ARG((long long)N * Ti * Hi * Wi * Cin_p * 2 < 0xFFFFFFF0LL && (long long)N * To * Ho * Wo * Cout_p * 2 < 0xFFFFFFF0LL,
                 "tensor beyond the 32-bit buffer range");
   SLV_CHECK_ARG(mt == 4 || mt == 8 || mt == 9, "M tile (4, 8 or 9 x 16 rows)");
+  SLV_CHECK_ARG(Mrows % (16 * mt) == 0 && Mrows >= Cout, "weight layout rows");
+  ClConv g;
+  memset(&g, 0, sizeof(g));
+  g.N = N; g.Ti = Ti; g.Hi = Hi; g.Wi = Wi; g.Cin_p = Cin_p; g.Cin = Cin_p;
+  g.Lt = To; g.Lh = Ho; g.Lw = Wo;
+  g.bmt = st; g.bmh = sh; g.bmw = sw; g.bot = -pt; g.boh = -ph; g.bow = -pw;
+  g.To = To; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.Cout_p = Cout_p;
+  g.omt = g.omh = g.omw = 1;
+  g.Mrows = Mrows;
+  for (int a = 0; a < kt; ++a)
+    for (int b = 0; b < kh; ++b)
+      for (int c = 0; c < kw; ++c) g.tap[g.ntaps] = (a + 8) | (b + 8) << 4 | (c + 8) << 8 | g.ntaps << 12, ++g.ntaps;
+  return cl16_launch(g, mt, x_bf16, w_layout_bf16, y_bf16, nullptr, scale_shift, res_bf16, relu, nullptr, nullptr, stream,
+                     __func__);
+}
+
+int32_t slv_cl16_conv_words(void) { return slv::CLC_WORDS; }
+
+int slv_cl16_conv(const int32_t* clconv, int mt, const void* x_bf16, const void* w_layout_bf16, void* y_bf16,
+                  const float* in_scale_shift, const float* scale_shift, const void* res_bf16, int relu,
+                  float* stat_sum, float* stat_sq, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(clconv && x_bf16 && w_layout_bf16 && y_bf16, "null pointer");
+  ClConv g;
+  memcpy(&g, clconv, sizeof(g));
+  SLV_CHECK_ARG(g.N > 0 && g.Cin_p > 0 && (g.Cin_p & 31) == 0 && g.Cin > 0 && g.Cin <= g.Cin_p && g.Cout > 0 &&
+                    g.Cout_p >= g.Cout && (g.Cout_p & 7) == 0, "channel counts (Cin_p % 32, Cout_p % 8)");
+  SLV_CHECK_ARG(g.Lt > 0 && g.Lh > 0 && g.Lw > 0 && g.Ti > 0 && g.Hi > 0 && g.Wi > 0 && g.To > 0 && g.Ho > 0 && g.Wo > 0,
+                "extents");
+  SLV_CHECK_ARG(g.ntaps >= 0 && g.ntaps <= 27, "taps");
+  SLV_CHECK_ARG((g.Lt - 1) * g.omt + g.oot < g.To && (g.Lh - 1) * g.omh + g.ooh < g.Ho && (g.Lw - 1) * g.omw + g.oow < g.Wo &&
+                    g.oot >= 0 && g.ooh >= 0 && g.oow >= 0 && g.omt > 0 && g.omh > 0 && g.omw > 0,
+                "the lattice does not fit the output tensor");
+  SLV_CHECK_ARG((long long)g.N * g.Ti * g.Hi * g.Wi * g.Cin_p * 2 < 0xFFFFFFF0LL &&
+                    (long long)g.N * g.To * g.Ho * g.Wo * g.Cout_p * 2 < 0xFFFFFFF0LL &&
+                    (long long)g.N * g.Lt * g.Lh * g.Lw < 0xFFFFFF00LL, "tensor beyond the 32-bit buffer range");
+  SLV_CHECK_ARG(mt == 4 || mt == 8 || mt == 9, "M tile (4, 8 or 9 x 16 rows)");
   SLV_CHECK_ARG(g.Mrows % (16 * mt) == 0 && g.Mrows >= g.Cout, "weight layout rows");
-  const unsigned P = (unsigned)g.N * g.To * g.Ho * g.Wo;
-  dim3 grid((P + CL_BN - 1) / CL_BN, g.Mrows / (16 * mt));
-#define SLV_CL16(MT_)                                                                                              \
-  hipLaunchKernelGGL((conv_cl16_kernel<MT_>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x_bf16, \
-                     (const unsigned short*)w_layout_bf16, (unsigned short*)y_bf16, scale_shift,                    \
-                     (const unsigned short*)res_bf16, relu, g)
-  if (mt == 4) SLV_CL16(4);
-  else if (mt == 8) SLV_CL16(8);
-  else SLV_CL16(9);
-#undef SLV_CL16
-  SLV_LAUNCH_CHECK();
-  return 0;
+  SLV_CHECK_ARG(!in_scale_shift || g.Cin_p <= CL_PRO_MAXC, "prologue table: Cin_p <= 1152");
+  SLV_CHECK_ARG((stat_sum == nullptr) == (stat_sq == nullptr), "stat_sum / stat_sq come together");
+  SLV_CHECK_ARG(!stat_sum || (!scale_shift && !res_bf16), "the statistics epilogue stores the raw output");
+  return cl16_launch(g, mt, x_bf16, w_layout_bf16, y_bf16, in_scale_shift, scale_shift, res_bf16, relu, stat_sum, stat_sq,
+                     stream, __func__);
+}
+
+int32_t slv_cl16_conv_nblk(const int32_t* clconv) {
+  slv::ClConv g;
+  memcpy(&g, clconv, sizeof(g));
+  const long long P = (long long)g.N * g.Lt * g.Lh * g.Lw;
+  return (int32_t)((P + slv::CL_BN - 1) / slv::CL_BN);
 }
 
 int slv_to_cl16(const float* x, void* y_bf16, int64_t N, int C, int Cp, int64_t S, slv_stream_t stream) {

@@ -517,6 +517,34 @@ int slv_bn_stats_finalize(const float* psum, const float* psq, int nblk, double 
   return 0;
 }
 
+// SyncBN forward (main.py:117-118): conv-epilogue partials -> fp64 sums -> all-reduce over RCCL -> finalize with the
+// GLOBAL count, one host call, one stream (the exchange sits between two kernels of the caller's stream).
+int slv_bn_sync_finalize(slv_comm_t comm, const float* psum, const float* psq, int nblk, double count_local,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                         float eps, float* mean_invstd, float* scale_shift, int C, double* sums_scratch,
+                         slv_stream_t stream) {
+  SLV_CHECK_ARG(comm && sums_scratch, "communicator / scratch");
+  int rc = slv_bn_partials_to_sums(psum, psq, nblk, C, sums_scratch, stream);
+  if (rc) return rc;
+  rc = slv::comm_allreduce_sum_f64(comm, sums_scratch, (size_t)2 * C, (hipStream_t)stream);
+  if (rc) return rc;
+  return slv_bn_finalize(sums_scratch, count_local * slv::comm_world(comm), gamma, beta, running_mean, running_var,
+                         momentum, eps, mean_invstd, scale_shift, C, stream);
+}
+
+// SyncBN backward: slice partials -> fp64 sums -> all-reduce -> folded coefficients, likewise
+int slv_bn_bwd_sync_finalize(slv_comm_t comm, const float* partial, int nsplit, double count_local, const float* gamma,
+                             const float* mean_invstd, const float* scale_shift, float* bwd5, float* dgamma,
+                             float* dbeta, int accumulate, int C, double* sums_scratch, slv_stream_t stream) {
+  SLV_CHECK_ARG(comm && sums_scratch, "communicator / scratch");
+  int rc = slv_bn_bwd_sums(partial, nsplit, C, sums_scratch, stream);
+  if (rc) return rc;
+  rc = slv::comm_allreduce_sum_f64(comm, sums_scratch, (size_t)2 * C, (hipStream_t)stream);
+  if (rc) return rc;
+  return slv_bn_bwd_finalize(sums_scratch, count_local * slv::comm_world(comm), gamma, mean_invstd, scale_shift, bwd5,
+                             dgamma, dbeta, accumulate, C, stream);
+}
+
 int slv_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* mean_invstd, float* scale_shift, int C, slv_stream_t stream) {
   SLV_CHECK_ARG(gamma && beta && running_mean && running_var && scale_shift && C > 0, "bad argument");

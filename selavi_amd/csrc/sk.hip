@@ -652,6 +652,26 @@ int slv_sk_iterate(const double* P, int64_t N, int K, double* beta, const double
   return 0;
 }
 
+// Row-sharded multi-GPU loop (sk_utils.py:287-329 re-designed: every rank keeps its rows): n_iters x (pass, local
+// reduce, all-reduce of the K column sums + err over RCCL, update) enqueued from ONE host call on ONE stream -- the
+// K-vector exchange sits between two kernels of the same stream, no process-group stream, no event hops, no Python.
+int slv_sk_iterate_sharded(slv_comm_t comm, const double* P, int64_t N_local, int64_t N_global, int K, double* beta,
+                           const double* r, double tol, int max_iter, int n_iters, void* ws, int grid,
+                           slv_stream_t stream) {
+  SLV_CHECK_ARG(comm, "null communicator");
+  for (int it = 0; it < n_iters; ++it) {
+    int rc = slv_sk_pass(P, N_local, N_global, K, beta, ws, grid, stream);
+    if (rc) return rc;
+    rc = slv_sk_local_reduce(K, ws, grid, stream);
+    if (rc) return rc;
+    rc = slv::comm_allreduce_sum_f64(comm, slv_sk_s_ptr(ws, K, grid), (size_t)K + 1, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = slv_sk_update(r, K, tol, max_iter, 0, ws, grid, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int slv_sk_local_reduce(int K, void* ws, int grid, slv_stream_t stream) {
   SLV_CHECK_ARG(ws && K > 0 && grid > 0, "null pointer or empty shape");
   SkWs w = carve(ws, K, grid);

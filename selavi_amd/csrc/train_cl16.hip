@@ -1,0 +1,607 @@
+// Training kernels of the 16-bit MFMA path (BASELINE configs[4]; the reference trains its convs in half precision
+// through apex O1, main.py:151-153,296-299) around csrc/conv_cl16.hip, which runs the forward conv (train mode:
+// BatchNorm + ReLU of the producer applied on load, batch statistics from the epilogue) and the backward-data conv
+// (same kernel on transposed weights, one launch per stride-parity class):
+//   * weight re-layouts from the fp32 master weights (per step): forward + backward-data bf16 layouts
+//   * the WEIGHT GRADIENT: dW[co][(tap, ci)] = sum_pos dY[pos][co] * act(X)[pos*stride + tap - pad][ci].  Both operands
+//     are channels-last, i.e. the contraction index (position) is the SLOW dimension of both: the tiles are staged in LDS
+//     position-major as they are loaded and the MFMA fragments (8 consecutive k per lane) come out of
+//     ds_read_b64_tr_b16, the LDS transpose read of gfx950.  fp32 partial tiles per K-slice, fixed-order reduce into the
+//     reference's fp32 [Cout][Cin][kt][kh][kw] layout (the optimizer keeps fp32 master weights).
+//   * channels-last bf16 versions of the HBM-bound BatchNorm kernels of csrc/elementwise.hip (block tail, backward
+//     reductions, backward apply) and the average-pool backward.
+#include "cl16.hpp"
+#include "../../include/selavi_hip.h"
+
+namespace slv {
+
+// ------------------------------------------------------------------------------------------ weight layouts
+// w fp32 [Cout][Cin][taps] ->
+//   wf bf16 [taps][Cin_p/32][MrowsF][32]   wf(tap, kc, m, j) = w[m][kc*32 + j][tap]          (forward: rows = cout)
+//   wt bf16 [taps][Cout_p/32][MrowsD][32]  wt(tap, kc, m, j) = w[kc*32 + j][m][tap]          (backward data: rows = cin)
+// patch_kw > 0 (stem, csrc/conv_cl16.hip:to_cl16_wpatch_kernel): the forward conv is a (1, kh, 1) conv over the
+// 32-channel W-patch layout, channel j = dw*Cin + c:  wf(a, 0, m, j) = w[m][c][0][a][dw].
+__global__ __launch_bounds__(256) void cl16_w_transform_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf,
+                                                               unsigned short* __restrict__ wt, int Cout, int Cin,
+                                                               int taps, int Cin_p, int Cout_p, int MrowsF, int MrowsD,
+                                                               int patch_kw, unsigned nf, unsigned nt) {
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < nf) {
+    const unsigned j = idx & 31, m = (idx >> 5) % MrowsF, r = (idx >> 5) / MrowsF;
+    float v = 0.f;
+    if (patch_kw > 0) {
+      const unsigned a = r;                       // kcs == 1
+      const unsigned dw = j / Cin, c = j - dw * Cin;
+      if (m < (unsigned)Cout && dw < (unsigned)patch_kw) v = w[((size_t)(m * Cin + c) * taps + a) * patch_kw + dw];
+    } else {
+      const unsigned kcs = Cin_p >> 5, kc = r % kcs, tap = r / kcs, c = kc * 32 + j;
+      if (m < (unsigned)Cout && c < (unsigned)Cin) v = w[((size_t)m * Cin + c) * taps + tap];
+    }
+    wf[idx] = f2bf(v);
+  } else if (idx - nf < nt) {
+    const unsigned i2 = idx - nf;
+    const unsigned j = i2 & 31, m = (i2 >> 5) % MrowsD, r = (i2 >> 5) / MrowsD;
+    const unsigned kcs = Cout_p >> 5, kc = r % kcs, tap = r / kcs, co = kc * 32 + j;
+    float v = 0.f;
+    if (co < (unsigned)Cout && m < (unsigned)Cin) v = w[((size_t)co * Cin + m) * taps + tap];
+    wt[i2] = f2bf(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient
+struct ClWgrad {                      // int32 x CLW_WORDS, mirrored by selavi_amd/ops16.py
+  int N;
+  int Ti, Hi, Wi, Cin_p, Cin;         // X [N][Ti][Hi][Wi][Cin_p]
+  int To, Ho, Wo, Cout_p;             // dY [N][To][Ho][Wo][Cout_p]
+  int st, sh, sw, pt, ph, pw;
+  int kt, kh, kw;
+  int Ncols;                          // kt*kh*kw * Cin_p: GEMM column = tap * Cin_p + ci
+  int mtiles, ntiles;                 // of the (BM, BN) the launch is instantiated for
+  int kslices, kper;                  // positions per K-slice (multiple of 32)
+};
+constexpr int CLW_WORDS = sizeof(ClWgrad) / 4;
+
+// K mapping of one 32-position step: lane group g = lane >> 4 contracts the tile rows {4g..4g+3} and {16+4g..16+4g+3}
+// (any bijection works as long as both operands use it; this one makes the 8 rows a half wave touches per transpose
+// read consecutive, and with a row stride == 32 (mod 64) bytes they fall into 8 different 32-byte bank groups).
+template <int WM, int WN, int PRO>
+__global__ __launch_bounds__(256, 2) void cl16_wgrad_kernel(const unsigned short* __restrict__ dy,
+                                                            const unsigned short* __restrict__ x,
+                                                            const float* __restrict__ in_ss, float* __restrict__ part,
+                                                            ClWgrad g, FastDiv dWo, FastDiv dHo, FastDiv dTo) {
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int SA = BM * 2 + 32, SB = BN * 2 + 32;             // row strides in bytes, (S / 32) odd
+  constexpr int APC = BM / 8, BPC = BN / 8;                     // 16-byte pieces per row
+  constexpr int AIT = (32 * APC + 255) / 256, BIT = (32 * BPC + 255) / 256;
+  constexpr int STAGE = 32 * (SA + SB);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * STAGE + (PRO ? 2 * 1152 * 4 : 0)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware bijective remap: consecutive units (the tiles of one K-slice read the same rows) share an XCD's L2
+  const unsigned total = gridDim.x, q8 = total >> 3, r8 = total & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const unsigned unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  const unsigned tiles = (unsigned)(g.mtiles * g.ntiles);
+  const unsigned slice = unit / tiles, tile = unit - slice * tiles;
+  const int m0 = (int)(tile / g.ntiles) * BM, n0 = (int)(tile % g.ntiles) * BN;
+  const unsigned P = (unsigned)g.N * g.To * g.Ho * g.Wo;
+  const unsigned k_lo = slice * (unsigned)g.kper, k_hi = min(k_lo + (unsigned)g.kper, P);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)(P * (unsigned)g.Cout_p * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)x, 0, (int)((unsigned)g.N * g.Ti * g.Hi * g.Wi * g.Cin_p * 2u), 0x00020000);
+  float* pro = (float*)(lds_raw + 2 * STAGE);
+  if constexpr (PRO == 1) {
+    for (int i = tid; i < 2 * g.Cin_p; i += 256) {
+      const int c = i % g.Cin_p, which = i / g.Cin_p;
+      pro[i] = c < g.Cin ? in_ss[which * g.Cin + c] : 0.f;
+    }
+  }
+  // ---- per-thread constants of the loaders
+  int arow[AIT];
+  unsigned aoff[AIT];                      // byte offset inside a dY row, or ~0 when the piece is outside the tensor
+#pragma unroll
+  for (int i = 0; i < AIT; ++i) {
+    const int pc = tid + 256 * i;
+    arow[i] = pc / APC;
+    const int c = m0 + (pc % APC) * 8;
+    aoff[i] = (pc < 32 * APC && c < g.Cout_p) ? (unsigned)c * 2u : 0xFFFFFFFFu;
+  }
+  int brow[BIT], bdt[BIT], bdh[BIT], bdw[BIT], bci[BIT];
+  bool bval[BIT];
+#pragma unroll
+  for (int i = 0; i < BIT; ++i) {
+    const int pc = tid + 256 * i;
+    brow[i] = pc / BPC;
+    const int col = n0 + (pc % BPC) * 8;
+    bval[i] = pc < 32 * BPC && col < g.Ncols;
+    const int tap = col / g.Cin_p;
+    bci[i] = col - tap * g.Cin_p;
+    bdw[i] = tap % g.kw - g.pw;
+    bdh[i] = (tap / g.kw) % g.kh - g.ph;
+    bdt[i] = tap / (g.kw * g.kh) - g.pt;
+  }
+  u32x4 ra[AIT], rb[BIT];
+  bool okb[BIT];
+  auto gload = [&](unsigned k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const unsigned p = k0 + arow[i];
+      const unsigned off = (p < k_hi && aoff[i] != 0xFFFFFFFFu) ? p * (unsigned)(g.Cout_p * 2) + aoff[i] : 0xFFFFFFF0u;
+      ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) {
+      const unsigned p = k0 + brow[i];
+      unsigned q = fdiv(p, dWo);
+      const int wo = p - q * g.Wo;
+      unsigned q2 = fdiv(q, dHo);
+      const int ho = q - q2 * g.Ho;
+      const unsigned n = fdiv(q2, dTo);
+      const int to = q2 - n * g.To;
+      const int t = to * g.st + bdt[i], h = ho * g.sh + bdh[i], w_ = wo * g.sw + bdw[i];
+      const bool ok = bval[i] && p < k_hi && (unsigned)t < (unsigned)g.Ti && (unsigned)h < (unsigned)g.Hi &&
+                      (unsigned)w_ < (unsigned)g.Wi;
+      okb[i] = ok;
+      const unsigned off = (((n * g.Ti + t) * g.Hi + h) * g.Wi + w_) * (unsigned)(g.Cin_p * 2) + (unsigned)bci[i] * 2u;
+      rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : 0xFFFFFFF0u, 0, 0));
+    }
+  };
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* A = lds_raw + buf * STAGE;
+    unsigned char* B = A + 32 * SA;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const int pc = tid + 256 * i;
+      if (pc < 32 * APC) *(u32x4*)(A + arow[i] * SA + (pc % APC) * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) {
+      const int pc = tid + 256 * i;
+      if (pc < 32 * BPC) {
+        u32x4 v = rb[i];
+        if constexpr (PRO == 1) {
+          float s[8], h[8];
+          const float* sp = pro + bci[i];
+          *(f32x4*)s = *(const f32x4*)sp;
+          *(f32x4*)(s + 4) = *(const f32x4*)(sp + 4);
+          *(f32x4*)h = *(const f32x4*)(sp + g.Cin_p);
+          *(f32x4*)(h + 4) = *(const f32x4*)(sp + g.Cin_p + 4);
+          const u32x4 t = affine_relu8(v, s, h);
+          v = okb[i] ? t : (u32x4){0u, 0u, 0u, 0u};
+        }
+        *(u32x4*)(B + brow[i] * SB + (pc % BPC) * 16) = v;
+      }
+    }
+  };
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fg = lane >> 4, fi = lane & 15;
+  // transpose-read address of this lane: row 4*fg + (fi >> 2) (+16 for the second half), 4 columns at 4*(fi & 3)
+  const int fa = (4 * fg + (fi >> 2)) * SA + (wm * WM * 16 + 4 * (fi & 3)) * 2;
+  const int fb = (4 * fg + (fi >> 2)) * SB + (wn * WN * 16 + 4 * (fi & 3)) * 2;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  if (k_lo < k_hi) {
+    gload(k_lo);
+    if constexpr (PRO == 1) __syncthreads();
+    lstore(0);
+    __syncthreads();
+  }
+  int buf = 0;
+  for (unsigned k0 = k_lo; k0 < k_hi; k0 += 32) {
+    const bool more = k0 + 32 < k_hi;
+    if (more) gload(k0 + 32);
+    const unsigned char* A = lds_raw + buf * STAGE;
+    const unsigned char* B = A + 32 * SA;
+    bf16x8 bfr[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(B + fb + j * 32));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(B + fb + j * 32 + 16 * SB));
+      const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      bfr[j] = __builtin_bit_cast(bf16x8, tmp);
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(A + fa + i * 32));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(A + fa + i * 32 + 16 * SA));
+      const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const bf16x8 afr = __builtin_bit_cast(bf16x8, tmp);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // ---- partial tile of this K-slice: part[slice][mtiles*BM][ntiles*BN] fp32.  C/D: col = lane & 15 (n), rows
+  // (lane >> 4) * 4 + r (m): 64-byte runs per lane group.
+  const size_t ldp = (size_t)g.ntiles * BN;
+  float* pt = part + ((size_t)slice * g.mtiles * BM + m0 + wm * WM * 16) * ldp + n0 + wn * WN * 16;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pt[(size_t)(i * 16 + fg * 4 + r) * ldp + j * 16 + fi] = acc[i][j][r];
+}
+
+// dw[co][ci][tap] = sum_slices part[s][co][tap*Cin_p + ci]  (s ascending: fixed order); patch_kw > 0: the stem's patch
+// columns (a*32 + dw*Cin + c) go back to w[co][c][0][a][dw]
+__global__ __launch_bounds__(256) void cl16_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                int Cout, int Cin, int taps, int Cin_p, int slices,
+                                                                size_t slice_stride, size_t ldp, int patch_kw,
+                                                                unsigned total) {
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  unsigned co, col;
+  if (patch_kw > 0) {                     // idx over [Cout][Cin][kh = taps][kw]
+    const unsigned dwi = idx % patch_kw, a = (idx / patch_kw) % taps, c = (idx / (patch_kw * taps)) % Cin;
+    co = idx / (patch_kw * taps * Cin);
+    col = a * 32 + dwi * Cin + c;
+  } else {                                // idx over [Cout][Cin][taps]
+    const unsigned tap = idx % taps, ci = (idx / taps) % Cin;
+    co = idx / (taps * Cin);
+    col = tap * Cin_p + ci;
+  }
+  const float* p = part + (size_t)co * ldp + col;
+  float s = 0.f;
+  for (int i = 0; i < slices; ++i) s += p[(size_t)i * slice_stride];
+  dw[idx] = s;
+}
+
+// ------------------------------------------------------------------------------------------ BatchNorm, channels last
+// out = relu?( x*s + h + (res ? (rss ? res*rs + rh : res) : 0) ) on [P][Cp] bf16; one thread per 16-byte piece
+__global__ __launch_bounds__(256) void cl16_bn_act_kernel(const unsigned short* __restrict__ x, const float* __restrict__ ss,
+                                                          const unsigned short* __restrict__ res,
+                                                          const float* __restrict__ rss, int relu,
+                                                          unsigned short* __restrict__ out, int C, int Cp,
+                                                          unsigned total /* P * Cp / 8 */) {
+  const unsigned pieces = Cp >> 3;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned c0 = (idx % pieces) * 8;
+    const u32x4 xv = *(const u32x4*)(x + (size_t)idx * 8);
+    u32x4 rv = {0u, 0u, 0u, 0u};
+    if (res) rv = *(const u32x4*)(res + (size_t)idx * 8);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned c = c0 + 2 * i + e;
+        float t = 0.f;
+        if (c < (unsigned)C) {
+          t = bn_affine(e ? bf_hi(xv[i]) : bf_lo(xv[i]), ss[c], ss[C + c]);
+          if (res) {
+            const float r = e ? bf_hi(rv[i]) : bf_lo(rv[i]);
+            t += rss ? bn_affine(r, rss[c], rss[C + c]) : r;
+          }
+          if (relu) t = fmaxf(t, 0.f);
+        }
+        v[e] = t;
+      }
+      o[i] = pack_bf2(v[0], v[1]);
+    }
+    *(u32x4*)(out + (size_t)idx * 8) = o;
+  }
+}
+
+// BatchNorm backward reductions on [P][Cp] bf16 (cf. bn_bwd_reduce_kernel of csrc/elementwise.hip):
+//   g' = mask * g ; part[c][nsplit][2] = { sum g', sum g' * xhat(x) } (+ part2 with xhat2(x2) for the downsample BN)
+// MASK 0: none; 1: own BN output > 0 (x*s + h); 2: block output v > 0 (g' is written to gout).
+// One block per position slice: thread = (row r = tid / pieces, 16-byte piece); rows r, r + RPB, ... of the slice.
+template <int MASK, bool TWO>
+__global__ __launch_bounds__(256) void cl16_bn_bwd_reduce_kernel(const unsigned short* __restrict__ gin,
+                                                                 const unsigned short* __restrict__ x,
+                                                                 const float* __restrict__ mi, const float* __restrict__ ss,
+                                                                 const unsigned short* __restrict__ v,
+                                                                 const unsigned short* __restrict__ x2,
+                                                                 const float* __restrict__ mi2,
+                                                                 unsigned short* __restrict__ gout,
+                                                                 float* __restrict__ part, float* __restrict__ part2,
+                                                                 int C, int Cp, unsigned P, unsigned per, int nsplit) {
+  extern __shared__ float sh[];                                  // [rpb][3][Cp]
+  const int pieces = Cp >> 3, rpb = 256 / pieces > 0 ? 256 / pieces : 1;
+  const int r = threadIdx.x / pieces, pc = threadIdx.x - r * pieces;
+  const unsigned e0 = blockIdx.x * per, e1 = min(e0 + per, P);
+  float a0[8], a1[8], a2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a0[i] = a1[i] = a2[i] = 0.f;
+  if (r < rpb) {
+    float mean[8], inv[8], mean2[8], inv2[8], s_[8], h_[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = pc * 8 + i;
+      const bool okc = c < C;
+      mean[i] = okc ? mi[c] : 0.f;
+      inv[i] = okc ? mi[C + c] : 0.f;
+      mean2[i] = (TWO && okc) ? mi2[c] : 0.f;
+      inv2[i] = (TWO && okc) ? mi2[C + c] : 0.f;
+      s_[i] = (MASK == 1 && okc) ? ss[c] : 0.f;
+      h_[i] = (MASK == 1 && okc) ? ss[C + c] : 0.f;
+    }
+    for (unsigned p = e0 + r; p < e1; p += rpb) {
+      const size_t ad = ((size_t)p * pieces + pc) * 8;
+      u32x4 gv = *(const u32x4*)(gin + ad);
+      const u32x4 xv = *(const u32x4*)(x + ad);
+      u32x4 vv = {0u, 0u, 0u, 0u}, x2v = {0u, 0u, 0u, 0u};
+      if (MASK == 2) vv = *(const u32x4*)(v + ad);
+      if (TWO) x2v = *(const u32x4*)(x2 + ad);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned wsel = i >> 1;
+        const bool hi = i & 1;
+        float gg = hi ? bf_hi(gv[wsel]) : bf_lo(gv[wsel]);
+        const float xx = hi ? bf_hi(xv[wsel]) : bf_lo(xv[wsel]);
+        if (MASK == 1) gg = bn_affine(xx, s_[i], h_[i]) > 0.f ? gg : 0.f;
+        if (MASK == 2) gg = (hi ? bf_hi(vv[wsel]) : bf_lo(vv[wsel])) > 0.f ? gg : 0.f;
+        a0[i] += gg;
+        a1[i] += gg * ((xx - mean[i]) * inv[i]);
+        if (TWO) a2[i] += gg * (((hi ? bf_hi(x2v[wsel]) : bf_lo(x2v[wsel])) - mean2[i]) * inv2[i]);
+        if (MASK == 2) {                                         // masked gradient: zero the element in place
+          if (!(((hi ? bf_hi(vv[wsel]) : bf_lo(vv[wsel])) > 0.f))) gv[wsel] &= hi ? 0x0000FFFFu : 0xFFFF0000u;
+        }
+      }
+      if (MASK == 2) *(u32x4*)(gout + ad) = gv;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sh[(r * 3 + 0) * Cp + pc * 8 + i] = a0[i];
+      sh[(r * 3 + 1) * Cp + pc * 8 + i] = a1[i];
+      sh[(r * 3 + 2) * Cp + pc * 8 + i] = a2[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int rr = 0; rr < rpb; ++rr) {                           // fixed order
+      t0 += sh[(rr * 3 + 0) * Cp + c];
+      t1 += sh[(rr * 3 + 1) * Cp + c];
+      t2 += sh[(rr * 3 + 2) * Cp + c];
+    }
+    part[((size_t)c * nsplit + blockIdx.x) * 2 + 0] = t0;
+    part[((size_t)c * nsplit + blockIdx.x) * 2 + 1] = t1;
+    if (TWO) {
+      part2[((size_t)c * nsplit + blockIdx.x) * 2 + 0] = t0;
+      part2[((size_t)c * nsplit + blockIdx.x) * 2 + 1] = t2;
+    }
+  }
+}
+
+// out = A1*mask*g + A2 + A3*x on [P][Cp] bf16 (b5 = s, h, A1, A2, A3 [5][C]); padding channels stay zero
+__global__ __launch_bounds__(256) void cl16_bn_bwd_apply_kernel(const unsigned short* __restrict__ gin,
+                                                                const unsigned short* __restrict__ x,
+                                                                const float* __restrict__ b5, int relu,
+                                                                unsigned short* __restrict__ out, int C, int Cp,
+                                                                unsigned total) {
+  const unsigned pieces = Cp >> 3;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned c0 = (idx % pieces) * 8;
+    const u32x4 gv = *(const u32x4*)(gin + (size_t)idx * 8);
+    const u32x4 xv = *(const u32x4*)(x + (size_t)idx * 8);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned c = c0 + 2 * i + e;
+        float t = 0.f;
+        if (c < (unsigned)C) {
+          const float xx = e ? bf_hi(xv[i]) : bf_lo(xv[i]);
+          float gg = e ? bf_hi(gv[i]) : bf_lo(gv[i]);
+          if (relu && !(bn_affine(xx, b5[c], b5[C + c]) > 0.f)) gg = 0.f;
+          t = b5[2 * C + c] * gg + b5[3 * C + c] + b5[4 * C + c] * xx;
+        }
+        v[e] = t;
+      }
+      o[i] = pack_bf2(v[0], v[1]);
+    }
+    *(u32x4*)(out + (size_t)idx * 8) = o;
+  }
+}
+
+// AdaptiveAvgPool(1) backward: dv[n][s][c] = dout[n][c] / S (bf16, padding channels zero)
+__global__ __launch_bounds__(256) void cl16_avgpool_bwd_kernel(const float* __restrict__ dout, unsigned short* __restrict__ dv,
+                                                               unsigned S, int C, int Cp, unsigned total) {
+  const unsigned pieces = Cp >> 3;
+  const float inv = 1.f / (float)S;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned pc = idx % pieces, n = (idx / pieces) / S;
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned c = pc * 8 + 2 * i;
+      const float a = c < (unsigned)C ? dout[(size_t)n * C + c] * inv : 0.f;
+      const float b = c + 1 < (unsigned)C ? dout[(size_t)n * C + c + 1] * inv : 0.f;
+      o[i] = pack_bf2(a, b);
+    }
+    *(u32x4*)(dv + (size_t)idx * 8) = o;
+  }
+}
+
+// bf16 [N][S][Cp] -> fp32 N,C,S (tests / inspection: the inverse of slv_to_cl16)
+__global__ __launch_bounds__(256) void cl16_from_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int C,
+                                                        int Cp, unsigned S, unsigned total /* N*C*S */) {
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const unsigned s = idx % S, c = (idx / S) % C, n = idx / (S * (unsigned)C);
+  y[idx] = bf2f(x[((size_t)n * S + s) * Cp + c]);
+}
+
+template <int WM, int WN>
+static int wgrad_launch(const ClWgrad& g, const void* dy, const void* x, const float* in_ss, float* part, hipStream_t st) {
+  const FastDiv dWo = make_fastdiv(g.Wo), dHo = make_fastdiv(g.Ho), dTo = make_fastdiv(g.To);
+  const unsigned blocks = (unsigned)g.mtiles * g.ntiles * g.kslices;
+  if (in_ss)
+    hipLaunchKernelGGL((cl16_wgrad_kernel<WM, WN, 1>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dy,
+                       (const unsigned short*)x, in_ss, part, g, dWo, dHo, dTo);
+  else
+    hipLaunchKernelGGL((cl16_wgrad_kernel<WM, WN, 0>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dy,
+                       (const unsigned short*)x, in_ss, part, g, dWo, dHo, dTo);
+  return 0;
+}
+
+}  // namespace slv
+
+extern "C" {
+
+int slv_cl16_w_transform(const float* w, void* wf_bf16, void* wt_bf16, int Cout, int Cin, int taps, int Cin_p,
+                         int Cout_p, int mrows_fwd, int mrows_dgrad, int patch_kw, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(w && (wf_bf16 || wt_bf16) && Cout > 0 && Cin > 0 && taps > 0, "bad argument");
+  SLV_CHECK_ARG((Cin_p & 31) == 0 && (Cout_p & 31) == 0 && Cin_p >= Cin && Cout_p >= Cout, "padded channel counts");
+  SLV_CHECK_ARG(!patch_kw || (Cin_p == 32 && patch_kw * Cin <= 32 && !wt_bf16), "patch layout: forward only, kw*Cin <= 32");
+  const long long nf = wf_bf16 ? (long long)taps * (Cin_p / 32) * mrows_fwd * 32 : 0;
+  const long long nt = wt_bf16 ? (long long)taps * (Cout_p / 32) * mrows_dgrad * 32 : 0;
+  SLV_CHECK_ARG(nf + nt < 0xFFFFFF00LL, "weights too large");
+  SLV_CHECK_ARG((!wf_bf16 || mrows_fwd >= Cout) && (!wt_bf16 || mrows_dgrad >= Cin), "layout rows");
+  hipLaunchKernelGGL(cl16_w_transform_kernel, dim3((unsigned)((nf + nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     (unsigned short*)wf_bf16, (unsigned short*)wt_bf16, Cout, Cin, taps, Cin_p, Cout_p, mrows_fwd,
+                     mrows_dgrad, patch_kw, (unsigned)nf, (unsigned)nt);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int32_t slv_cl16_wgrad_words(void) { return slv::CLW_WORDS; }
+
+size_t slv_cl16_wgrad_ws_bytes(const int32_t* clw, int wm, int wn) {
+  slv::ClWgrad g;
+  memcpy(&g, clw, sizeof(g));
+  return (size_t)g.kslices * g.mtiles * wm * 32 * g.ntiles * wn * 32 * sizeof(float);
+}
+
+int slv_cl16_wgrad(const int32_t* clw, int wm, int wn, const void* dy_bf16, const void* x_bf16,
+                   const float* in_scale_shift, float* dw, int Cout, int patch_kw, void* ws, size_t ws_bytes,
+                   slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(clw && dy_bf16 && x_bf16 && dw && ws, "null pointer");
+  ClWgrad g;
+  memcpy(&g, clw, sizeof(g));
+  SLV_CHECK_ARG(wm >= 2 && wm <= 5 && wn >= 2 && wn <= 5, "tile (wm, wn in 2..5: 64..160 rows / columns)");
+  SLV_CHECK_ARG(g.N > 0 && (g.Cin_p & 31) == 0 && (g.Cout_p & 31) == 0 && g.Cin > 0 && g.Cin <= g.Cin_p && Cout > 0 &&
+                    Cout <= g.Cout_p, "channel counts");
+  SLV_CHECK_ARG(g.kt > 0 && g.kh > 0 && g.kw > 0 && g.Ncols == g.kt * g.kh * g.kw * g.Cin_p, "columns");
+  SLV_CHECK_ARG(g.mtiles * wm * 32 >= g.Cout_p && g.ntiles * wn * 32 >= g.Ncols && g.mtiles > 0 && g.ntiles > 0, "tiles");
+  SLV_CHECK_ARG(g.kslices > 0 && g.kper > 0 && (g.kper & 31) == 0 &&
+                    (long long)g.kslices * g.kper >= (long long)g.N * g.To * g.Ho * g.Wo, "K slices");
+  SLV_CHECK_ARG((long long)g.N * g.Ti * g.Hi * g.Wi * g.Cin_p * 2 < 0xFFFFFFF0LL &&
+                    (long long)g.N * g.To * g.Ho * g.Wo * g.Cout_p * 2 < 0xFFFFFFF0LL, "tensor beyond the 32-bit buffer range");
+  SLV_CHECK_ARG(!in_scale_shift || g.Cin_p <= 1152, "prologue table: Cin_p <= 1152");
+  SLV_CHECK_ARG(!patch_kw || (g.Cin_p == 32 && g.kt == 1 && g.kw == 1), "patch layout");
+  SLV_CHECK_ARG(ws_bytes >= slv_cl16_wgrad_ws_bytes(clw, wm, wn), "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)ws;
+#define SLV_WG(A_, B_) \
+  if (wm == A_ && wn == B_) wgrad_launch<A_, B_>(g, dy_bf16, x_bf16, in_scale_shift, part, st)
+  SLV_WG(2, 2); SLV_WG(2, 3); SLV_WG(2, 4); SLV_WG(2, 5);
+  SLV_WG(3, 2); SLV_WG(3, 3); SLV_WG(3, 4); SLV_WG(3, 5);
+  SLV_WG(4, 2); SLV_WG(4, 3); SLV_WG(4, 4); SLV_WG(4, 5);
+  SLV_WG(5, 2); SLV_WG(5, 3); SLV_WG(5, 4); SLV_WG(5, 5);
+#undef SLV_WG
+  SLV_LAUNCH_CHECK();
+  const int taps = g.kt * g.kh * g.kw;
+  const int Cin_w = patch_kw ? g.Cin / patch_kw : g.Cin;        // patch mode: g.Cin = kw * C patch channels in use
+  const unsigned total = patch_kw ? (unsigned)Cout * Cin_w * taps * patch_kw : (unsigned)Cout * g.Cin * taps;
+  const size_t ldp = (size_t)g.ntiles * wn * 32;
+  hipLaunchKernelGGL(cl16_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, dw, Cout, Cin_w, taps,
+                     g.Cin_p, g.kslices, (size_t)g.mtiles * wm * 32 * ldp, ldp, patch_kw, total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_cl16_bn_act(const void* x_bf16, const float* scale_shift, const void* res_bf16, const float* res_scale_shift,
+                    int relu, void* out_bf16, int64_t P, int C, int Cp, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(x_bf16 && scale_shift && out_bf16 && P > 0 && C > 0 && Cp >= C && (Cp & 7) == 0, "bad argument");
+  const long long total = P * (Cp / 8);
+  SLV_CHECK_ARG(total < 0xFFFFFF00LL, "tensor too large");
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(cl16_bn_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x_bf16,
+                     scale_shift, (const unsigned short*)res_bf16, res_scale_shift, relu, (unsigned short*)out_bf16, C, Cp,
+                     (unsigned)total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int32_t slv_cl16_bn_bwd_nsplit(int64_t P, int Cp) {
+  const int pieces = Cp / 8, rpb = 256 / pieces > 0 ? 256 / pieces : 1;
+  // ~32 rows per thread at least, at most 1024 slices
+  long long ns = (P + (long long)rpb * 32 - 1) / ((long long)rpb * 32);
+  if (ns > 1024) ns = 1024;
+  if (ns < 1) ns = 1;
+  return (int32_t)ns;
+}
+
+int slv_cl16_bn_bwd_reduce(const void* g_bf16, const void* x_bf16, const float* mean_invstd, const float* scale_shift_mask,
+                           const void* v_mask_bf16, const void* x2_bf16, const float* mean_invstd2, void* g_out_bf16,
+                           float* partial, float* partial2, int64_t P, int C, int Cp, int nsplit, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(g_bf16 && x_bf16 && mean_invstd && partial && P > 0 && C > 0 && Cp >= C && (Cp & 7) == 0 && nsplit > 0,
+                "bad argument");
+  SLV_CHECK_ARG(!(scale_shift_mask && v_mask_bf16), "one mask at most");
+  SLV_CHECK_ARG(!v_mask_bf16 || g_out_bf16, "the masked gradient needs an output");
+  SLV_CHECK_ARG(!x2_bf16 || (mean_invstd2 && partial2), "second BatchNorm: mean_invstd2, partial2");
+  SLV_CHECK_ARG(P < 0xFFFFFF00LL && Cp <= 2048, "tensor too large");
+  const int pieces = Cp / 8, rpb = 256 / pieces > 0 ? 256 / pieces : 1;
+  SLV_CHECK_ARG(pieces <= 256, "Cp <= 2048");
+  const unsigned per = (unsigned)((P + nsplit - 1) / nsplit);
+  const size_t shb = (size_t)rpb * 3 * Cp * sizeof(float);
+  const int mask = scale_shift_mask ? 1 : (v_mask_bf16 ? 2 : 0);
+  const bool two = x2_bf16 != nullptr;
+#define SLV_R(M_, T_)                                                                                               \
+  hipLaunchKernelGGL((cl16_bn_bwd_reduce_kernel<M_, T_>), dim3(nsplit), dim3(256), shb, (hipStream_t)stream,        \
+                     (const unsigned short*)g_bf16, (const unsigned short*)x_bf16, mean_invstd, scale_shift_mask,    \
+                     (const unsigned short*)v_mask_bf16, (const unsigned short*)x2_bf16, mean_invstd2,               \
+                     (unsigned short*)g_out_bf16, partial, partial2, C, Cp, (unsigned)P, per, nsplit)
+  if (mask == 0 && !two) SLV_R(0, false);
+  else if (mask == 0) SLV_R(0, true);
+  else if (mask == 1 && !two) SLV_R(1, false);
+  else if (mask == 1) SLV_R(1, true);
+  else if (!two) SLV_R(2, false);
+  else SLV_R(2, true);
+#undef SLV_R
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_cl16_bn_bwd_apply(const void* g_bf16, const void* x_bf16, const float* bwd5, int relu, void* out_bf16, int64_t P,
+                          int C, int Cp, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(g_bf16 && x_bf16 && bwd5 && out_bf16 && P > 0 && C > 0 && Cp >= C && (Cp & 7) == 0, "bad argument");
+  const long long total = P * (Cp / 8);
+  SLV_CHECK_ARG(total < 0xFFFFFF00LL, "tensor too large");
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(cl16_bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)g_bf16, (const unsigned short*)x_bf16, bwd5, relu, (unsigned short*)out_bf16, C,
+                     Cp, (unsigned)total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_cl16_avgpool_bwd(const float* dout, void* dv_bf16, int64_t N, int64_t S, int C, int Cp, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(dout && dv_bf16 && N > 0 && S > 0 && C > 0 && Cp >= C && (Cp & 7) == 0, "bad argument");
+  const long long total = N * S * (Cp / 8);
+  SLV_CHECK_ARG(total < 0xFFFFFF00LL && S < 0x7FFFFFFFLL, "tensor too large");
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(cl16_avgpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout,
+                     (unsigned short*)dv_bf16, (unsigned)S, C, Cp, (unsigned)total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_from_cl16(const void* x_bf16, float* y, int64_t N, int C, int Cp, int64_t S, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(x_bf16 && y && N > 0 && C > 0 && Cp >= C && S > 0, "bad argument");
+  const long long total = N * C * S;
+  SLV_CHECK_ARG(total < 0xFFFFFF00LL, "tensor too large");
+  hipLaunchKernelGGL(cl16_from_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x_bf16, y, C, Cp, (unsigned)S, (unsigned)total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

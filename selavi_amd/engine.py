@@ -13,7 +13,7 @@ import torch
 
 import os
 
-from . import ops
+from . import ops as _ops32
 
 # BatchNorm-backward partial sums from the dgrad epilogue (True) or from a separate reduce pass (False)
 FUSE_BN_BWD_REDUCE = os.environ.get("SELAVI_FUSE_BNR", "1") == "1"
@@ -50,8 +50,10 @@ class Raw:
 class Ctx:
     """Execution context of one trunk pass."""
 
-    def __init__(self, training, sync=None):
+    def __init__(self, training, sync=None, ops=None):
         self.training = training
+        self.ops = ops if ops is not None else _ops32      # kernel backend: selavi_amd.ops (fp32 N,C,T,H,W) or
+                                                            # selavi_amd.ops16 (bf16 channels-last, fp32 master weights)
         self.sync = sync            # (process_group, world_size) for SyncBN or None
         self.grads = {}             # id(param) -> grad tensor
         self.grad_out = None        # id(param) -> preallocated gradient view (parallel.GradSink), or None
@@ -74,26 +76,26 @@ def conv_bn(ctx, x, conv, bn, need_dx=True):
         xin, in_ss = x.y, x.ss
     else:
         xin, in_ss = x, None
-    plan = ops.ConvPlan.get(tuple(xin.shape), conv.out_channels, conv.kernel3, conv.stride3, conv.padding3, xin.device)
+    plan = ctx.ops.plan_for(xin, conv)
     # one pass over the weights makes the forward (tap-major) and backward-data layouts of this step
     # (issuing these small kernels on the side stream was measured: no gain)
-    wf, wt = ops.conv_w_transform(plan, conv.weight, need_wt=ctx.training and need_dx)
-    y, ssum, ssq = ops.conv_fwd(plan, xin, conv.weight, in_ss=in_ss, in_relu=in_ss is not None,
+    wf, wt = ctx.ops.conv_w_transform(plan, conv.weight, need_wt=ctx.training and need_dx)
+    y, ssum, ssq = ctx.ops.conv_fwd(plan, xin, conv.weight, in_ss=in_ss, in_relu=in_ss is not None,
                                 want_stats=ctx.training, wf=wf)
     if ctx.training:
-        mi, ss = ops.bn_train_finalize(ssum, ssq, plan.count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+        mi, ss = ctx.ops.bn_train_finalize(ssum, ssq, plan.count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                        bn.momentum, bn.eps, sync=ctx.sync)
         bn.note_batch()
     else:
-        mi, ss = ops.bn_eval_params(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        mi, ss = ctx.ops.bn_eval_params(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
     return Raw(y, ss, mi, plan, conv, bn, x, wt)
 
 
 def tail(ctx, r, res=None, res_raw=None, relu=True):
     """Materialise relu(bn(r) + residual)."""
     if res_raw is not None:
-        return ops.bn_act(r.y, r.ss, res=res_raw.y, res_ss=res_raw.ss, relu=relu)
-    return ops.bn_act(r.y, r.ss, res=res, relu=relu)
+        return ctx.ops.bn_act(r.y, r.ss, res=res_raw.y, res_ss=res_raw.ss, relu=relu)
+    return ctx.ops.bn_act(r.y, r.ss, res=res, relu=relu)
 
 
 def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, keep_g=False, fuse_bn=False):
@@ -110,14 +112,14 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
     # materialise dXout once (in place over g, which is dead afterwards unless it doubles as the
     # residual addend) and feed plain tensors to both GEMMs (1.8x faster than folding the BN backward
     # into the wgrad/dgrad operand loaders, which is what round 1 started with)
-    dxo = ops.bn_bwd_apply(g, r.y, b5, a_relu, out=torch.empty_like(g) if (keep_g or addend is g) else None)
+    dxo = ctx.ops.bn_bwd_apply(g, r.y, b5, a_relu, out=torch.empty_like(g) if (keep_g or addend is g) else None)
 
     def dgrad():
-        wt = r.wt if r.wt is not None else ops.conv_wt_transform(r.plan, r.conv.weight)
-        if fuse_bn and not FUSE_BN_BWD_REDUCE:
-            return ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out), None
+        wt = r.wt if r.wt is not None else ctx.ops.conv_wt_transform(r.plan, r.conv.weight)
+        if fuse_bn and not (FUSE_BN_BWD_REDUCE and ctx.ops.FUSE_BNR):
+            return ctx.ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out), None
         bnr = (src.y, src.ss, src.mi) if fuse_bn else None
-        return ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out, bnr=bnr)
+        return ctx.ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out, bnr=bnr)
 
     w = r.conv.weight
     dw_out = ctx.grad_out.get(id(w)) if ctx.grad_out is not None else None     # persistent bucket view (parallel.py)
@@ -132,7 +134,7 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
         res = dgrad() if need_dx else None
         side.wait_event(ready)
         with torch.cuda.stream(side):
-            dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None, out=dw_out)
+            dw = ctx.ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None, out=dw_out)
         for t in (dxo, xin, in_ss):                 # allocated on `cur`, read on `side`
             if t is not None:
                 t.record_stream(side)
@@ -140,7 +142,7 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
             dw.record_stream(cur)                   # allocated on `side`, consumed by the optimizer on `cur`
         ctx.side = side
     else:
-        dw = ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None, out=dw_out)
+        dw = ctx.ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None, out=dw_out)
         res = dgrad() if need_dx else None
     ctx.grads[id(r.conv.weight)] = dw.view_as(r.conv.weight)
     return res
@@ -150,7 +152,7 @@ def bn_bwd_own(ctx, r, g, part=None):
     """BN backward coefficients for Raw r consumed through relu(bn(.)) with upstream gradient g
     (part: the partial sums, when the dgrad that produced g already formed them)."""
     dg, db = ctx.grad_like(r.bn.weight), ctx.grad_like(r.bn.bias)
-    b5, _, _ = ops.bn_bwd(g, r.y, r.mi, r.bn.weight, ss_mask=r.ss, sync=ctx.sync, dgamma=dg, dbeta=db, part=part)
+    b5, _, _ = ctx.ops.bn_bwd(g, r.y, r.mi, r.bn.weight, ss_mask=r.ss, sync=ctx.sync, dgamma=dg, dbeta=db, part=part)
     ctx.grads[id(r.bn.weight)] = dg
     ctx.grads[id(r.bn.bias)] = db
     return b5
@@ -182,12 +184,12 @@ def block_bwd(ctx, rec, dv, need_du=True):
     dg, db = ctx.grad_like(last.bn.weight), ctx.grad_like(last.bn.bias)
     if ds is not None:
         dg2, db2 = ctx.grad_like(ds.bn.weight), ctx.grad_like(ds.bn.bias)
-        b5, b5ds, dz = ops.bn_bwd(dv, last.y, last.mi, last.bn.weight, v_mask=rec.v, x2=ds.y, mi2=ds.mi,
+        b5, b5ds, dz = ctx.ops.bn_bwd(dv, last.y, last.mi, last.bn.weight, v_mask=rec.v, x2=ds.y, mi2=ds.mi,
                                   gamma2=ds.bn.weight, sync=ctx.sync, dgamma=dg, dbeta=db, dgamma2=dg2, dbeta2=db2)
         ctx.grads[id(ds.bn.weight)] = dg2
         ctx.grads[id(ds.bn.bias)] = db2
     else:
-        b5, b5ds, dz = ops.bn_bwd(dv, last.y, last.mi, last.bn.weight, v_mask=rec.v, sync=ctx.sync, dgamma=dg,
+        b5, b5ds, dz = ctx.ops.bn_bwd(dv, last.y, last.mi, last.bn.weight, v_mask=rec.v, sync=ctx.sync, dgamma=dg,
                                   dbeta=db)
     ctx.grads[id(last.bn.weight)] = dg
     ctx.grads[id(last.bn.bias)] = db
@@ -237,7 +239,7 @@ def video_stage_forward(ctx, base, stage, x):
         recs.append(rec)
         u = rec.v
     if stage == "layer4":
-        return ops.avgpool_fwd(u), (recs, u)
+        return ctx.ops.avgpool_fwd(u), (recs, u)
     return u, (recs, None)
 
 
@@ -252,7 +254,7 @@ def video_stage_backward(ctx, stage, saved, dout):
         join_side_streams(ctx)
         return None
     recs, u_last = saved
-    dv = ops.avgpool_bwd(dout.contiguous(), u_last) if stage == "layer4" else dout
+    dv = ctx.ops.avgpool_bwd(dout.contiguous(), u_last) if stage == "layer4" else dout
     for rec in reversed(recs):
         dv = block_bwd(ctx, rec, dv)
     join_side_streams(ctx)       # (joining only once per trunk would gain 0.2 ms: measured, not worth the hazard)
@@ -278,7 +280,7 @@ def audio_forward(ctx, base, spec):
     """ResNet-9/18 on 1 x F x T' spectrograms (torchvision ResNet), 2-D = 3-D with T=1."""
     x = _as5d(spec)
     r0 = conv_bn(ctx, x, base.conv1, base.bn1, need_dx=False)
-    u, idx = ops.bnrelu_maxpool_fwd(r0.y, r0.ss)
+    u, idx = ctx.ops.bnrelu_maxpool_fwd(r0.y, r0.ss)
     recs = []
     for layer in (base.layer1, base.layer2, base.layer3, base.layer4):
         for blk in layer:
@@ -287,16 +289,16 @@ def audio_forward(ctx, base, spec):
             rec = block_fwd(ctx, u, chain, ds)
             recs.append(rec)
             u = rec.v
-    feat = ops.avgpool_fwd(u)
+    feat = ctx.ops.avgpool_fwd(u)
     return feat, (x, r0, idx, recs, u)
 
 
 def audio_backward(ctx, saved, dfeat):
     x, r0, idx, recs, u_last = saved
-    dv = ops.avgpool_bwd(dfeat.contiguous(), u_last)
+    dv = ctx.ops.avgpool_bwd(dfeat.contiguous(), u_last)
     for rec in reversed(recs):
         dv = block_bwd(ctx, rec, dv)
-    dy0 = ops.maxpool_bwd(dv, idx, tuple(r0.y.shape))
+    dy0 = ctx.ops.maxpool_bwd(dv, idx, tuple(r0.y.shape))
     b5 = bn_bwd_own(ctx, r0, dy0)
     backprop_raw(ctx, r0, dy0, b5, True, need_dx=False)
     join_side_streams(ctx)

@@ -74,8 +74,8 @@ class AVModel(nn.Module):             # model.py:169-252
     def set_sync_bn(self, mode, group=None):
         """mode: 'auto' (sync iff torch.distributed is initialised with world_size > 1), True, False."""
         if mode is True:
-            import torch.distributed as dist
-            sync = (group, dist.get_world_size(group))
+            from .comm import sync_pair
+            sync = sync_pair(group)           # RCCL behind the C ABI when the backend is nccl, else the torch group
         elif mode == "auto":
             sync = "auto"
         else:
@@ -85,6 +85,15 @@ class AVModel(nn.Module):             # model.py:169-252
         self.audio_network.base.sync = sync
         for h in self._heads():
             h.sync = sync
+
+    def set_precision(self, precision):
+        """"fp32" (default; every parity claim) or "bf16": the video trunk -- 99 % of the step's FLOPs -- trains on the
+        16-bit MFMA path (what --use_fp16 / apex O1 does to the convs in the reference, main.py:151-153): bf16
+        channels-last activations and activation gradients, fp32 accumulation, fp32 master weights, BatchNorm
+        statistics and parameters in fp32, no loss scaling (bf16 has fp32's exponent range).  The audio trunk
+        (0.6 % of the FLOPs, on its own stream) and the heads stay on the fp32 kernels."""
+        assert precision in ("fp32", "bf16")
+        self.video_network.base.precision = precision
 
     def set_grad_sink(self, sink):
         """parallel.DataParallel: parameter gradients are written into the sink's flat buffers and all-reduced per

@@ -139,6 +139,7 @@ class VideoResNet(nn.Module):
         self.avgpool = Identity()
         self.fc = Identity()           # model.py:99
         self.sync = None
+        self.precision = "fp32"        # "bf16": the 16-bit MFMA path (ops16; main.py:151 --use_fp16), see AVModel.set_precision
 
     def forward(self, x):
         u = x.contiguous()
@@ -201,12 +202,21 @@ def _stage_params(trunk, stage):
     return ps
 
 
+def _backend(trunk):
+    """Kernel backend of a trunk: fp32 N,C,T,H,W (ops) or bf16 channels-last with fp32 master weights (ops16)."""
+    if getattr(trunk, "precision", "fp32") == "bf16":
+        from . import ops16
+        return ops16
+    return ops
+
+
 def _sync_of(mod):
     s = getattr(mod, "sync", None)
     if s == "auto":
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return (None, dist.get_world_size())
+            from .comm import sync_pair
+            return sync_pair(None)
         return None
     return s
 
@@ -252,18 +262,18 @@ class VideoStageFunction(torch.autograd.Function):
     def forward(fctx, trunk, stage, x, *params):
         training = trunk.training
         need_grad = training and any(fctx.needs_input_grad)
-        ectx = engine.Ctx(training, sync=_sync_of(trunk) if training else None)
+        ectx = engine.Ctx(training, sync=_sync_of(trunk) if training else None, ops=_backend(trunk))
         out, saved = engine.video_stage_forward(ectx, trunk, stage, x)
         fctx.need = need_grad
         if need_grad:
-            fctx.saved_rec, fctx.trunk, fctx.stage, fctx.sync = saved, trunk, stage, ectx.sync
+            fctx.saved_rec, fctx.trunk, fctx.stage, fctx.sync, fctx.ops = saved, trunk, stage, ectx.sync, ectx.ops
         return out
 
     @staticmethod
     def backward(fctx, dout):
         if not fctx.need:
             raise RuntimeError("selavi_amd: backward through a trunk that ran in eval / no_grad mode")
-        ectx = engine.Ctx(True, sync=fctx.sync)
+        ectx = engine.Ctx(True, sync=fctx.sync, ops=fctx.ops)
         params = _stage_params(fctx.trunk, fctx.stage)
         sink = getattr(fctx.trunk, "grad_sink", None)
         if sink is not None:

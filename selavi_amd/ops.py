@@ -109,6 +109,14 @@ class ConvPlan:
         return p
 
 
+def plan_for(xin, conv):
+    """The plan of conv layer ``conv`` (nn.Conv holder) applied to ``xin`` -- the engine's entry (ops16 has its own)."""
+    return ConvPlan.get(tuple(xin.shape), conv.out_channels, conv.kernel3, conv.stride3, conv.padding3, xin.device)
+
+
+FUSE_BNR = True          # the backward-data epilogue can form the source BatchNorm's backward partial sums
+
+
 # Per-layer-shape timing of the launch configurations at plan creation -- the counterpart of
 # `cudnn.benchmark = True` (/root/reference/main.py:187).  Off by default (deterministic heuristics);
 # selavi_amd.train / bench.py switch it on.  SELAVI_BENCHMARK=0/1 overrides.
@@ -303,9 +311,15 @@ def gemm_nt(A, B, bias=None, out=None):
 
 
 # ---------------------------------------------------------------------------------- BatchNorm
-def _allreduce(t, group):
-    import torch.distributed as dist
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+def _allreduce(t, where):
+    """where: comm.NativeComm (RCCL call on the current stream) or a torch.distributed group."""
+    from .comm import allreduce_sum_
+    allreduce_sum_(t, where)
+
+
+def _native(sync):
+    from .comm import NativeComm
+    return sync[0] if isinstance(sync[0], NativeComm) else None
 
 
 def bn_train_finalize(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps, sync=None):
@@ -320,6 +334,11 @@ def bn_train_finalize(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps,
                                 ptr(rvar), float(momentum), float(eps), ptr(mi), ptr(ss), Cc, stream())
         return mi, ss
     sums = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+    comm = _native(sync)
+    if comm is not None:        # one library call, one stream: partials -> sums -> RCCL all-reduce -> finalize
+        C.slv_bn_sync_finalize(comm.h, ptr(ssum), ptr(ssq), ssum.shape[1], float(count), ptr(gamma), ptr(beta), ptr(rmean),
+                               ptr(rvar), float(momentum), float(eps), ptr(mi), ptr(ss), Cc, ptr(sums), stream())
+        return mi, ss
     C.slv_bn_partials_to_sums(ptr(ssum), ptr(ssq), ssum.shape[1], Cc, ptr(sums), stream())
     _allreduce(sums, sync[0])
     count = count * sync[1]
@@ -365,7 +384,18 @@ def bn_bwd(g, x, mi, gamma, ss_mask=None, v_mask=None, x2=None, mi2=None, gamma2
         gout = torch.empty_like(g) if v_mask is not None else None
         C.slv_bn_bwd_reduce(ptr(g), ptr(x), ptr(mi), ptr(ss_mask), ptr(v_mask), ptr(x2), ptr(mi2), ptr(gout),
                             ptr(part), ptr(part2), Bn, Cc, P, ns, stream())
-    count = float(Bn * P)
+    outs = bn_bwd_finish(part, part2, ns, float(Bn * P), mi, gamma, ss_mask, mi2, gamma2, sync, dgamma, dbeta,
+                         dgamma2, dbeta2)
+    return outs[0], outs[1], gout
+
+
+def bn_bwd_finish(part, part2, ns, count, mi, gamma, ss_mask, mi2, gamma2, sync, dgamma, dbeta, dgamma2, dbeta2):
+    """Slice partials [C][ns][2] -> folded BatchNorm-backward coefficients bwd5 [5][C] (+ dgamma, dbeta); SyncBN: the
+    fp64 sums are all-reduced in between.  Shared by the fp32 (N,C,T,H,W) and the bf16 channels-last reductions."""
+    Cc = gamma.numel()
+    dev = gamma.device
+    comm = _native(sync) if sync is not None else None
+    local_count = count
     if sync is not None:
         count *= sync[1]
     outs = []
@@ -375,6 +405,12 @@ def bn_bwd(g, x, mi, gamma, ss_mask=None, v_mask=None, x2=None, mi2=None, gamma2
             outs.append(None)
             continue
         b5 = _f32(5, Cc, device=dev)
+        if comm is not None:
+            sums = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+            C.slv_bn_bwd_sync_finalize(comm.h, ptr(pt_), ns, local_count, ptr(ga_), ptr(mi_), ptr(ss_), ptr(b5), ptr(dg_),
+                                       ptr(db_), 0, Cc, ptr(sums), stream())
+            outs.append(b5)
+            continue
         if sync is None:
             C.slv_bn_bwd_sums_finalize(ptr(pt_), ns, count, ptr(ga_), ptr(mi_), ptr(ss_), ptr(b5), ptr(dg_), ptr(db_),
                                        0, Cc, stream())
@@ -386,7 +422,7 @@ def bn_bwd(g, x, mi, gamma, ss_mask=None, v_mask=None, x2=None, mi2=None, gamma2
         C.slv_bn_bwd_finalize(ptr(sums), count, ptr(ga_), ptr(mi_), ptr(ss_), ptr(b5), ptr(dg_), ptr(db_), 0, Cc,
                               stream())
         outs.append(b5)
-    return outs[0], outs[1], gout
+    return outs
 
 
 def bn_bwd_apply(g, x, b5, relu, out=None):

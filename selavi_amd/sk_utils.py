@@ -120,9 +120,22 @@ def softmax64(logits):
     return P
 
 
-def _allreduce(t, group):
+def _allreduce(t, group, comm=None):
+    """Sum over the ranks of ``group``: through the RCCL communicator behind the C ABI when there is one (comm.py),
+    else through torch.distributed."""
+    if comm is not None and t.is_cuda and t.dtype in (torch.float64, torch.float32, torch.int64):
+        comm.allreduce_(t)
+        return
     import torch.distributed as dist
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def _comm_of(group, backend):
+    """The native communicator of ``group`` for the HIP backend (None: torch.distributed carries the exchange)."""
+    if group is None or backend is not _HIP:
+        return None
+    from .comm import NativeComm
+    return NativeComm.for_group(group)
 
 
 def sinkhorn(P, r, lamb, N_global=None, group=None, backend=None, tol=1e-1, max_iter=2000,
@@ -134,6 +147,7 @@ def sinkhorn(P, r, lamb, N_global=None, group=None, backend=None, tol=1e-1, max_
     exactly: err is tested on counters 0,10,20,... only, so the iteration count is == 1 (mod 10)
     unless the 2000 cap hits."""
     be = backend or _HIP
+    comm = _comm_of(group, be)
     N, K = P.shape
     N_global = N if N_global is None else N_global
     dev = be.device_of(P)
@@ -146,7 +160,7 @@ def sinkhorn(P, r, lamb, N_global=None, group=None, backend=None, tol=1e-1, max_
     be.begin(P, N_global, beta, ws, grid)                       # beta = 1/N (:390), s0
     be.local_reduce(K, ws, grid)
     if group is not None:
-        _allreduce(be.s_view(ws, K, grid), group)
+        _allreduce(be.s_view(ws, K, grid), group, comm)
     be.update(r, K, tol, max_iter, True, ws, grid)              # alpha0 = r / s0
     host = [be.host_status_buffer(), be.host_status_buffer()]
     pending = []
@@ -157,6 +171,9 @@ def sinkhorn(P, r, lamb, N_global=None, group=None, backend=None, tol=1e-1, max_
         while len(pending) < 2 and n_enq < max_iter + batch:
             if group is None:
                 be.iterate(P, beta, r, tol, max_iter, batch, ws, grid)
+            elif comm is not None:      # pass, local reduce, RCCL all-reduce, update x batch: one host call, one stream
+                C.slv_sk_iterate_sharded(comm.h, ptr(P), N, N_global, K, ptr(beta), ptr(r), float(tol), int(max_iter),
+                                         int(batch), ptr(ws), grid, stream())
             else:
                 fused = getattr(be, "pass_reduce", None)        # one host call instead of two (optional in a backend)
                 sv = be.s_view(ws, K, grid)
@@ -197,7 +214,7 @@ def optimize_L_sk_gpu(args, PS, hc, logger=None, group=None, N_global=None, back
         grid = be.default_grid(N, K)
         colsum = be.colsum(PS, None, be.workspace(K, grid, dev), grid)                  # PS.sum(0) :368
         if group is not None:
-            _allreduce(colsum, group)
+            _allreduce(colsum, group, _comm_of(group, be))
         marginals_argsort = torch.argsort(colsum)
         if (args.dist is None) or args.diff_dist_every:
             if args.distribution == 'gauss':
@@ -229,7 +246,7 @@ def optimize_L_sk_gpu(args, PS, hc, logger=None, group=None, N_global=None, back
     r /= r.sum()                                                                        # :393
     L, logsum, info = sinkhorn(PS, r, args.lamb, N_global=Ng, group=group, backend=be)
     if group is not None:
-        _allreduce(logsum, group)
+        _allreduce(logsum, group, _comm_of(group, be))
     cost = -(1. / args.lamb) * float(logsum.item()) / Ng                                # :418-419
     if getattr(args, "rank", 0) == 0 and logger is not None:
         logger.info(f"error: {info['err']}, step : {info['iters']}")
@@ -253,7 +270,7 @@ def l1_cost_matrix(emb1, emb2, group=None, backend=None):
     C.slv_sk_l1_cost_matrix(ptr(emb1.contiguous()), ptr(emb2.contiguous()), N, K, ptr(part), nsplit, ptr(out),
                             stream())
     if group is not None:
-        _allreduce(out, group)
+        _allreduce(out, group, _comm_of(group, _HIP))
     return out
 
 

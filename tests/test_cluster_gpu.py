@@ -286,3 +286,65 @@ def test_two_rank_cluster_rounds_match_single_process():
         assert len(np.unique(ret[0][0][rnd][:, 0])) > 1
     np.testing.assert_array_equal(ret[0][1], ret[1][1])
     np.testing.assert_array_equal(ret[0][1], ret1[0][1])
+
+
+def _native_comm_worker(rank, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from selavi_amd import ops, sk_utils
+        from selavi_amd.comm import NativeComm
+        from tests._synth import synth_PS
+        comm = NativeComm.for_group(None)
+        assert comm is not None and comm.world == 1 and "rccl" in comm.library()
+        ret["lib"] = comm.library()
+        # collectives of one rank are the identity
+        for dt in (torch.float64, torch.float32, torch.int64):
+            t = (torch.arange(1000, device="cuda") % 17).to(dt)
+            want = t.clone()
+            comm.allreduce_(t)
+            torch.cuda.synchronize()
+            assert torch.equal(t, want), dt
+        # SyncBN in one call == the single-process finalize (same kernels, fp64 sums in between)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        Cc, nblk = 45, 37
+        ps, pq = torch.randn(Cc, nblk, device="cuda", generator=g), torch.rand(Cc, nblk, device="cuda", generator=g) * 9
+        gamma, beta = torch.rand(Cc, device="cuda", generator=g) + 0.5, torch.randn(Cc, device="cuda", generator=g)
+        outs = []
+        for sync in (None, (comm, 1)):
+            rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+            mi, ss = ops.bn_train_finalize(ps, pq, 1000.0, gamma, beta, rm, rv, 0.1, 1e-5, sync=sync)
+            outs.append(torch.cat([mi.flatten(), ss.flatten(), rm, rv]))
+        assert torch.equal(outs[0], outs[1])
+        part = torch.randn(Cc, 11, 2, device="cuda", generator=g)
+        o2 = []
+        for sync in (None, (comm, 1)):
+            dg, db = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+            b5 = ops.bn_bwd_finish(part, None, 11, 1000.0, mi, gamma, ss, None, None, sync, dg, db, None, None)[0]
+            o2.append(torch.cat([b5.flatten(), dg, db]))
+        assert torch.equal(o2[0], o2[1])
+        # sharded Sinkhorn-Knopp loop through slv_sk_iterate_sharded == the single-GPU loop
+        PS = synth_PS(2048, 28, 2.0, 3)
+
+        class A:
+            distribution, dist, diff_dist_every, diff_dist_per_head = 'default', None, False, True
+            gauss_sd, headcount, lamb, rank = 0.1, 1, 20, 0
+        c0, L0 = sk_utils.optimize_L_sk_gpu(A(), torch.from_numpy(PS).cuda(), 0, None)
+        i0 = sk_utils.optimize_L_sk_gpu.last_info["iters"]
+        c1, L1 = sk_utils.optimize_L_sk_gpu(A(), torch.from_numpy(PS).cuda(), 0, None, group=dist.group.WORLD, N_global=2048)
+        assert c0 == c1 and torch.equal(L0, L1) and sk_utils.optimize_L_sk_gpu.last_info["iters"] == i0
+        ret["ok"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_rccl_communicator_world1():
+    """RCCL behind the C ABI (slv_comm_*): unique-id bootstrap through torch.distributed, the collectives on
+    the caller's stream, the one-call SyncBN (slv_bn_sync_finalize / slv_bn_bwd_sync_finalize) and the one-call sharded
+    Sinkhorn-Knopp loop (slv_sk_iterate_sharded) against their single-process counterparts, on a world of one rank."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_native_comm_worker, args=(29810 + os.getpid() % 80, ret), nprocs=1, join=True)
+    assert ret.get("ok") and "rccl" in ret["lib"]
