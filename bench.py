@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sk", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the 16-bit leg (BASELINE configs[4])")
+    ap.add_argument("--cfg5-batch", type=int, default=CFG5["batch"], help="per-GPU batch of the 16-bit leg (cfg5: 128)")
+    ap.add_argument("--cfg5-steps", type=int, default=5)
     return ap.parse_args()
 
 
@@ -108,10 +111,14 @@ def sk_bench(rank, world, dev, iters=50):
     beta = torch.empty(n, dtype=torch.float64, device=dev)
     r = torch.full((K,), 1.0 / K, dtype=torch.float64, device=dev)
     grp = dist.group.WORLD if world > 1 else None
+    comm = sk_utils._comm_of(grp, be)        # RCCL behind the C ABI (None over gloo: torch.distributed carries it)
 
     def run(k):
         if world == 1:
             be.iterate(P, beta, r, 0.0, 10 ** 9, k, ws, grid)
+        elif comm is not None:               # the product's sharded loop: k iterations in one host call, one stream
+            from selavi_amd._lib import C, ptr, stream
+            C.slv_sk_iterate_sharded(comm.h, ptr(P), n, N, K, ptr(beta), ptr(r), 0.0, 10 ** 9, k, ptr(ws), grid, stream())
         else:
             sv = be.s_view(ws, K, grid)
             for _ in range(k):
@@ -121,7 +128,7 @@ def sk_bench(rank, world, dev, iters=50):
     be.begin(P, N, beta, ws, grid)
     be.local_reduce(K, ws, grid)
     if world > 1:
-        dist.all_reduce(be.s_view(ws, K, grid), group=grp)
+        sk_utils._allreduce(be.s_view(ws, K, grid), grp, comm)
     be.update(r, K, 0.0, 10 ** 9, True, ws, grid)
     run(5)
     torch.cuda.synchronize()
@@ -139,7 +146,7 @@ def sk_bench(rank, world, dev, iters=50):
         ms = t.item()
     gbs = n * K * 8 / ms / 1e6      # per-GPU algorithmic bytes (one read of the fp64 shard) / time
     note = None if world == 1 else ("rows sharded over %d GPUs: the pass over a shard takes ~%.0f us, each iteration is then bound by "
-                                    "the latency of its K-vector all-reduce and three host-enqueued launches" % (world, 76.0 / world))
+                                    "the latency of its K-vector all-reduce (RCCL on the compute stream, slv_sk_iterate_sharded)" % (world, 76.0 / world))
     return dict(iters_per_s=1e3 / ms, us_per_iter=ms * 1e3, N=N, K=K, rows_per_gpu=n, grid=grid, note=note,
                 roofline=dict(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
                               traffic=_pmc_traffic("sk_pass") if world == 1 else None))
@@ -202,6 +209,114 @@ def sk_round_estimate(m, dev, world, step_clips_per_s, sk):
                 "clips_per_s_including_sk": step_clips_per_s * t_train / (N / (rate16 * world) + t_sk + t_train),
                 "note": "SELAVI_FEATURE_PASS=bf16 / args.feature_pass: eval forward on bf16 channels-last activations "
                         "(selavi_amd/infer16.py); features within ~5e-3 of fp32, labels not bit-exact; off by default"}}
+
+
+CFG5 = dict(batch=128, T=32, S=112, F=129, Tp=100, K=309, hc=10)
+FWD_GFLOP_PER_CLIP_T32 = 162.08 + 0.506 + 0.0168      # SURVEY 8d, T = 32
+FWD_MB_PER_CLIP_T32_BF16 = 1036.2 / 2 + 3.38           # video bytes halve in bf16; the audio trunk stays fp32
+PEAK_BF16_MFMA_TF = 2500.0
+
+
+def hot_conv16_roofline(batch, T, dev):
+    """Dominant kernel of the 16-bit step: conv_cl16_kernel<9, PRO, EPI> on the layer-1 spatial conv
+    Conv3d(64->144,(1,3,3)) (train mode: BatchNorm + ReLU prologue on load, statistics epilogue), timed with HIP events
+    on its stream.  Algorithmic bytes = input + output in bf16 (64 + 144 channels x 2 B per position)."""
+    from selavi_amd import ops16
+
+    class Conv:
+        in_channels, out_channels, kernel3, stride3, padding3 = 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = ops16.to_channels_last16(torch.randn(batch, 64, T, 56, 56, device=dev, generator=g))
+    plan = ops16.plan_for(x, Conv)
+    w = torch.randn(144, 64, 1, 3, 3, device=dev, generator=g) * 0.04
+    ss = torch.stack([torch.rand(64, device=dev, generator=g) + 0.5, torch.randn(64, device=dev, generator=g) * 0.1]).contiguous()
+    wf, _ = ops16.conv_w_transform(plan, w, need_wt=False)
+    for _ in range(3):
+        ops16.conv_fwd(plan, x, w, in_ss=ss, in_relu=True, wf=wf)
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops16.conv_fwd(plan, x, w, in_ss=ss, in_relu=True, wf=wf)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    pos = batch * T * 56 * 56
+    return dict(ms=ms, flop=2.0 * pos * 144 * 64 * 9, bytes=pos * (64 + 144) * 2.0)
+
+
+def bf16_leg(a, rank, world, local, dev):
+    """BASELINE configs[4] ("cfg5"): large-batch stress on the 16-bit MFMA path -- per-GPU batch 128 x 32-frame clips
+    (global 1024 on 8 GPUs), video trunk in bf16 (fp32 master weights, fp32 BatchNorm statistics), audio + heads fp32."""
+    import torch.distributed as dist
+    from selavi_amd import model as smodel, optim, train
+    B, T, hc, K = a.cfg5_batch, CFG5["T"], CFG5["hc"], CFG5["K"]
+    torch.manual_seed(31)
+    m = smodel.load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', use_mlp=True, num_classes=K,
+                          pretrained=False, norm_feat=False, use_max_pool=False, headcount=hc).to(dev)
+    m.set_precision("bf16")
+    m.train()
+    net = train.data_parallel(m, [local]) if world > 1 else m
+    opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    video = torch.randn(B, 3, T, CFG5["S"], CFG5["S"], device=dev, generator=g)
+    audio = torch.randn(B, 1, CFG5["F"], CFG5["Tp"], device=dev, generator=g)
+    selflabels = torch.randint(0, K, (4096, hc), device=dev, generator=g)
+    selected = torch.randint(0, 4096, (B,), device=dev, generator=g)
+    torch.cuda.reset_peak_memory_stats(dev)
+    for _ in range(2):
+        loss = train.train_step(net, opt, video, audio, selflabels, selected, hc)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    steps = a.cfg5_steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = train.train_step(net, opt, video, audio, selflabels, selected, hc)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    peak = torch.cuda.max_memory_allocated(dev)
+    ms = dt / steps * 1e3
+    with torch.no_grad():
+        m(video, audio)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(3):
+            m(video, audio)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - tf0) / 3 * 1e3
+    hot = hot_conv16_roofline(min(B, 64), T, dev)
+    step_tf = 3 * FWD_GFLOP_PER_CLIP_T32 * B / ms
+    step_gbs = 3 * FWD_MB_PER_CLIP_T32_BF16 * B / ms
+    loss_v = float(loss.item())
+    del m, net, opt
+    return {
+        "metric": "clips/sec (video+audio fwd/bwd + loss + SGD), 16-bit MFMA path", "value": world * B * steps / dt,
+        "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": 2, "ms_per_step": ms, "dtype": "bf16",
+        "config": {"workload": "cfg5: R(2+1)D-18 in bf16 (fp32 master weights, fp32 BN statistics) + ResNet-9/heads fp32, "
+                               "per-GPU bs=%d, 32x112x112 video, 1x129x100 log-mel, K=309, headcount=10" % B,
+                   "global_batch": world * B, "parallelism": "dp%d" % world, "loss_last_step": loss_v,
+                   "peak_hbm_gb": round(peak / 2 ** 30, 2)},
+        "roofline": {"bound": "hbm", "achieved": hot["bytes"] / hot["ms"] / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": hot["bytes"] / hot["ms"] / 1e6 / PEAK_HBM_GBS, "traffic": None,
+                     "kernel": "conv_cl16_kernel<9,1,1> layer1 (1,3,3) 64->144 train forward at bs %d" % min(B, 64),
+                     "ms_per_launch": hot["ms"], "mfma_tflops": hot["flop"] / hot["ms"] / 1e9,
+                     "mfma_frac": hot["flop"] / hot["ms"] / 1e9 / PEAK_BF16_MFMA_TF,
+                     "note": "bf16: this conv's arithmetic intensity (128 FLOP/B) is below the ridge (312): HBM-bound"},
+        "step_roofline": {"mfma": {"achieved": step_tf, "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s per GPU",
+                                   "frac": step_tf / PEAK_BF16_MFMA_TF},
+                          "hbm": {"achieved": step_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s per GPU (algorithmic)",
+                                  "frac": step_gbs / PEAK_HBM_GBS}},
+        "forward": {"ms": fwd_ms, "clips_per_s_per_gpu": B / fwd_ms * 1e3,
+                    "hbm_frac": FWD_MB_PER_CLIP_T32_BF16 * B / fwd_ms / PEAK_HBM_GBS,
+                    "mfma_frac": FWD_GFLOP_PER_CLIP_T32 * B / fwd_ms / PEAK_BF16_MFMA_TF},
+    }
 
 
 def cpu_baseline(batch):
@@ -313,6 +428,17 @@ def main():
     hot = hot_conv_roofline(B, dev)
     sk = None if a.no_sk else sk_bench(rank, world, dev)
     sk_round = sk_round_estimate(m, dev, world, clips, sk) if sk else None
+    cfg5 = None
+    if not a.no_cfg5:
+        del video, audio
+        m.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+        try:
+            cfg5 = bf16_leg(a, rank, world, local, dev)
+        except Exception as e:                       # a second leg: never take the headline line down with it
+            if world > 1:
+                raise                                # (but ranks must not diverge inside collectives)
+            cfg5 = {"error": repr(e)}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.cpu_batch)
@@ -347,6 +473,7 @@ def main():
                                         "forward is MFMA-bound, its compute ceiling is 12.5 % of the HBM roofline"}},
             "sk": sk,
             "sk_round": sk_round,
+            "cfg5_bf16": cfg5,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -252,34 +252,45 @@ __global__ __launch_bounds__(256) void cl16_wgrad_reduce_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------ BatchNorm, channels last
-// out = relu?( x*s + h + (res ? (rss ? res*rs + rh : res) : 0) ) on [P][Cp] bf16; one thread per 16-byte piece
+// Elementwise kernels on [P][Cp] bf16: one thread per 16-byte piece (8 channels).  The grid stride (gridDim.x * 256) is a
+// multiple of Cp/8 (cl16_ew_blocks), so a thread keeps ITS 8 channels for every position it visits and loads their
+// per-channel coefficients once, into registers (the first version fetched them per element: 0.8 - 1.3 TB/s).
+// out = relu?( x*s + h + (res ? (rss ? res*rs + rh : res) : 0) )
+template <bool RES, bool RSS>
 __global__ __launch_bounds__(256) void cl16_bn_act_kernel(const unsigned short* __restrict__ x, const float* __restrict__ ss,
                                                           const unsigned short* __restrict__ res,
                                                           const float* __restrict__ rss, int relu,
                                                           unsigned short* __restrict__ out, int C, int Cp,
                                                           unsigned total /* P * Cp / 8 */) {
   const unsigned pieces = Cp >> 3;
-  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
-    const unsigned c0 = (idx % pieces) * 8;
+  const unsigned first = blockIdx.x * 256u + threadIdx.x, c0 = (first % pieces) * 8;
+  float s[8], h[8], rs[8], rh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bool ok = c0 + i < (unsigned)C;
+    s[i] = ok ? ss[c0 + i] : 0.f;
+    h[i] = ok ? ss[C + c0 + i] : 0.f;
+    rs[i] = (RSS && ok) ? rss[c0 + i] : 0.f;
+    rh[i] = (RSS && ok) ? rss[C + c0 + i] : 0.f;
+  }
+  const bool tail = c0 + 8 > (unsigned)C;                        // this piece holds padding channels: keep them zero
+  for (unsigned idx = first; idx < total; idx += gridDim.x * 256u) {
     const u32x4 xv = *(const u32x4*)(x + (size_t)idx * 8);
     u32x4 rv = {0u, 0u, 0u, 0u};
-    if (res) rv = *(const u32x4*)(res + (size_t)idx * 8);
+    if (RES) rv = *(const u32x4*)(res + (size_t)idx * 8);
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float v[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const unsigned c = c0 + 2 * i + e;
-        float t = 0.f;
-        if (c < (unsigned)C) {
-          t = bn_affine(e ? bf_hi(xv[i]) : bf_lo(xv[i]), ss[c], ss[C + c]);
-          if (res) {
-            const float r = e ? bf_hi(rv[i]) : bf_lo(rv[i]);
-            t += rss ? bn_affine(r, rss[c], rss[C + c]) : r;
-          }
-          if (relu) t = fmaxf(t, 0.f);
+        float t = bn_affine(e ? bf_hi(xv[i]) : bf_lo(xv[i]), s[2 * i + e], h[2 * i + e]);
+        if (RES) {
+          const float r = e ? bf_hi(rv[i]) : bf_lo(rv[i]);
+          t += RSS ? bn_affine(r, rs[2 * i + e], rh[2 * i + e]) : r;
         }
+        if (relu) t = fmaxf(t, 0.f);
+        if (tail && c0 + 2 * i + e >= (unsigned)C) t = 0.f;
         v[e] = t;
       }
       o[i] = pack_bf2(v[0], v[1]);
@@ -377,8 +388,18 @@ __global__ __launch_bounds__(256) void cl16_bn_bwd_apply_kernel(const unsigned s
                                                                 unsigned short* __restrict__ out, int C, int Cp,
                                                                 unsigned total) {
   const unsigned pieces = Cp >> 3;
-  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
-    const unsigned c0 = (idx % pieces) * 8;
+  const unsigned first = blockIdx.x * 256u + threadIdx.x, c0 = (first % pieces) * 8;
+  float s[8], h[8], a1[8], a2[8], a3[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bool ok = c0 + i < (unsigned)C;
+    s[i] = ok ? b5[c0 + i] : 0.f;
+    h[i] = ok ? b5[C + c0 + i] : 0.f;
+    a1[i] = ok ? b5[2 * C + c0 + i] : 0.f;
+    a2[i] = ok ? b5[3 * C + c0 + i] : 0.f;
+    a3[i] = ok ? b5[4 * C + c0 + i] : 0.f;
+  }
+  for (unsigned idx = first; idx < total; idx += gridDim.x * 256u) {
     const u32x4 gv = *(const u32x4*)(gin + (size_t)idx * 8);
     const u32x4 xv = *(const u32x4*)(x + (size_t)idx * 8);
     u32x4 o;
@@ -387,15 +408,11 @@ __global__ __launch_bounds__(256) void cl16_bn_bwd_apply_kernel(const unsigned s
       float v[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const unsigned c = c0 + 2 * i + e;
-        float t = 0.f;
-        if (c < (unsigned)C) {
-          const float xx = e ? bf_hi(xv[i]) : bf_lo(xv[i]);
-          float gg = e ? bf_hi(gv[i]) : bf_lo(gv[i]);
-          if (relu && !(bn_affine(xx, b5[c], b5[C + c]) > 0.f)) gg = 0.f;
-          t = b5[2 * C + c] * gg + b5[3 * C + c] + b5[4 * C + c] * xx;
-        }
-        v[e] = t;
+        const int k = 2 * i + e;
+        const float xx = e ? bf_hi(xv[i]) : bf_lo(xv[i]);
+        float gg = e ? bf_hi(gv[i]) : bf_lo(gv[i]);
+        if (relu && !(bn_affine(xx, s[k], h[k]) > 0.f)) gg = 0.f;
+        v[e] = a1[k] * gg + a2[k] + a3[k] * xx;                  // padding channels: all coefficients are zero
       }
       o[i] = pack_bf2(v[0], v[1]);
     }
@@ -429,6 +446,18 @@ __global__ __launch_bounds__(256) void cl16_from_kernel(const unsigned short* __
   if (idx >= total) return;
   const unsigned s = idx % S, c = (idx / S) % C, n = idx / (S * (unsigned)C);
   y[idx] = bf2f(x[((size_t)n * S + s) * Cp + c]);
+}
+
+// grid of an elementwise launch: gridDim.x * 256 must be a multiple of Cp / 8 (see cl16_bn_act_kernel)
+static unsigned cl16_ew_blocks(long long total, int Cp) {
+  const int pieces = Cp / 8;
+  int gcd = 256, b = pieces;
+  while (b) { const int t = gcd % b; gcd = b; b = t; }
+  const int unit = pieces / gcd;                                  // blocks must come in multiples of this
+  long long want = (total + 255) / 256;
+  if (want > 4096) want = 4096;
+  long long blocks = (want + unit - 1) / unit * unit;
+  return (unsigned)blocks;
 }
 
 template <int WM, int WN>
@@ -518,10 +547,16 @@ int slv_cl16_bn_act(const void* x_bf16, const float* scale_shift, const void* re
   SLV_CHECK_ARG(x_bf16 && scale_shift && out_bf16 && P > 0 && C > 0 && Cp >= C && (Cp & 7) == 0, "bad argument");
   const long long total = P * (Cp / 8);
   SLV_CHECK_ARG(total < 0xFFFFFF00LL, "tensor too large");
-  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(cl16_bn_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x_bf16,
-                     scale_shift, (const unsigned short*)res_bf16, res_scale_shift, relu, (unsigned short*)out_bf16, C, Cp,
-                     (unsigned)total);
+  SLV_CHECK_ARG(!res_scale_shift || res_bf16, "res_scale_shift without res");
+  const unsigned blocks = cl16_ew_blocks(total, Cp);
+#define SLV_ACT(R_, S_)                                                                                                  \
+  hipLaunchKernelGGL((cl16_bn_act_kernel<R_, S_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,                      \
+                     (const unsigned short*)x_bf16, scale_shift, (const unsigned short*)res_bf16, res_scale_shift, relu, \
+                     (unsigned short*)out_bf16, C, Cp, (unsigned)total)
+  if (!res_bf16) SLV_ACT(false, false);
+  else if (!res_scale_shift) SLV_ACT(true, false);
+  else SLV_ACT(true, true);
+#undef SLV_ACT
   SLV_LAUNCH_CHECK();
   return 0;
 }
@@ -573,7 +608,7 @@ int slv_cl16_bn_bwd_apply(const void* g_bf16, const void* x_bf16, const float* b
   SLV_CHECK_ARG(g_bf16 && x_bf16 && bwd5 && out_bf16 && P > 0 && C > 0 && Cp >= C && (Cp & 7) == 0, "bad argument");
   const long long total = P * (Cp / 8);
   SLV_CHECK_ARG(total < 0xFFFFFF00LL, "tensor too large");
-  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  const unsigned blocks = cl16_ew_blocks(total, Cp);
   hipLaunchKernelGGL(cl16_bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                      (const unsigned short*)g_bf16, (const unsigned short*)x_bf16, bwd5, relu, (unsigned short*)out_bf16, C,
                      Cp, (unsigned)total);

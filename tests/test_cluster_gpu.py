@@ -255,7 +255,10 @@ def _cluster_worker(rank, world, port, hc, K, ret):
         loader = [(torch.stack([ds[i][0] for i in range(b, b + 16)]), torch.stack([ds[i][1] for i in range(b, b + 16)]))
                   for b in range(0, 64, 16)]
         warmup_batchnorm(Args(), m, loader, batches=4)
-        args = Args(headcount=hc, rank=rank, match=True, ind_groups=2, distribution='gauss')
+        # batches of 32 on every rank AND in the single process: launch configurations (and with them the fp32 summation
+        # order of the eval forward) follow the batch shape, and on a randomly initialised model the features of all
+        # clips nearly coincide, so the assignment hinges on the last bits of the logits
+        args = Args(headcount=hc, rank=rank, match=True, ind_groups=2, distribution='gauss', sk_batch_size=32)
         np.random.seed(31)            # utils.py:277-283 seeds every rank alike; the streams diverge inside round 1
         torch.manual_seed(31)         # (only the searching rank draws match_order's pairs)
         labels = torch.zeros(192, hc, dtype=torch.long, device="cuda")

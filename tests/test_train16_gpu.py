@@ -275,16 +275,38 @@ def _step_setup(precision, hc=2, K=7, B=4, T=4, S=32):
     return m, opt, video, audio, sl, sel, hc
 
 
+def _damp(m, gamma):
+    """The last BatchNorm of every residual block starts at ``gamma``: blocks close to the identity."""
+    with torch.no_grad():
+        for li in range(1, 5):
+            for blk in getattr(m.video_network.base, f"layer{li}"):
+                blk.conv2[1].weight.fill_(gamma)
+
+
 def test_bf16_training_step_against_fp32_step():
     """The whole step with the video trunk on the 16-bit path (fp32 master weights, fp32 BatchNorm statistics) against
-    the fp32 HIP step from the same initialisation: same loss to bf16 accuracy, gradients of the video trunk aligned
-    (cosine), running statistics close; then the loss goes down over a few steps and the run is bit-reproducible."""
+    the fp32 HIP step from the same initialisation.
+
+    At random init this train-mode-BatchNorm ResNet is chaotic in its gradients: rounding ONLY the conv weights and the
+    clip to bf16 and running the fp32 kernels already turns the parameter gradients by cos 0.3-0.4
+    (tests/diag/bf16_grad_cos.py; DESIGN 5 has the fp32-vs-fp64 figures of the reference itself).  The comparison is
+    therefore made where the backward is well conditioned -- residual blocks started close to the identity (last
+    BatchNorm gamma = 0.1, the usual zero-init-residual recipe) -- and against the fp32 step fed the same bf16-rounded
+    weights and clip: there the gradients of every tensor must point the same way.  Then: the loss matches to bf16
+    accuracy, goes down over a few steps, and the run is bit-reproducible (fixed-order reductions everywhere)."""
     from selavi_amd import train
+    from selavi_amd.utils import get_loss
     outs = {}
-    for prec in ("fp32", "bf16", "bf16"):
-        m, opt, video, audio, sl, sel, hc = _step_setup(prec)
+    for tag in ("fp32r", "bf16", "bf16b"):
+        m, opt, video, audio, sl, sel, hc = _step_setup("fp32" if tag == "fp32r" else "bf16", B=8, T=8, S=64)
+        _damp(m, 0.1)
+        if tag == "fp32r":
+            with torch.no_grad():
+                for p in m.video_network.parameters():
+                    if p.dim() == 5:
+                        p.copy_(p.to(torch.bfloat16).float())
+            video = video.to(torch.bfloat16).float()
         fv, fa = m(video, audio)
-        from selavi_amd.utils import get_loss
         labels = sl[sel, :]
         loss = 0.5 * get_loss(fv, labels, headcount=hc) + 0.5 * get_loss(fa, labels, headcount=hc)
         opt.zero_grad()
@@ -293,23 +315,21 @@ def test_bf16_training_step_against_fp32_step():
         assert all(gr.dtype == torch.float32 for gr in grads.values())
         rv = m.video_network.base.layer2[0].conv1[0][1].running_var.clone()
         opt.step()
-        losses = [float(loss)] + [float(train.train_step(m, opt, video, audio, sl, sel, hc)) for _ in range(5)]
+        losses = [float(loss.detach())] + [float(train.train_step(m, opt, video, audio, sl, sel, hc)) for _ in range(5)]
         w_end = torch.cat([p.detach().flatten() for p in m.video_network.parameters()])
-        outs.setdefault(prec, []).append((losses, grads, rv, w_end))
-    (l32, g32, rv32, _), (l16, g16, rv16, w16), (l16b, _, _, w16b) = outs["fp32"][0], outs["bf16"][0], outs["bf16"][1]
-    assert abs(l16[0] - l32[0]) <= 2e-2 * abs(l32[0]), (l16[0], l32[0])
+        outs[tag] = (losses, grads, rv, w_end)
+    (l32, g32, rv32, _), (l16, g16, rv16, w16), (l16b, _, _, w16b) = outs["fp32r"], outs["bf16"], outs["bf16b"]
+    assert abs(l16[0] - l32[0]) <= 5e-3 * abs(l32[0]), (l16[0], l32[0])
     assert l16[-1] < l16[0] and np.isfinite(l16).all()
     np.testing.assert_allclose(rv16.cpu(), rv32.cpu(), rtol=5e-2, atol=1e-3)
-    worst = 1.0
+    cos = {}
     for n in g32:
         a, b = g32[n].flatten().double(), g16[n].flatten().double()
-        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
-        if a.numel() >= 512:
-            worst = min(worst, cos)
-    # train-mode BatchNorm at random init amplifies rounding (the reference's own fp32 run deviates from its
-    # fp64 run by ~1e-2): the bf16 gradients must still point the same way
-    assert worst > 0.9, worst
-    assert l16 == l16b and torch.equal(w16, w16b)                    # fixed-order reductions everywhere
+        cos[n] = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+    vals = np.array(sorted(cos.values()))
+    worst = min(cos, key=cos.get)
+    assert vals[0] > 0.9 and np.median(vals) > 0.97, (worst, vals[:5], float(np.median(vals)))
+    assert l16 == l16b and torch.equal(w16, w16b)
 
 
 def test_bf16_eval_forward_through_the_engine_matches_infer16():

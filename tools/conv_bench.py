@@ -6,27 +6,7 @@ import torch
 from selavi_amd import ops
 
 B = 16
-LAYERS = [  # name, Cin, T, H, W, Cout, k, stride, pad
-    ("stem.0", 3, 16, 112, 112, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
-    ("stem.3", 45, 16, 56, 56, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
-    ("l1.spatial", 64, 16, 56, 56, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
-    ("l1.temporal", 144, 16, 56, 56, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
-    ("l2.0.sp_s2", 64, 16, 56, 56, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
-    ("l2.0.tm_s2", 230, 16, 28, 28, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0)),
-    ("l2.1.spatial", 128, 8, 28, 28, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
-    ("l2.1.temporal", 288, 8, 28, 28, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
-    ("l2.0.ds", 64, 16, 56, 56, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
-    ("l3.0.sp_s2", 128, 8, 28, 28, 460, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
-    ("l3.0.tm_s2", 460, 8, 14, 14, 256, (3, 1, 1), (2, 1, 1), (1, 0, 0)),
-    ("l3.0.ds", 128, 8, 28, 28, 256, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
-    ("l3.1.spatial", 256, 4, 14, 14, 576, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
-    ("l3.1.temporal", 576, 4, 14, 14, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
-    ("l4.0.sp_s2", 256, 4, 14, 14, 921, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
-    ("l4.0.tm_s2", 921, 4, 7, 7, 512, (3, 1, 1), (2, 1, 1), (1, 0, 0)),
-    ("l4.0.ds", 256, 4, 14, 14, 512, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
-    ("l4.1.spatial", 512, 2, 7, 7, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
-    ("l4.1.temporal", 1152, 2, 7, 7, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
-]
+from tools.conv_bench_layers import LAYERS
 if os.environ.get("TUNE", "0") == "1":      # time with the benchmark-mode (autotuned) configurations
     ops.benchmark = True
 sel = sys.argv[1] if len(sys.argv) > 1 else ""
