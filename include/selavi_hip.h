@@ -266,6 +266,12 @@ int slv_heads_bn_apply(const float* h, const double* sums, double count, const v
 int slv_heads_ce(const float* logits, const int64_t* labels /* [B][label_stride], column g % hc */,
                  int label_stride, int hc, float* loss_rows /* [G*B] */, float* dlogits /* nullable */,
                  float grad_scale, int G, int B, int K, slv_stream_t stream);
+/* *total = scale * sum(loss_rows) in one workgroup, fixed order (the mean of utils.py:377-387 without a host-side reduce) */
+int slv_heads_ce_total(const float* loss_rows, int64_t n, float scale, float* total, slv_stream_t stream);
+/* Dropout(0.3) keep-masks of the heads (model.py:79,85) from Philox4x32-10: element e of m1 | m2 = word e % 4 of the block
+ * with counter (e / 4, offset) under key `seed`; 1.0 iff word >= p * 2^32.  Pure function of (seed, offset, e). */
+int slv_dropout_masks(uint64_t seed, uint64_t offset, float p, float* m1, int64_t n1, float* m2 /* nullable */,
+                      int64_t n2, slv_stream_t stream);
 int slv_heads_linear_bwd_w(const float* dout, const float* x, int shared_x, int hc, const float* mask,
                            float mask_scale, float* dW /* [G][OUT][IN] */, float* dbias /* nullable */,
                            int G, int B, int IN, int OUT, slv_stream_t stream);

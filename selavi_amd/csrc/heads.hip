@@ -124,6 +124,54 @@ __global__ __launch_bounds__(256) void heads_ce_kernel(const float* __restrict__
   }
 }
 
+// total = scale * sum_rows loss_rows (one workgroup, fixed order): the mean over heads and batch of utils.py:377-387
+__global__ __launch_bounds__(256) void heads_ce_total_kernel(const float* __restrict__ loss_rows, int n, float scale,
+                                                             float* __restrict__ total) {
+  __shared__ float sh[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += loss_rows[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = sh[0] * scale;
+}
+
+// Dropout keep-masks (model.py:79,85: Dropout(0.3) before each Linear of MLPv2) from Philox4x32-10 (Salmon et al.,
+// SC'11): element e of the concatenation m1 | m2 is word e % 4 of the block with counter (e / 4, offset) under key
+// seed; keep iff word >= p * 2^32.  A mask is a pure function of (seed, offset, e): no generator state on the device.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ __launch_bounds__(256) void dropout_masks_kernel(unsigned long long seed, unsigned long long offset,
+                                                            unsigned thresh, float* __restrict__ m1, size_t n1,
+                                                            float* __restrict__ m2, size_t n2) {
+  const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;      // one Philox block = 4 elements per thread
+  if (blk * 4 >= n1 + n2) return;
+  unsigned r[4];
+  philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), (unsigned)offset, (unsigned)(offset >> 32), (unsigned)seed,
+                (unsigned)(seed >> 32), r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const size_t e = blk * 4 + i;
+    const float keep = r[i] >= thresh ? 1.f : 0.f;
+    if (e < n1) m1[e] = keep;
+    else if (e < n1 + n2) m2[e - n1] = keep;
+  }
+}
+
 // dW[g][n][k] = sum_b dout[g][b][n] * Xm(g)[b][k] ; dbias[g][n] = sum_b dout[g][b][n]
 template <bool MASK>
 __global__ __launch_bounds__(256) void heads_linear_bwd_w_kernel(const float* __restrict__ dout,
@@ -331,6 +379,25 @@ int slv_heads_ce(const float* logits, const int64_t* labels, int label_stride, i
   SLV_CHECK_ARG(logits && labels && loss_rows && G > 0 && B > 0 && K > 0 && hc > 0, "bad argument");
   hipLaunchKernelGGL(heads_ce_kernel, dim3((G * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, labels,
                      label_stride, hc, loss_rows, dlogits, grad_scale, G, B, K);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_heads_ce_total(const float* loss_rows, int64_t n, float scale, float* total, slv_stream_t stream) {
+  SLV_CHECK_ARG(loss_rows && total && n > 0 && n < 0x7FFFFFFF, "bad argument");
+  hipLaunchKernelGGL(heads_ce_total_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows, (int)n, scale, total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_dropout_masks(uint64_t seed, uint64_t offset, float p, float* m1, int64_t n1, float* m2, int64_t n2,
+                      slv_stream_t stream) {
+  SLV_CHECK_ARG(m1 && n1 > 0 && n2 >= 0 && (m2 || n2 == 0) && p >= 0.f && p < 1.f, "bad argument");
+  const double t = (double)(p * 4294967296.0f);             // float product, as the oracle forms it
+  const unsigned thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+  const size_t blocks4 = ((size_t)(n1 + n2) + 3) / 4;
+  hipLaunchKernelGGL(dropout_masks_kernel, dim3((unsigned)((blocks4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (unsigned long long)seed, (unsigned long long)offset, thresh, m1, (size_t)n1, m2, (size_t)n2);
   SLV_LAUNCH_CHECK();
   return 0;
 }

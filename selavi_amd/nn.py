@@ -327,6 +327,18 @@ class LinearHead(nn.Linear):
             HeadsFunction.apply(HeadSpec([self], 1, True, False, True, None), x, x, *head_params([self]))[0]
 
 
+_DROPOUT = {"seed": None, "offset": 0}
+
+
+def _dropout_stream():
+    """(seed, offset) of the next dropout draw: Philox key = torch's seed at first use (torch.manual_seed / opt.py:152
+    control it; like the reference's per-process generators it is the same on every rank), counter offset = draws so far."""
+    if _DROPOUT["seed"] != torch.initial_seed():
+        _DROPOUT["seed"], _DROPOUT["offset"] = torch.initial_seed(), 0
+    _DROPOUT["offset"] += 1
+    return _DROPOUT["seed"] & 0xFFFFFFFFFFFFFFFF, _DROPOUT["offset"]
+
+
 class HeadSpec:
     def __init__(self, heads, hc, single, has_hidden, training, sync, masks=None, grad_sink=None):
         self.heads, self.hc, self.single, self.has_hidden = heads, hc, single, has_hidden
@@ -380,9 +392,9 @@ class HeadsFunction(torch.autograd.Function):
             if train and p > 0:
                 if spec.masks is not None:
                     m1, m2 = spec.masks
-                else:
-                    m1 = torch.bernoulli(torch.full((G, B, IN), 1 - p, device=dev))
-                    m2 = torch.bernoulli(torch.full((G, B, HID), 1 - p, device=dev))
+                else:                       # both masks in one launch of the library's own Philox (not torch's generator)
+                    m1, m2 = f32(G, B, IN), f32(G, B, HID)
+                    C.slv_dropout_masks(*_dropout_stream(), float(p), ptr(m1), m1.numel(), ptr(m2), m2.numel(), st)
                 msc = 1.0 / (1.0 - p)
             W1 = ops.PtrArray([l.weight for l in lin1])
             h = f32(G, B, HID)
@@ -413,7 +425,11 @@ class HeadsFunction(torch.autograd.Function):
             IN, K = lin[0].weight.shape[1], lin[0].weight.shape[0]
             m1, msc = None, 1.0
             if train and p > 0:
-                m1 = spec.masks[0] if spec.masks is not None else torch.bernoulli(torch.full((G, B, IN), 1 - p, device=dev))
+                if spec.masks is not None:
+                    m1 = spec.masks[0]
+                else:
+                    m1 = f32(G, B, IN)
+                    C.slv_dropout_masks(*_dropout_stream(), float(p), ptr(m1), m1.numel(), 0, 0, st)
                 msc = 1.0 / (1.0 - p)
             W, bb = ops.PtrArray([l.weight for l in lin]), ops.PtrArray([l.bias for l in lin])
             logits = f32(G, B, K)
@@ -512,8 +528,10 @@ class GroupedCE(torch.autograd.Function):
         loss_rows = torch.empty(G * B, dtype=torch.float32, device=logits.device)
         dl = torch.empty_like(logits)
         C.slv_heads_ce(ptr(logits), ptr(tg), hc, hc, ptr(loss_rows), ptr(dl), 1.0 / (G * B), G, B, K, stream())
+        total = torch.empty((), dtype=torch.float32, device=logits.device)
+        C.slv_heads_ce_total(ptr(loss_rows), G * B, 1.0 / (G * B), ptr(total), stream())
         fctx.save_for_backward(dl)
-        return loss_rows.sum() / (G * B)
+        return total
 
     @staticmethod
     def backward(fctx, gout):

@@ -550,3 +550,37 @@ def test_graphed_step_replays_bit_identically_to_eager():
     assert float(l0) == float(l1)
     for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.gpu
+def test_dropout_masks_are_philox_bit_exact_and_loss_total():
+    """slv_dropout_masks against the numpy Philox4x32-10 oracle (bit-exact, both masks of one launch, ragged sizes),
+    and the in-library loss mean against the per-row losses."""
+    from oracle.philox_ref import dropout_mask
+    from selavi_amd._lib import C, ptr, stream
+    for seed, off, p, n1, n2 in [(31, 1, 0.3, 20 * 16 * 512, 20 * 16 * 512), (2 ** 40 + 7, 2 ** 33 + 5, 0.5, 1001, 37),
+                                 (0, 0, 0.0, 5, 0)]:
+        m1 = torch.empty(n1, device="cuda")
+        m2 = torch.empty(max(n2, 1), device="cuda")
+        C.slv_dropout_masks(seed, off, p, ptr(m1), n1, ptr(m2) if n2 else 0, n2, stream())
+        want = dropout_mask(seed, off, p, n1 + n2)
+        np.testing.assert_array_equal(m1.cpu().numpy(), want[:n1])
+        if n2:
+            np.testing.assert_array_equal(m2[:n2].cpu().numpy(), want[n1:])
+    rows = torch.rand(321, device="cuda")
+    tot = torch.empty((), device="cuda")
+    C.slv_heads_ce_total(ptr(rows), 321, 1.0 / 321, ptr(tot), stream())
+    assert abs(float(tot) - float(rows.double().mean())) < 1e-6
+    # the model draws its masks from this generator: two train-mode forwards differ, a re-seeded one repeats
+    from selavi_amd import model as smodel
+    m = smodel.load_model(use_mlp=True, num_classes=7, norm_feat=False, headcount=2).cuda().train()
+    v, a = torch.randn(4, 3, 4, 32, 32, device="cuda"), torch.randn(4, 1, 40, 36, device="cuda")
+    outs = []
+    for seed in (5, 5, 6):
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            o1 = m(v, a)[0].stacked.clone()
+            o2 = m(v, a)[0].stacked.clone()
+        assert not torch.equal(o1, o2)
+        outs.append(o1)
+    assert not torch.equal(outs[0], outs[2])

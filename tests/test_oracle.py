@@ -130,3 +130,18 @@ def test_model_oracle_matches_reference_golden(golden_dir, fx):
     for k in g.files:
         if k.startswith("post/"):
             np.testing.assert_allclose(sd[k[5:]].flatten()[:64].numpy(), g[k], rtol=1e-3, atol=1e-5)
+
+
+def test_philox_oracle_known_answers():
+    """oracle/philox_ref.py against the known-answer vectors Random123 publishes for philox4x32-10 (kat_vectors)."""
+    from oracle.philox_ref import dropout_mask, philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(v) for v in philox4x32_10([ctr], key)[0]) == want
+    m = dropout_mask(31, 1, 0.3, 200000)
+    assert abs(m.mean() - 0.7) < 5e-3 and set(np.unique(m)) == {0.0, 1.0}
+    assert not np.array_equal(m, dropout_mask(31, 2, 0.3, 200000))          # another offset, another mask
+    np.testing.assert_array_equal(dropout_mask(31, 1, 0.3, 1000, first=777), m[777:1777])
