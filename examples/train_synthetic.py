@@ -40,6 +40,10 @@ def parse(argv=None):
     ap.add_argument("--wd", type=float, default=1e-5)
     ap.add_argument("--dump-path", default="")
     ap.add_argument("--bn-warmup", type=int, default=2)
+    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
+                    help="bf16: the video trunk trains on the 16-bit MFMA path (main.py:151 --use_fp16)")
+    ap.add_argument("--feature-pass", dest="feature_pass", choices=("fp32", "bf16"), default="fp32",
+                    help="arithmetic of the SK round's eval forward over the dataset (sk_utils.py:137-233)")
     a = ap.parse_args(argv)
     # what sk_utils.optimize_L_sk_gpu / cluster read from `args` (opt.py)
     a.distribution, a.dist, a.diff_dist_every, a.diff_dist_per_head = "default", None, False, True
@@ -73,6 +77,7 @@ def main(argv=None):
     model = smodel.load_model(vid_base_arch="r2plus1d_18", aud_base_arch="resnet9", use_mlp=True,
                               num_classes=args.num_clusters, pretrained=False, norm_feat=False,
                               use_max_pool=False, headcount=args.headcount).cuda()          # main.py:105-114
+    model.set_precision(args.precision)                                                     # :151-153
     optimizer = optim.SGD(model.parameters(), lr=args.base_lr, momentum=0.9, weight_decay=args.wd)   # :132-137
     net = model
     if args.world_size > 1:
@@ -122,6 +127,7 @@ def main(argv=None):
                             "optimizer": optimizer.state_dict(), "selflabels": selflabels}, ckpt)   # :223-242
     if args.world_size > 1:
         dist.destroy_process_group()
+    main.last_nmi = nmi if args.rank == 0 and args.epochs > start_epoch else None
     return log, selflabels, model
 
 

@@ -36,7 +36,7 @@ struct ClConv {
   int omt, omh, omw, oot, ooh, oow;
   int Mrows;                         // rows of the weight layout [slab][Cin_p/32][Mrows][32]
   int ntaps;
-  int tap[27];                       // (dt + 8) | (dh + 8) << 4 | (dw + 8) << 8 | weight slab << 12
+  int tap[64];                       // (dt + 8) | (dh + 8) << 4 | (dw + 8) << 8 | weight slab << 12
 };
 constexpr int CLC_WORDS = sizeof(ClConv) / 4;
 
@@ -430,7 +430,7 @@ int slv_conv_cl16_fwd(const int32_t* geom, int mt, const void* x_bf16, const voi
   SLV_CHECK_ARG(N > 0 && Cin_p > 0 && (Cin_p & 31) == 0 && Cout > 0 && Cout_p >= Cout && (Cout_p & 7) == 0,
                 "channel counts (Cin_p % 32, Cout_p % 8)");
   SLV_CHECK_ARG(kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0 && kt <= 8 && kh <= 8 && kw <= 8 &&
-                    kt * kh * kw <= 27, "kernel / stride");
+                    kt * kh * kw <= 64, "kernel / stride");
   SLV_CHECK_ARG(To == (Ti + 2 * pt - kt) / st + 1 && Ho == (Hi + 2 * ph - kh) / sh + 1 &&
                     Wo == (Wi + 2 * pw - kw) / sw + 1 && To > 0 && Ho > 0 && Wo > 0,
                 "output extent does not match the geometry");
@@ -466,7 +466,7 @@ int slv_cl16_conv(const int32_t* clconv, int mt, const void* x_bf16, const void*
                     g.Cout_p >= g.Cout && (g.Cout_p & 7) == 0, "channel counts (Cin_p % 32, Cout_p % 8)");
   SLV_CHECK_ARG(g.Lt > 0 && g.Lh > 0 && g.Lw > 0 && g.Ti > 0 && g.Hi > 0 && g.Wi > 0 && g.To > 0 && g.Ho > 0 && g.Wo > 0,
                 "extents");
-  SLV_CHECK_ARG(g.ntaps >= 0 && g.ntaps <= 27, "taps");
+  SLV_CHECK_ARG(g.ntaps >= 0 && g.ntaps <= 64, "taps");
   SLV_CHECK_ARG((g.Lt - 1) * g.omt + g.oot < g.To && (g.Lh - 1) * g.omh + g.ooh < g.Ho && (g.Lw - 1) * g.omw + g.oow < g.Wo &&
                     g.oot >= 0 && g.ooh >= 0 && g.oow >= 0 && g.omt > 0 && g.omh > 0 && g.omw > 0,
                 "the lattice does not fit the output tensor");

@@ -456,8 +456,8 @@ static unsigned cl16_ew_blocks(long long total, int Cp) {
   int gcd = 256, b = pieces;
   while (b) { const int t = gcd % b; gcd = b; b = t; }
   const int unit = pieces / gcd;                                  // blocks must come in multiples of this
-  long long want = (total + 255) / 256;
-  if (want > 4096) want = 4096;
+  long long want = (total + 2047) / 2048;                         // >= 8 pieces per thread: the per-thread coefficient loads
+  if (want > 4096) want = 4096;                                   // (up to 10 x 16 B) must not outweigh the data
   long long blocks = (want + unit - 1) / unit * unit;
   return (unsigned)blocks;
 }

@@ -125,7 +125,7 @@ def _clconv(N, Bdims, Cin_p, Cin, L, bm, bo, Odims, Cout, Cout_p, om, oo, Mrows,
     if _CLC_WORDS is None:
         _CLC_WORDS = C.slv_cl16_conv_words()
     g = np.zeros(_CLC_WORDS, dtype=np.int32)
-    assert len(taps) <= 27 and all(-8 <= d <= 7 for t in taps for d in t[:3])
+    assert len(taps) <= 64 and all(-8 <= d <= 7 for t in taps for d in t[:3])
     g[:28] = [N, *Bdims, Cin_p, Cin, *L, *bm, *bo, *Odims, Cout, Cout_p, *om, *oo, Mrows, len(taps)]
     for i, (dt, dh, dw, slab) in enumerate(taps):
         g[28 + i] = (dt + 8) | (dh + 8) << 4 | (dw + 8) << 8 | slab << 12
