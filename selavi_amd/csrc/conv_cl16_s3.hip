@@ -1,0 +1,386 @@
+// 16-bit MFMA path: the stride-1 (1,3,3) "same" convolutions -- two thirds of the video trunk's FLOPs, forward AND
+// backward data (a stride-1 backward-data conv is the same conv on flipped taps) -- with the input PATCH resident in LDS.
+//
+// csrc/conv_cl16.hip fetches every activation row once per tap (9x) and the whole weight slab once per 128 positions: the
+// kernel is bound by its L2 -> LDS traffic (17.4 KB per K-step and block), not by MFMA or HBM.  Here a block of 8 waves
+// owns 256 CONSECUTIVE positions (flat index over n,t,h,w) and, per group of 64 (or 32) input channels, loads the flat
+// run of rows [p0 - W - 1, p0 + 256 + W + 1) ONCE into LDS: every tap (dh, dw) is then the same LDS image read at a row
+// offset dh*W + dw, with the lanes whose tap falls outside the image (w + dw, h + dh out of range -- the flat run wraps
+// into the neighbouring image row / frame there) zeroed in registers.  Only the weights stream per tap.  Per 256
+// positions and 64 channels: 47 KB of activations + 9 x 18 KB of weights against 2 x 9 x 2 x 17.4 KB = 626 KB before;
+// the train-mode prologue (BatchNorm + ReLU on load) runs once per element instead of once per tap.
+//
+// Pipeline: the patch of channel group g+1 is fetched into registers at the start of group g and written to LDS at its
+// end (9 stages later); the weights of the next (tap, group) stage are fetched one stage ahead
+// (register-staged double buffer, one barrier per stage = per 2 K-steps of 32 channels).  One patch buffer: the next
+// group's rows are written behind an extra barrier after the group's last tap.  Blocks of SLV_S3_NW waves (32 positions each).
+// Epilogue as in conv_cl16.hip (transposed tile through LDS, 16-byte stores, optional statistics / affine / residual).
+#include "cl16.hpp"
+#include "../../include/selavi_hip.h"
+
+namespace slv {
+
+#ifndef SLV_S3_NW
+#define SLV_S3_NW 4
+#endif
+constexpr int S3_NW = SLV_S3_NW, S3_BN = 32 * S3_NW, S3_THREADS = 64 * S3_NW;
+constexpr int S3_PIT = (S3_BN + 2 * 56 + 2) * 8 / S3_THREADS + 1;      // S3_PIT * threads >= patch rows * 8 (W <= 56)
+#ifndef SLV_S3_ABL
+#define SLV_S3_ABL 0     // timing ablations (tools/s3_ablate.sh): 1 no MFMA, 2 no fragment reads, 3 no weight loads,
+#endif                   // 4 no output stores, 5 no barriers in the K loop, 6 no patch loads, 7 no K loop at all, 8 the K loop
+                         // twice -- results are wrong for != 0.  Measured on the layer-1 forward (0.284 ms): 7 -> 0.068 ms
+                         // (prologue + epilogue), 8 -> 0.483 (the loop is 0.2 ms), 1 -> 0.257, 3 -> 0.224, 2/4/5/6 -> 0.27-0.28:
+                         // no single resource binds; the phases of a stage (weight loads, 22 fragment reads, 36 MFMAs, LDS
+                         // writes, barrier) run back to back in 2 waves per SIMD that move in lockstep.
+
+// Channel groups of 64 (2 K-chunks of 32); an odd chunk count (160, 288, 480, 928 channels) leaves the last group with one
+template <int MT, int PRO, int EPI>
+__global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_cl16_s3_kernel(const unsigned short* __restrict__ x,
+                                                                     const unsigned short* __restrict__ wl,
+                                                                     unsigned short* __restrict__ y,
+                                                                     const float* __restrict__ in_ss,
+                                                                     const float* __restrict__ scale_shift,
+                                                                     const unsigned short* __restrict__ res, int relu,
+                                                                     float* __restrict__ stat_sum,
+                                                                     float* __restrict__ stat_sq, ClConv g, int prow) {
+  constexpr int BM = MT * 16, KCG = 2;
+  constexpr int ROWB = KCG * 64;                        // bytes per patch row: the group's channels
+  constexpr int SLOTS = KCG * 4;                        // 16-byte slots per patch row
+  constexpr int AB = BM * ROWB;                         // one weight stage: KCG blocks of [BM][64 B]
+  constexpr int APIECES = BM * SLOTS, AIT = (APIECES + S3_THREADS - 1) / S3_THREADS;
+  constexpr int OROW = BM * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int PB = prow * ROWB;
+  unsigned char* const patch0 = lds_raw;
+  unsigned char* const ast0 = lds_raw + PB;
+  float* const pro = (float*)(lds_raw + PB + 2 * AB);            // PRO 1: [2][Cin_p]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = g.Wi, H = g.Hi;
+  const unsigned P = (unsigned)g.N * g.Ti * g.Hi * g.Wi;         // lattice == input positions == output positions
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(P * (unsigned)g.Cin_p * 2u), 0x00020000);
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (XCD_REMAP) {
+    const unsigned nb = gridDim.x * gridDim.y, lin = blockIdx.x + blockIdx.y * gridDim.x, q8 = nb >> 3, r8 = nb & 7,
+                   xcd = lin & 7, loc = lin >> 3;
+    const unsigned unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    by = unit / gridDim.x;
+    bx = unit - by * gridDim.x;
+  }
+  const int m0 = by * BM;
+  const unsigned p0 = bx * S3_BN;
+  const int kcs = g.Cin_p >> 5, groups = (kcs + KCG - 1) / KCG;
+  const int nst = SLV_S3_ABL == 7 ? 0 : groups * g.ntaps;      // ablation 7: prologue + epilogue only
+  if constexpr (PRO == 1) {
+    for (int i = tid; i < 2 * g.Cin_p; i += S3_THREADS) {
+      const int c = i % g.Cin_p, which = i / g.Cin_p;
+      pro[i] = c < g.Cin ? in_ss[which * g.Cin + c] : 0.f;
+    }
+  }
+  // ---- fragment lanes: positions of this lane's two 16-position tiles, their tap-validity masks
+  const int fr = lane & 15, fk = lane >> 4;
+  int prow_l[2];                                     // patch row of the position itself (tap offset 0)
+  unsigned okm[2];                                   // bit (eh+1)*3 + (ew+1): the tap at offset (eh, ew) is inside the image
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pl = wave * 32 + j * 16 + fr;
+    const unsigned p = p0 + pl;
+    prow_l[j] = pl + W + 1;
+    const unsigned q = p / (unsigned)W;
+    const int w = p - q * W, h = q % (unsigned)H;
+    unsigned m = 0;
+    if (p < P)
+#pragma unroll
+      for (int eh = -1; eh <= 1; ++eh)
+#pragma unroll
+        for (int ew = -1; ew <= 1; ++ew)
+          if ((unsigned)(h + eh) < (unsigned)H && (unsigned)(w + ew) < (unsigned)W) m |= 1u << ((eh + 1) * 3 + ew + 1);
+    okm[j] = m;
+  }
+  // ---- loaders
+  u32x4 rp[S3_PIT], ra[AIT];
+  unsigned pvalid = 0;                               // bit i: patch piece i of this thread lies inside the tensor
+  auto load_patch = [&](int cg) __attribute__((always_inline)) {
+    pvalid = 0;
+#pragma unroll
+    for (int i = 0; i < S3_PIT; ++i) {
+      const int idx = tid + S3_THREADS * i, r = idx / SLOTS, s = idx - r * SLOTS;
+      const long long q = (long long)p0 - W - 1 + r;
+      const int c = cg * (KCG * 32) + s * 8;
+      const bool ok = r < prow && q >= 0 && q < (long long)P && c < g.Cin_p;
+      pvalid |= (unsigned)ok << i;
+      const unsigned off = (unsigned)q * (unsigned)(g.Cin_p * 2) + (unsigned)c * 2u;
+      rp[i] = SLV_S3_ABL == 6 ? (u32x4){off, 0u, 0u, 0u}
+                              : __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : 0xFFFFFFF0u, 0, 0));
+    }
+  };
+  auto store_patch = [&](int cg) __attribute__((always_inline)) {
+    unsigned char* dst = patch0;
+#pragma unroll
+    for (int i = 0; i < S3_PIT; ++i) {
+      const int idx = tid + S3_THREADS * i, r = idx / SLOTS, s = idx - r * SLOTS;
+      if (r < prow) {
+        u32x4 v = rp[i];
+        if constexpr (PRO == 1) {
+          float sc[8], sh[8];
+          const float* sp = pro + cg * (KCG * 32) + s * 8;
+          *(f32x4*)sc = *(const f32x4*)sp;
+          *(f32x4*)(sc + 4) = *(const f32x4*)(sp + 4);
+          *(f32x4*)sh = *(const f32x4*)(sp + g.Cin_p);
+          *(f32x4*)(sh + 4) = *(const f32x4*)(sp + g.Cin_p + 4);
+          const u32x4 t = affine_relu8(v, sc, sh);
+          v = ((pvalid >> i) & 1) ? t : (u32x4){0u, 0u, 0u, 0u};
+        }
+        *(u32x4*)(dst + r * ROWB + ((s ^ (r & (SLOTS - 1))) << 4)) = v;
+      }
+    }
+  };
+  auto load_a = [&](int cg, int t) __attribute__((always_inline)) {
+    const int slab = g.tap[t] >> 12;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const int pc = tid + S3_THREADS * i;
+      if (pc < APIECES) {
+        const int kl = pc / (BM * 4), rem = pc - kl * (BM * 4), kc = cg * KCG + kl;
+        ra[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (kc < kcs && SLV_S3_ABL != 3) ra[i] = *(const u32x4*)(wl + ((size_t)(slab * kcs + kc) * g.Mrows + m0) * 32 + rem * 8);
+      }
+    }
+  };
+  auto store_a = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* dst = ast0 + buf * AB;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const int pc = tid + S3_THREADS * i;
+      if (pc < APIECES) {
+        const int kl = pc / (BM * 4), rem = pc - kl * (BM * 4), row = rem >> 2;
+        *(u32x4*)(dst + kl * (BM * 64) + row * 64 + (((rem & 3) ^ cl_swz(row)) << 4)) = ra[i];
+      }
+    }
+  };
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fsw = (fk ^ cl_swz(fr)) << 4;
+  // ---- prologue of the pipeline
+  if (nst > 0) {
+    load_patch(0);
+    load_a(0, 0);
+    if constexpr (PRO == 1) __syncthreads();
+    store_patch(0);
+    store_a(0);
+    __syncthreads();
+  }
+  int cg = 0, t = 0;                                 // stage being COMPUTED
+  for (int rep = 0; rep < (SLV_S3_ABL == 8 ? 2 : 1); ++rep)      // ablation 8: the K loop twice
+  for (int st = 0; st < nst; ++st) {
+    if (SLV_S3_ABL == 8 && st == 0) { cg = 0; t = 0; }
+    int ncg = cg, nt = t + 1;                        // the next stage
+    if (nt == g.ntaps) {
+      nt = 0;
+      ++ncg;
+    }
+    const bool more = st + 1 < nst;
+    if (more) load_a(ncg, nt);
+    if (t == 0 && cg + 1 < groups) load_patch(cg + 1);
+    {
+      const int tp = g.tap[t];
+      const int eh = ((tp >> 4) & 15) - 8 + g.boh, ew = ((tp >> 8) & 15) - 8 + g.bow;
+      const int roff = eh * W + ew;
+      const unsigned bit = 1u << ((eh + 1) * 3 + ew + 1);
+      const unsigned char* A = ast0 + (st & 1) * AB;
+      const unsigned char* Bp = patch0;
+      const int live = min(KCG, kcs - cg * KCG);        // K-chunks of this group that exist
+#pragma unroll
+      for (int kl = 0; kl < KCG; ++kl) {
+        if (kl >= live) break;
+        bf16x8 b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int r = prow_l[j] + roff;
+          u32x4 v = SLV_S3_ABL == 2 ? (u32x4){(unsigned)r, 1u, 2u, 3u}
+                                    : *(const u32x4*)(Bp + r * ROWB + (((kl * 4 + fk) ^ (r & (SLOTS - 1))) << 4));
+          if (!(okm[j] & bit)) v = (u32x4){0u, 0u, 0u, 0u};
+          b[j] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const bf16x8 a = SLV_S3_ABL == 2 ? __builtin_bit_cast(bf16x8, (u32x4){(unsigned)(i + roff), 5u, 6u, 7u})
+                                           : *(const bf16x8*)(A + kl * (BM * 64) + (i * 16 + fr) * 64 + fsw);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (SLV_S3_ABL == 1) acc[i][j][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, a)[0] ^ __builtin_bit_cast(u32x4, b[j])[0]);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (more) store_a((st + 1) & 1);
+    if (t == g.ntaps - 1 && cg + 1 < groups) {       // ONE patch buffer: every wave is done with this group's rows first
+      __syncthreads();
+      store_patch(cg + 1);
+    }
+    if (SLV_S3_ABL != 5) __syncthreads();
+    cg = ncg;
+    t = nt;
+  }
+  // ---- epilogue (cf. conv_cl16.hip): transposed tile [position][cout] through LDS, 16-byte stores along the channels
+  __syncthreads();
+  unsigned char* ot = lds_raw;                          // [S3_BN][OROW]
+  float* ssl = (float*)(lds_raw + S3_BN * OROW);        // EPI 0: [2][BM]; EPI 1: [8 waves][2][BM]
+  if (EPI == 0 && scale_shift) {
+    for (int i = tid; i < 2 * BM; i += S3_THREADS) {
+      const int c = m0 + (i % BM);
+      ssl[i] = c < g.Cout ? scale_shift[(i / BM) * g.Cout + c] : 0.f;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int co = m0 + i * 16 + fk * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == 0 && scale_shift) {
+      sc = *(const f32x4*)(ssl + i * 16 + fk * 4);
+      sh = *(const f32x4*)(ssl + BM + i * 16 + fk * 4);
+    }
+    float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pl = wave * 32 + j * 16 + fr;
+      const unsigned p = p0 + pl;
+      float v[4];
+      if constexpr (EPI == 0) {
+        uint2 rr = make_uint2(0u, 0u);
+        if (res && p < P && co < g.Cout_p) rr = *(const uint2*)(res + (size_t)p * g.Cout_p + co);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float tt = acc[i][j][r] * sc[r] + sh[r];
+          if (res) tt += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
+          if (relu) tt = fmaxf(tt, 0.f);
+          v[r] = (co + r < g.Cout) ? tt : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      }
+      const unsigned lo = pack_bf2(v[0], v[1]), hi = pack_bf2(v[2], v[3]);
+      *(uint2*)(ot + pl * OROW + (i * 16 + fk * 4) * 2) = make_uint2(lo, hi);
+      if constexpr (EPI == 1) {
+        const float r0 = bf_lo(lo), r1 = bf_hi(lo), r2 = bf_lo(hi), r3 = bf_hi(hi);
+        ps[0] += r0; ps[1] += r1; ps[2] += r2; ps[3] += r3;
+        pq[0] += r0 * r0; pq[1] += r1 * r1; pq[2] += r2 * r2; pq[3] += r3 * r3;
+      }
+    }
+    if constexpr (EPI == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(ps[r]), b = row16_sum(pq[r]);
+        if (fr == 0) {
+          ssl[(wave * 2 + 0) * BM + i * 16 + fk * 4 + r] = a;
+          ssl[(wave * 2 + 1) * BM + i * 16 + fk * 4 + r] = b;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if constexpr (EPI == 1) {                              // the 8 waves' partials in fixed order -> [Cout][gridDim.x]
+    for (int i = tid; i < 2 * BM; i += S3_THREADS) {
+      const int c = i % BM, which = i / BM;
+      if (m0 + c < g.Cout) {
+        float tt = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < S3_NW; ++wv) tt += ssl[(wv * 2 + which) * BM + c];
+        (which ? stat_sq : stat_sum)[(size_t)(m0 + c) * gridDim.x + bx] = tt;
+      }
+    }
+  }
+  const int c_lo = m0, c_hi = min(m0 + BM, g.Cout_p);
+  const int c_end = (by == gridDim.y - 1) ? g.Cout_p : c_hi;
+  const int pieces = (c_end - c_lo) >> 3;
+  const float inv_pieces = 1.f / (float)pieces;
+  for (int idx = tid; idx < S3_BN * pieces; idx += S3_THREADS) {
+    const int pl = (int)(((float)idx + 0.5f) * inv_pieces), pc = idx - pl * pieces;   // exact: idx < 2^15
+    const unsigned p = p0 + pl;
+    if (p >= P) continue;
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (c_lo + pc * 8 < c_hi) val = *(const u32x4*)(ot + pl * OROW + pc * 16);
+    if (SLV_S3_ABL != 4 || val[0] == 0x12345678u) *(u32x4*)(y + (size_t)p * g.Cout_p + c_lo + pc * 8) = val;
+  }
+}
+
+// Does this launch fit the patch kernel?  Stride 1, lattice == input == output positions, every tap within one row /
+// column of the position, the patch (256 + 2W + 2 rows) within the loader's reach and the LDS.
+static bool s3_eligible(const ClConv& g) {
+  if (g.ntaps <= 0 || g.ntaps > 9) return false;
+  if (g.Lt != g.Ti || g.Lh != g.Hi || g.Lw != g.Wi || g.To != g.Ti || g.Ho != g.Hi || g.Wo != g.Wi) return false;
+  if (g.bmt != 1 || g.bmh != 1 || g.bmw != 1 || g.omt != 1 || g.omh != 1 || g.omw != 1 || g.oot || g.ooh || g.oow) return false;
+  for (int t = 0; t < g.ntaps; ++t) {
+    const int dt = (g.tap[t] & 15) - 8 + g.bot, dh = ((g.tap[t] >> 4) & 15) - 8 + g.boh, dw = ((g.tap[t] >> 8) & 15) - 8 + g.bow;
+    if (dt != 0 || dh < -1 || dh > 1 || dw < -1 || dw > 1) return false;
+  }
+  const int prow = S3_BN + 2 * g.Wi + 2;
+  if (prow * 8 > S3_PIT * S3_THREADS) return false;
+  return true;
+}
+
+template <int MT, int PRO, int EPI>
+static int s3_launch_one(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss,
+                         const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq,
+                         hipStream_t st) {
+  constexpr int BM = MT * 16, KCG = 2;
+  const int prow = S3_BN + 2 * g.Wi + 2;
+  const size_t k_loop = (size_t)prow * KCG * 64 + 2 * (size_t)BM * KCG * 64 + (PRO ? 2 * (size_t)g.Cin_p * 4 : 0);
+  const size_t epi = (size_t)S3_BN * (BM * 2 + 16) + (size_t)2 * S3_NW * BM * 4;
+  const size_t lds = k_loop > epi ? k_loop : epi;
+  if (lds > 160 * 1024) return fail(-2, "%s: the patch does not fit the LDS", "slv_cl16_conv");
+  static bool attr_set = false;                          // per instantiation; idempotent, so a race is harmless
+  if (!attr_set) {
+    SLV_HIP(hipFuncSetAttribute((const void*)conv_cl16_s3_kernel<MT, PRO, EPI>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const unsigned P = (unsigned)g.N * g.Ti * g.Hi * g.Wi;
+  dim3 grid((P + S3_BN - 1) / S3_BN, g.Mrows / BM);
+  hipLaunchKernelGGL((conv_cl16_s3_kernel<MT, PRO, EPI>), grid, dim3(S3_THREADS), lds, st, (const unsigned short*)x,
+                     (const unsigned short*)wl, (unsigned short*)y, in_ss, scale_shift, (const unsigned short*)res, relu,
+                     stat_sum, stat_sq, g, prow);
+  return 0;
+}
+
+static bool s3_enabled() {
+  static const bool enabled = []() {
+    const char* e = getenv("SELAVI_CL16_S3");
+    return !(e && e[0] == '0');
+  }();
+  return enabled;
+}
+bool cl16_s3_applies(const ClConv& g) { return s3_enabled() && s3_eligible(g); }
+int cl16_s3_positions() { return S3_BN; }
+
+// returns 1 when the launch was taken by the patch kernel, 0 when it does not apply, < 0 on error
+int cl16_s3_try(const ClConv& g, int mt, const void* x, const void* wl, void* y, const float* in_ss,
+                const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq, hipStream_t st) {
+  if (!cl16_s3_applies(g)) return 0;
+  const int pro = in_ss ? 1 : 0, epi = stat_sum ? 1 : 0;
+  int rc = 0;
+#define SLV_S3_K(MT_, PRO_, EPI_) \
+  rc = s3_launch_one<MT_, PRO_, EPI_>(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, st)
+#define SLV_S3_MT(MT_)                                  \
+  do {                                                  \
+    if (pro == 0 && epi == 0) SLV_S3_K(MT_, 0, 0);      \
+    else if (pro == 1 && epi == 0) SLV_S3_K(MT_, 1, 0); \
+    else if (pro == 0 && epi == 1) SLV_S3_K(MT_, 0, 1); \
+    else SLV_S3_K(MT_, 1, 1);                           \
+  } while (0)
+  if (mt == 4) SLV_S3_MT(4);
+  else if (mt == 8) SLV_S3_MT(8);
+  else SLV_S3_MT(9);
+#undef SLV_S3_MT
+#undef SLV_S3_K
+  if (rc) return rc;
+  rc = launch_check("slv_cl16_conv");
+  return rc ? rc : 1;
+}
+
+}  // namespace slv
