@@ -39,13 +39,14 @@ FWD_MB_PER_CLIP = 518.1 + 3.38          # sum over convs of (in + out
 def _pmc_traffic(key):
     """Measured HBM bytes/launch recorded by the PMC passes of this round (tools/pmc_traffic.sh ->
     profiles/r01_pmc.json; None if not recorded)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-        v = d.get(key)
-        if isinstance(v, dict):
-            return v.get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
+    for name in ("r02_pmc.json", "r01_pmc.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            v = d.get(key)
+            if isinstance(v, dict) and v.get("hbm_bytes_per_launch"):
+                return v.get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
     return None
 
 
@@ -321,7 +322,9 @@ def bf16_leg(a, rank, world, local, dev):
                    "global_batch": world * B, "parallelism": "dp%d" % world, "loss_last_step": loss_v,
                    "peak_hbm_gb": round(peak / 2 ** 30, 2)},
         "roofline": {"bound": "hbm", "achieved": hot["bytes"] / hot["ms"] / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": hot["bytes"] / hot["ms"] / 1e6 / PEAK_HBM_GBS, "traffic": None,
+                     "frac": hot["bytes"] / hot["ms"] / 1e6 / PEAK_HBM_GBS,
+                     # PMC bytes per launch at 16 clips x 16 frames (tools/pmc_traffic.sh), scaled to this launch's positions
+                     "traffic": (lambda t: None if t is None else t * (min(B, 64) * T) / (16.0 * 16.0))(_pmc_traffic("hot_conv16_fwd")),
                      "kernel": "conv_cl16_kernel<9,1,1> layer1 (1,3,3) 64->144 train forward at bs %d" % min(B, 64),
                      "ms_per_launch": hot["ms"], "mfma_tflops": hot["flop"] / hot["ms"] / 1e9,
                      "mfma_frac": hot["flop"] / hot["ms"] / 1e9 / PEAK_BF16_MFMA_TF,

@@ -33,7 +33,7 @@ class NativeComm:
             return None
         if os.environ.get("SELAVI_NATIVE_COMM", "1") == "0" or dist.get_backend(group) != "nccl":
             return None
-        key = id(group) if group is not None else 0
+        key = 0 if (group is None or group is dist.group.WORLD) else id(group)      # WORLD and None are the same group
         got = cls._cache.get(key)
         if got is not None:
             return got

@@ -327,16 +327,12 @@ class LinearHead(nn.Linear):
             HeadsFunction.apply(HeadSpec([self], 1, True, False, True, None), x, x, *head_params([self]))[0]
 
 
-_DROPOUT = {"seed": None, "offset": 0}
-
-
 def _dropout_stream():
-    """(seed, offset) of the next dropout draw: Philox key = torch's seed at first use (torch.manual_seed / opt.py:152
-    control it; like the reference's per-process generators it is the same on every rank), counter offset = draws so far."""
-    if _DROPOUT["seed"] != torch.initial_seed():
-        _DROPOUT["seed"], _DROPOUT["offset"] = torch.initial_seed(), 0
-    _DROPOUT["offset"] += 1
-    return _DROPOUT["seed"] & 0xFFFFFFFFFFFFFFFF, _DROPOUT["offset"]
+    """(key, counter offset) of the next dropout draw for the library's Philox (slv_dropout_masks): both are drawn from
+    torch's default CPU generator, so ``torch.manual_seed`` (opt.py:152 / utils.py:277-283) controls the masks exactly as it
+    controls the reference's -- re-seeding replays them -- without a device-side generator state or an ATen launch."""
+    v = torch.empty(2, dtype=torch.int64).random_()
+    return int(v[0]) & 0xFFFFFFFFFFFFFFFF, int(v[1]) & 0xFFFFFFFFFFFFFFFF
 
 
 class HeadSpec:

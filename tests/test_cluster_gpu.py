@@ -247,6 +247,7 @@ def _cluster_worker(rank, world, port, hc, K, ret, match=True):
         from selavi_amd.data import SyntheticAVDataset
         from selavi_amd.utils import warmup_batchnorm
         torch.cuda.set_device(0)
+        torch.manual_seed(31)         # utils.py:277-283 at start-up: the warm-up's dropout masks (head BatchNorm1d statistics)
         ds = SyntheticAVDataset(n=192, T=4, S=32, F=40, Tp=36, n_classes=K)
         m = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
         portable_init_(m, seed=31)
