@@ -333,7 +333,11 @@ int slv_avgpool_cl16(const void* x_bf16, float* y, int64_t N, int64_t S, int C, 
  *     BatchNorm + ReLU of the producing layer applied on load);
  *   stat_sum/stat_sq [Cout][slv_cl16_conv_nblk()] (nullable, together): per-channel partial sum / sum of squares of the
  *     bf16-rounded output -- the input of slv_bn_stats_finalize / slv_bn_partials_to_sums;
- *   otherwise as slv_conv_cl16_fwd (scale_shift / res / relu epilogue; res doubles as the backward-data addend).
+ *   otherwise as slv_conv_cl16_fwd (scale_shift / res / relu epilogue; res doubles as the backward-data addend);
+ *   bnr_* (backward data inside a conv chain, cf. slv_conv_dgrad): with g = the gradient as stored, x = bnr_x (raw
+ *     output of the layer that produced this conv's input) and g' = g * (x*scale + shift > 0), every channel gets
+ *     slv_cl16_conv_nblk() partial pairs bnr_part[c][bnr_slot0 + tile] = {sum g', sum g' * (x - mean) * invstd} -- the
+ *     input of slv_bn_bwd_sums[_finalize]; the parity classes of a strided layer use consecutive slot ranges.
  * slv_cl16_w_transform: fp32 [Cout][Cin][taps] -> forward layout [taps][Cin_p/32][mrows_fwd][32] and backward-data
  *   layout [taps][Cout_p/32][mrows_dgrad][32] (either nullable); patch_kw > 0: forward layout of the stem's W-patch conv.
  * slv_cl16_wgrad: dw[Cout][Cin][taps] (fp32, reference layout) = sum_pos dy[pos][co] * act(x)[pos*stride+tap-pad][ci];
@@ -344,7 +348,9 @@ int32_t slv_cl16_conv_words(void);
 int32_t slv_cl16_conv_nblk(const int32_t* clconv);
 int slv_cl16_conv(const int32_t* clconv, int mt, const void* x_bf16, const void* w_layout_bf16, void* y_bf16,
                   const float* in_scale_shift, const float* scale_shift, const void* res_bf16, int relu,
-                  float* stat_sum, float* stat_sq, slv_stream_t stream);
+                  float* stat_sum, float* stat_sq, const void* bnr_x_bf16 /* nullable: no fused reduction */,
+                  const float* bnr_scale_shift /* [2][Cout] */, const float* bnr_mean_invstd /* [2][Cout] */,
+                  float* bnr_part /* [Cout][bnr_nslots][2] */, int bnr_slot0, int bnr_nslots, slv_stream_t stream);
 int slv_cl16_w_transform(const float* w, void* wf_bf16, void* wt_bf16, int Cout, int Cin, int taps, int Cin_p,
                          int Cout_p, int mrows_fwd, int mrows_dgrad, int patch_kw, slv_stream_t stream);
 int32_t slv_cl16_wgrad_words(void);

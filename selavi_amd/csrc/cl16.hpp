@@ -67,6 +67,18 @@ struct ClConv {
 };
 constexpr int CLC_WORDS = sizeof(ClConv) / 4;
 
+// EPI 2 (backward data inside a conv chain): the gradient this launch produces is reduced right away for the BatchNorm
+// backward of the layer whose output the conv read: with x = that layer's raw output at the same positions,
+// g' = g * (x*s + h > 0), part[c][slot0 + tile][2] = { sum g', sum g' * (x - mean) * invstd } -- the input of
+// slv_bn_bwd_sums[_finalize] (replaces a separate slv_cl16_bn_bwd_reduce pass over g and x).
+struct ClBnr {
+  const unsigned short* x;      // [P_out][Cout_p] bf16, the tensor shaped like this launch's output
+  const float* ss;              // [2][Cout] scale, shift (the ReLU mask)
+  const float* mi;              // [2][Cout] mean, invstd
+  float* part;                  // [Cout][nslots][2]
+  int slot0, nslots;
+};
+
 constexpr int CL_BN = 128, CL_ROWB = 64;
 #ifndef SLV_CL16_XCD_REMAP
 #define SLV_CL16_XCD_REMAP 1
@@ -94,6 +106,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 bool cl16_s3_applies(const ClConv& g);
 int cl16_s3_positions();
 int cl16_s3_try(const ClConv& g, int mt, const void* x, const void* wl, void* y, const float* in_ss,
-                const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq, hipStream_t st);
+                const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr,
+                hipStream_t st);
 
 }  // namespace slv

@@ -25,6 +25,7 @@ namespace slv {
 //        store, and backward-data with its addend).
 // EPI 1: y = acc -> bf16 plus per-channel partial sums of y and y^2 over the block's positions, taken on the ROUNDED
 //        values the consumer will normalise: stat_sum / stat_sq [Cout][gridDim.x] (train-mode BatchNorm statistics).
+// EPI 2: EPI 0 without the affine (backward data + addend) plus the BatchNorm-backward sums of ClBnr (cl16.hpp).
 template <int MT, int PRO, int EPI>
 __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const unsigned short* __restrict__ x,
                                                            const unsigned short* __restrict__ wl,
@@ -33,13 +34,13 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
                                                            const float* __restrict__ scale_shift,   // [2][Cout] or null
                                                            const unsigned short* __restrict__ res,  // output-shaped or null
                                                            int relu, float* __restrict__ stat_sum,
-                                                           float* __restrict__ stat_sq, ClConv g) {
+                                                           float* __restrict__ stat_sq, ClBnr bn, ClConv g) {
   constexpr int BM = MT * 16;
   constexpr int APIECES = BM * 4, AITER = (APIECES + 255) / 256;
   constexpr int OROW = BM * 2 + 16;                   // bytes per position row of the transposed output tile (+16: banks)
   constexpr int STAGE = (BM + CL_BN) * CL_ROWB;
   constexpr int KLOOP = 2 * STAGE + (PRO ? 2 * CL_PRO_MAXC * 4 : 0);
-  constexpr int EPIB = CL_BN * OROW + 8 * BM * 4 + CL_BN * 4;
+  constexpr int EPIB = CL_BN * OROW + 12 * BM * 4 + CL_BN * 4;
   constexpr int LDSB = KLOOP > EPIB ? KLOOP : EPIB;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDSB];
   unsigned char(*lds)[STAGE] = (unsigned char(*)[STAGE])lds_raw;
@@ -170,7 +171,8 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
   __syncthreads();                                      // the K loop's last fragment reads are done
   unsigned char* ot = lds_raw;                          // [CL_BN][OROW]
   float* ssl = (float*)(lds_raw + CL_BN * OROW);        // EPI 0: [2][BM] scale, shift; EPI 1: [4 waves][2][BM] partials
-  unsigned* opos = (unsigned*)(lds_raw + CL_BN * OROW + 8 * BM * 4);   // [CL_BN] output position (row index) or ~0
+  float* red = ssl + (EPI == 2 ? 4 * BM : 0);           // EPI 2: [4][BM] s, h, mean, invstd first, then the partials
+  unsigned* opos = (unsigned*)(lds_raw + CL_BN * OROW + 12 * BM * 4);  // [CL_BN] output position (row index) or ~0
   if (tid < CL_BN) {
     const unsigned p = bx * CL_BN + tid;
     unsigned q = p, o = 0xFFFFFFFFu;
@@ -188,6 +190,12 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
       ssl[i] = c < g.Cout ? scale_shift[(i / BM) * g.Cout + c] : 0.f;
     }
   }
+  if constexpr (EPI == 2) {
+    for (int i = tid; i < 4 * BM; i += 256) {
+      const int c = m0 + (i % BM), which = i / BM;
+      ssl[i] = c < g.Cout ? (which < 2 ? bn.ss[which * g.Cout + c] : bn.mi[(which - 2) * g.Cout + c]) : 0.f;
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -198,12 +206,20 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
       sh = *(const f32x4*)(ssl + BM + i * 16 + fk * 4);
     }
     float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f}, bh = bs, bmean = bs, binv = bs;
+    if constexpr (EPI == 2) {
+      bs = *(const f32x4*)(ssl + i * 16 + fk * 4);
+      bh = *(const f32x4*)(ssl + BM + i * 16 + fk * 4);
+      bmean = *(const f32x4*)(ssl + 2 * BM + i * 16 + fk * 4);
+      binv = *(const f32x4*)(ssl + 3 * BM + i * 16 + fk * 4);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int pl = wave * 32 + j * 16 + fr;             // position inside the block
       float v[4];
-      if constexpr (EPI == 0) {
-        const unsigned op = opos[pl];
+      const unsigned op2 = opos[pl];
+      if constexpr (EPI != 1) {
+        const unsigned op = op2;
         uint2 rr = make_uint2(0u, 0u);
         if (res && op != 0xFFFFFFFFu && co < g.Cout_p) rr = *(const uint2*)(res + (size_t)op * g.Cout_p + co);
 #pragma unroll
@@ -224,26 +240,39 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
         ps[0] += r0; ps[1] += r1; ps[2] += r2; ps[3] += r3;
         pq[0] += r0 * r0; pq[1] += r1 * r1; pq[2] += r2 * r2; pq[3] += r3 * r3;
       }
+      if constexpr (EPI == 2) {                          // BatchNorm-backward sums of the source layer (ClBnr)
+        uint2 xr = make_uint2(0u, 0u);
+        if ((op2 != 0xFFFFFFFFu) && co < g.Cout_p) xr = *(const uint2*)(bn.x + (size_t)op2 * g.Cout_p + co);
+        const float gg[4] = {bf_lo(lo), bf_hi(lo), bf_lo(hi), bf_hi(hi)};
+        const float xx[4] = {bf_lo(xr.x), bf_hi(xr.x), bf_lo(xr.y), bf_hi(xr.y)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gm = bn_affine(xx[r], bs[r], bh[r]) > 0.f ? gg[r] : 0.f;
+          ps[r] += gm;
+          pq[r] += gm * ((xx[r] - bmean[r]) * binv[r]);
+        }
+      }
     }
-    if constexpr (EPI == 1) {                            // 16 positions per lane group -> lane fr == 0 of each group
+    if constexpr (EPI >= 1) {                            // 16 positions per lane group -> lane fr == 0 of each group
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a = row16_sum(ps[r]), b = row16_sum(pq[r]);
         if (fr == 0) {
-          ssl[(wave * 2 + 0) * BM + i * 16 + fk * 4 + r] = a;
-          ssl[(wave * 2 + 1) * BM + i * 16 + fk * 4 + r] = b;
+          red[(wave * 2 + 0) * BM + i * 16 + fk * 4 + r] = a;
+          red[(wave * 2 + 1) * BM + i * 16 + fk * 4 + r] = b;
         }
       }
     }
   }
   __syncthreads();
-  if constexpr (EPI == 1) {                              // the 4 waves' partials in fixed order -> [Cout][gridDim.x]
+  if constexpr (EPI >= 1) {                              // the 4 waves' partials in fixed order
     for (int i = tid; i < 2 * BM; i += 256) {
       const int c = i % BM, which = i / BM;
       if (m0 + c < g.Cout) {
-        const float t = ((ssl[(0 * 2 + which) * BM + c] + ssl[(1 * 2 + which) * BM + c]) + ssl[(2 * 2 + which) * BM + c]) +
-                        ssl[(3 * 2 + which) * BM + c];
-        (which ? stat_sq : stat_sum)[(size_t)(m0 + c) * gridDim.x + bx] = t;
+        const float t = ((red[(0 * 2 + which) * BM + c] + red[(1 * 2 + which) * BM + c]) + red[(2 * 2 + which) * BM + c]) +
+                        red[(3 * 2 + which) * BM + c];
+        if constexpr (EPI == 1) (which ? stat_sq : stat_sum)[(size_t)(m0 + c) * gridDim.x + bx] = t;   // [Cout][tiles]
+        else bn.part[((size_t)(m0 + c) * bn.nslots + bn.slot0 + bx) * 2 + which] = t;                  // [Cout][slots][2]
       }
     }
   }
@@ -351,22 +380,23 @@ extern "C" {
 
 static int cl16_launch(const slv::ClConv& g, int mt, const void* x, const void* wl, void* y, const float* in_ss,
                        const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq,
-                       slv_stream_t stream, const char* fn) {
+                       const slv::ClBnr& bnr, slv_stream_t stream, const char* fn) {
   using namespace slv;
   {   // stride-1 (1,3,3) convs: the LDS-resident-patch kernel (csrc/conv_cl16_s3.hip)
-    const int r = cl16_s3_try(g, mt, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, (hipStream_t)stream);
+    const int r = cl16_s3_try(g, mt, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, bnr, (hipStream_t)stream);
     if (r != 0) return r < 0 ? r : 0;
   }
   const unsigned P = (unsigned)g.N * g.Lt * g.Lh * g.Lw;
   dim3 grid((P + CL_BN - 1) / CL_BN, g.Mrows / (16 * mt));
-  const int pro = in_ss ? 1 : 0, epi = stat_sum ? 1 : 0;
+  const int pro = in_ss ? 1 : 0, epi = bnr.part ? 2 : (stat_sum ? 1 : 0);
 #define SLV_CL16(MT_, PRO_, EPI_)                                                                                     \
   hipLaunchKernelGGL((conv_cl16_kernel<MT_, PRO_, EPI_>), grid, dim3(256), 0, (hipStream_t)stream,                    \
                      (const unsigned short*)x, (const unsigned short*)wl, (unsigned short*)y, in_ss, scale_shift,     \
-                     (const unsigned short*)res, relu, stat_sum, stat_sq, g)
+                     (const unsigned short*)res, relu, stat_sum, stat_sq, bnr, g)
 #define SLV_CL16_MT(MT_)                              \
   do {                                                \
-    if (pro == 0 && epi == 0) SLV_CL16(MT_, 0, 0);    \
+    if (epi == 2) SLV_CL16(MT_, 0, 2);                \
+    else if (pro == 0 && epi == 0) SLV_CL16(MT_, 0, 0); \
     else if (pro == 1 && epi == 0) SLV_CL16(MT_, 1, 0); \
     else if (pro == 0 && epi == 1) SLV_CL16(MT_, 0, 1); \
     else SLV_CL16(MT_, 1, 1);                          \
@@ -411,15 +441,17 @@ int slv_conv_cl16_fwd(const int32_t* geom, int mt, const void* x_bf16, const voi
   for (int a = 0; a < kt; ++a)
     for (int b = 0; b < kh; ++b)
       for (int c = 0; c < kw; ++c) g.tap[g.ntaps] = (a + 8) | (b + 8) << 4 | (c + 8) << 8 | g.ntaps << 12, ++g.ntaps;
-  return cl16_launch(g, mt, x_bf16, w_layout_bf16, y_bf16, nullptr, scale_shift, res_bf16, relu, nullptr, nullptr, stream,
-                     __func__);
+  return cl16_launch(g, mt, x_bf16, w_layout_bf16, y_bf16, nullptr, scale_shift, res_bf16, relu, nullptr, nullptr,
+                     ClBnr{nullptr, nullptr, nullptr, nullptr, 0, 0}, stream, __func__);
 }
 
 int32_t slv_cl16_conv_words(void) { return slv::CLC_WORDS; }
+int32_t slv_cl16_conv_nblk(const int32_t* clconv);
 
 int slv_cl16_conv(const int32_t* clconv, int mt, const void* x_bf16, const void* w_layout_bf16, void* y_bf16,
                   const float* in_scale_shift, const float* scale_shift, const void* res_bf16, int relu,
-                  float* stat_sum, float* stat_sq, slv_stream_t stream) {
+                  float* stat_sum, float* stat_sq, const void* bnr_x_bf16, const float* bnr_scale_shift,
+                  const float* bnr_mean_invstd, float* bnr_part, int bnr_slot0, int bnr_nslots, slv_stream_t stream) {
   using namespace slv;
   SLV_CHECK_ARG(clconv && x_bf16 && w_layout_bf16 && y_bf16, "null pointer");
   ClConv g;
@@ -440,7 +472,13 @@ int slv_cl16_conv(const int32_t* clconv, int mt, const void* x_bf16, const void*
   SLV_CHECK_ARG(!in_scale_shift || g.Cin_p <= CL_PRO_MAXC, "prologue table: Cin_p <= 1152");
   SLV_CHECK_ARG((stat_sum == nullptr) == (stat_sq == nullptr), "stat_sum / stat_sq come together");
   SLV_CHECK_ARG(!stat_sum || (!scale_shift && !res_bf16), "the statistics epilogue stores the raw output");
+  SLV_CHECK_ARG(!bnr_part || (bnr_x_bf16 && bnr_scale_shift && bnr_mean_invstd && bnr_slot0 >= 0 &&
+                              bnr_slot0 + slv_cl16_conv_nblk(clconv) <= bnr_nslots),
+                "fused BatchNorm-backward sums: x, scale_shift, mean_invstd, slot range");
+  SLV_CHECK_ARG(!bnr_part || (!in_scale_shift && !stat_sum && !scale_shift && !relu),
+                "the fused sums belong to a plain backward-data launch");
   return cl16_launch(g, mt, x_bf16, w_layout_bf16, y_bf16, in_scale_shift, scale_shift, res_bf16, relu, stat_sum, stat_sq,
+                     ClBnr{(const unsigned short*)bnr_x_bf16, bnr_scale_shift, bnr_mean_invstd, bnr_part, bnr_slot0, bnr_nslots},
                      stream, __func__);
 }
 

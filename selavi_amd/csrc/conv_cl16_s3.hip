@@ -42,7 +42,7 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
                                                                      const float* __restrict__ scale_shift,
                                                                      const unsigned short* __restrict__ res, int relu,
                                                                      float* __restrict__ stat_sum,
-                                                                     float* __restrict__ stat_sq, ClConv g, int prow) {
+                                                                     float* __restrict__ stat_sq, ClBnr bn, ClConv g, int prow) {
   constexpr int BM = MT * 16, KCG = 2;
   constexpr int ROWB = KCG * 64;                        // bytes per patch row: the group's channels
   constexpr int SLOTS = KCG * 4;                        // 16-byte slots per patch row
@@ -228,11 +228,19 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
   // ---- epilogue (cf. conv_cl16.hip): transposed tile [position][cout] through LDS, 16-byte stores along the channels
   __syncthreads();
   unsigned char* ot = lds_raw;                          // [S3_BN][OROW]
-  float* ssl = (float*)(lds_raw + S3_BN * OROW);        // EPI 0: [2][BM]; EPI 1: [8 waves][2][BM]
+  float* ssl = (float*)(lds_raw + S3_BN * OROW);        // EPI 0: [2][BM]; EPI 1: [waves][2][BM]; EPI 2: [4][BM] + [waves][2][BM]
+  float* red = ssl + (EPI == 2 ? 4 * BM : 0);
   if (EPI == 0 && scale_shift) {
     for (int i = tid; i < 2 * BM; i += S3_THREADS) {
       const int c = m0 + (i % BM);
       ssl[i] = c < g.Cout ? scale_shift[(i / BM) * g.Cout + c] : 0.f;
+    }
+    __syncthreads();
+  }
+  if constexpr (EPI == 2) {
+    for (int i = tid; i < 4 * BM; i += S3_THREADS) {
+      const int c = m0 + (i % BM), which = i / BM;
+      ssl[i] = c < g.Cout ? (which < 2 ? bn.ss[which * g.Cout + c] : bn.mi[(which - 2) * g.Cout + c]) : 0.f;
     }
     __syncthreads();
   }
@@ -245,12 +253,19 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
       sh = *(const f32x4*)(ssl + BM + i * 16 + fk * 4);
     }
     float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f}, bh = bs, bmean = bs, binv = bs;
+    if constexpr (EPI == 2) {
+      bs = *(const f32x4*)(ssl + i * 16 + fk * 4);
+      bh = *(const f32x4*)(ssl + BM + i * 16 + fk * 4);
+      bmean = *(const f32x4*)(ssl + 2 * BM + i * 16 + fk * 4);
+      binv = *(const f32x4*)(ssl + 3 * BM + i * 16 + fk * 4);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int pl = wave * 32 + j * 16 + fr;
       const unsigned p = p0 + pl;
       float v[4];
-      if constexpr (EPI == 0) {
+      if constexpr (EPI != 1) {
         uint2 rr = make_uint2(0u, 0u);
         if (res && p < P && co < g.Cout_p) rr = *(const uint2*)(res + (size_t)p * g.Cout_p + co);
 #pragma unroll
@@ -271,27 +286,40 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
         ps[0] += r0; ps[1] += r1; ps[2] += r2; ps[3] += r3;
         pq[0] += r0 * r0; pq[1] += r1 * r1; pq[2] += r2 * r2; pq[3] += r3 * r3;
       }
+      if constexpr (EPI == 2) {                          // BatchNorm-backward sums of the source layer (ClBnr)
+        uint2 xr = make_uint2(0u, 0u);
+        if ((p < P) && co < g.Cout_p) xr = *(const uint2*)(bn.x + (size_t)p * g.Cout_p + co);
+        const float gg[4] = {bf_lo(lo), bf_hi(lo), bf_lo(hi), bf_hi(hi)};
+        const float xx[4] = {bf_lo(xr.x), bf_hi(xr.x), bf_lo(xr.y), bf_hi(xr.y)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gm = bn_affine(xx[r], bs[r], bh[r]) > 0.f ? gg[r] : 0.f;
+          ps[r] += gm;
+          pq[r] += gm * ((xx[r] - bmean[r]) * binv[r]);
+        }
+      }
     }
-    if constexpr (EPI == 1) {
+    if constexpr (EPI >= 1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a = row16_sum(ps[r]), b = row16_sum(pq[r]);
         if (fr == 0) {
-          ssl[(wave * 2 + 0) * BM + i * 16 + fk * 4 + r] = a;
-          ssl[(wave * 2 + 1) * BM + i * 16 + fk * 4 + r] = b;
+          red[(wave * 2 + 0) * BM + i * 16 + fk * 4 + r] = a;
+          red[(wave * 2 + 1) * BM + i * 16 + fk * 4 + r] = b;
         }
       }
     }
   }
   __syncthreads();
-  if constexpr (EPI == 1) {                              // the 8 waves' partials in fixed order -> [Cout][gridDim.x]
+  if constexpr (EPI >= 1) {                              // the waves' partials in fixed order
     for (int i = tid; i < 2 * BM; i += S3_THREADS) {
       const int c = i % BM, which = i / BM;
       if (m0 + c < g.Cout) {
         float tt = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < S3_NW; ++wv) tt += ssl[(wv * 2 + which) * BM + c];
-        (which ? stat_sq : stat_sum)[(size_t)(m0 + c) * gridDim.x + bx] = tt;
+        for (int wv = 0; wv < S3_NW; ++wv) tt += red[(wv * 2 + which) * BM + c];
+        if constexpr (EPI == 1) (which ? stat_sq : stat_sum)[(size_t)(m0 + c) * gridDim.x + bx] = tt;
+        else bn.part[((size_t)(m0 + c) * bn.nslots + bn.slot0 + bx) * 2 + which] = tt;
       }
     }
   }
@@ -327,11 +355,11 @@ static bool s3_eligible(const ClConv& g) {
 template <int MT, int PRO, int EPI>
 static int s3_launch_one(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss,
                          const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq,
-                         hipStream_t st) {
+                         const ClBnr& bnr, hipStream_t st) {
   constexpr int BM = MT * 16, KCG = 2;
   const int prow = S3_BN + 2 * g.Wi + 2;
   const size_t k_loop = (size_t)prow * KCG * 64 + 2 * (size_t)BM * KCG * 64 + (PRO ? 2 * (size_t)g.Cin_p * 4 : 0);
-  const size_t epi = (size_t)S3_BN * (BM * 2 + 16) + (size_t)2 * S3_NW * BM * 4;
+  const size_t epi = (size_t)S3_BN * (BM * 2 + 16) + (size_t)(4 + 2 * S3_NW) * BM * 4;
   const size_t lds = k_loop > epi ? k_loop : epi;
   if (lds > 160 * 1024) return fail(-2, "%s: the patch does not fit the LDS", "slv_cl16_conv");
   static bool attr_set = false;                          // per instantiation; idempotent, so a race is harmless
@@ -344,7 +372,7 @@ static int s3_launch_one(const ClConv& g, const void* x, const void* wl, void* y
   dim3 grid((P + S3_BN - 1) / S3_BN, g.Mrows / BM);
   hipLaunchKernelGGL((conv_cl16_s3_kernel<MT, PRO, EPI>), grid, dim3(S3_THREADS), lds, st, (const unsigned short*)x,
                      (const unsigned short*)wl, (unsigned short*)y, in_ss, scale_shift, (const unsigned short*)res, relu,
-                     stat_sum, stat_sq, g, prow);
+                     stat_sum, stat_sq, bnr, g, prow);
   return 0;
 }
 
@@ -360,15 +388,17 @@ int cl16_s3_positions() { return S3_BN; }
 
 // returns 1 when the launch was taken by the patch kernel, 0 when it does not apply, < 0 on error
 int cl16_s3_try(const ClConv& g, int mt, const void* x, const void* wl, void* y, const float* in_ss,
-                const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq, hipStream_t st) {
+                const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr,
+                hipStream_t st) {
   if (!cl16_s3_applies(g)) return 0;
-  const int pro = in_ss ? 1 : 0, epi = stat_sum ? 1 : 0;
+  const int pro = in_ss ? 1 : 0, epi = bnr.part ? 2 : (stat_sum ? 1 : 0);
   int rc = 0;
 #define SLV_S3_K(MT_, PRO_, EPI_) \
-  rc = s3_launch_one<MT_, PRO_, EPI_>(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, st)
+  rc = s3_launch_one<MT_, PRO_, EPI_>(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, bnr, st)
 #define SLV_S3_MT(MT_)                                  \
   do {                                                  \
-    if (pro == 0 && epi == 0) SLV_S3_K(MT_, 0, 0);      \
+    if (epi == 2) SLV_S3_K(MT_, 0, 2);                  \
+    else if (pro == 0 && epi == 0) SLV_S3_K(MT_, 0, 0); \
     else if (pro == 1 && epi == 0) SLV_S3_K(MT_, 1, 0); \
     else if (pro == 0 && epi == 1) SLV_S3_K(MT_, 0, 1); \
     else SLV_S3_K(MT_, 1, 1);                           \

@@ -482,7 +482,8 @@ __global__ void sk_sum_splits_kernel(const double* __restrict__ partial, double*
     else if (kj__ <= 5) { constexpr int KJ = 5; __VA_ARGS__; }                    \
     else if (kj__ <= 7) { constexpr int KJ = 7; __VA_ARGS__; }                    \
     else if (kj__ <= 8) { constexpr int KJ = 8; __VA_ARGS__; }                    \
-    else return ::slv::fail(-2, "%s: K > 512 is not supported", __func__);  \
+    else if (kj__ <= 12) { constexpr int KJ = 12; __VA_ARGS__; }                  \
+    else return ::slv::fail(-2, "%s: K > 768 is not supported (per-lane column registers; the reference's datasets use 309 / 400)", __func__); \
   } while (0)
 
 static inline size_t sh_bytes(int KJ) { return sizeof(double) * (SK_WAVES * KJ * 64 + SK_WAVES); }

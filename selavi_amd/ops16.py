@@ -109,7 +109,7 @@ import os
 
 from . import ops as _ops
 
-FUSE_BNR = False            # BatchNorm-backward partial sums come from slv_cl16_bn_bwd_reduce (no dgrad epilogue yet)
+FUSE_BNR = os.environ.get("SELAVI_CL16_FUSE_BNR", "1") == "1"     # BatchNorm-backward sums from the backward-data epilogue
 bn_train_finalize = _ops.bn_train_finalize
 bn_eval_params = _ops.bn_eval_params
 bnrelu_maxpool_fwd = _ops.bnrelu_maxpool_fwd        # the audio trunk stays on the fp32 kernels
@@ -217,6 +217,8 @@ class Plan16:
                     self.g_dgrad.append(_clconv(N, (To, Ho, Wo), self.Cout_p, Cout, (Lt, Lh, Lw), (1, 1, 1), (0, 0, 0),
                                                 (Ti, Hi, Wi), self.Cin, self.Cin_p, (st, sh, sw), (ct, ch, cw),
                                                 self.mrows_d, tp))
+        self.dgrad_nblk = [C.slv_cl16_conv_nblk(g_.ctypes.data) for g_ in self.g_dgrad]     # position tiles per class
+        self.bnr_slots = sum(self.dgrad_nblk)
         # ---- weight gradient: M = Cout_p, N = taps * Cin_p, K = output positions
         self.wm, self.wn = _pick_w(self.Cout_p), _pick_w(self.taps * self.Cin_p)
         mtiles, ntiles = -(-self.Cout_p // (32 * self.wm)), -(-(self.taps * self.Cin_p) // (32 * self.wn))
@@ -288,24 +290,37 @@ def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True, wf=None, ou
         ssum = torch.empty(plan.Cout, plan.nblk, dtype=torch.float32, device=x.device)
         ssq = torch.empty_like(ssum)
     C.slv_cl16_conv(plan.g_fwd.ctypes.data, plan.mt_f, ptr(x), ptr(wf), ptr(y), ptr(in_ss), 0, 0, 0, ptr(ssum), ptr(ssq),
-                    stream())
+                    0, 0, 0, 0, 0, 0, stream())
     return y, ssum, ssq
 
 
 def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out=None, bnr=None):
-    """dx = conv_transpose(dy) (+ addend): the forward kernel on the transposed weights, one launch per parity class."""
-    assert bnr is None and bwd5 is None and not plan.stem
+    """dx = conv_transpose(dy) (+ addend): the forward kernel on the transposed weights, one launch per parity class.
+    bnr = (x, scale_shift, mean_invstd) of the layer that produced this conv's input: the epilogue also emits that
+    BatchNorm's backward partial sums and (dx, part) is returned -- pass ``part`` to bn_bwd."""
+    assert bwd5 is None and not plan.stem
     dx = out if out is not None else _bf16(*plan.in_shape, device=dy.device)
     if plan.chunks is not None:
+        parts = []
         for b0, b1, sub in plan.chunks:
-            conv_dgrad(sub, dy[b0:b1], wt, addend=None if addend is None else addend[b0:b1], out=dx[b0:b1])
-        return dx
+            r = conv_dgrad(sub, dy[b0:b1], wt, addend=None if addend is None else addend[b0:b1], out=dx[b0:b1],
+                           bnr=None if bnr is None else (bnr[0][b0:b1], bnr[1], bnr[2]))
+            parts.append(r[1] if bnr is not None else None)
+        return dx if bnr is None else (dx, torch.cat(parts, 1))
     in_place = addend is not None and addend.data_ptr() == dx.data_ptr()
-    for g in plan.g_dgrad:
-        if g[27] == 0 and in_place:     # a parity class no tap reaches (1x1x1 stride-2 downsample: 7 of 8): dx = addend, as is
-            continue
-        C.slv_cl16_conv(g.ctypes.data, plan.mt_d, ptr(dy), ptr(wt), ptr(dx), 0, 0, ptr(addend), 0, 0, 0, stream())
-    return dx
+    part = rx = rss = rmi = None
+    if bnr is not None:
+        rx, rss, rmi = bnr
+        assert rx.shape == dx.shape and rx.dtype == torch.bfloat16
+        part = torch.empty(plan.Cin, plan.bnr_slots, 2, dtype=torch.float32, device=dy.device)
+    slot = 0
+    for g, nb in zip(plan.g_dgrad, plan.dgrad_nblk):
+        if g[27] == 0 and in_place and bnr is None:   # a parity class no tap reaches (1x1x1 stride-2 downsample: 7 of 8)
+            continue                                  # with dx = addend in place: nothing to do
+        C.slv_cl16_conv(g.ctypes.data, plan.mt_d, ptr(dy), ptr(wt), ptr(dx), 0, 0, ptr(addend), 0, 0, 0, ptr(rx), ptr(rss),
+                        ptr(rmi), ptr(part), slot, plan.bnr_slots, stream())
+        slot += nb
+    return dx if bnr is None else (dx, part)
 
 
 def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, in_relu=False, out=None):
@@ -345,17 +360,22 @@ def bn_act(x, ss, res=None, res_ss=None, relu=True):
 
 def bn_bwd(g, x, mi, gamma, ss_mask=None, v_mask=None, x2=None, mi2=None, gamma2=None, ss2=None, sync=None,
            dgamma=None, dbeta=None, dgamma2=None, dbeta2=None, part=None):
-    """ops.bn_bwd on channels-last bf16 tensors.  Returns (bwd5, bwd5_2, g_masked)."""
-    assert part is None
+    """ops.bn_bwd on channels-last bf16 tensors.  Returns (bwd5, bwd5_2, g_masked).  ``part``: the partial sums when
+    the backward-data conv that produced g already formed them (conv_dgrad(bnr=...))."""
     Cc = gamma.numel()
     P, Cp = _pc(x, Cc)
     dev = x.device
-    ns = C.slv_cl16_bn_bwd_nsplit(P, Cp)
-    part = torch.empty(Cc, ns, 2, dtype=torch.float32, device=dev)
-    part2 = torch.empty(Cc, ns, 2, dtype=torch.float32, device=dev) if x2 is not None else None
-    gout = torch.empty_like(g) if v_mask is not None else None
-    C.slv_cl16_bn_bwd_reduce(ptr(g), ptr(x), ptr(mi), ptr(ss_mask), ptr(v_mask), ptr(x2), ptr(mi2), ptr(gout), ptr(part),
-                             ptr(part2), P, Cc, Cp, ns, stream())
+    part2 = gout = None
+    if part is not None:
+        assert ss_mask is not None and v_mask is None and x2 is None
+        ns = part.shape[1]
+    else:
+        ns = C.slv_cl16_bn_bwd_nsplit(P, Cp)
+        part = torch.empty(Cc, ns, 2, dtype=torch.float32, device=dev)
+        part2 = torch.empty(Cc, ns, 2, dtype=torch.float32, device=dev) if x2 is not None else None
+        gout = torch.empty_like(g) if v_mask is not None else None
+        C.slv_cl16_bn_bwd_reduce(ptr(g), ptr(x), ptr(mi), ptr(ss_mask), ptr(v_mask), ptr(x2), ptr(mi2), ptr(gout),
+                                 ptr(part), ptr(part2), P, Cc, Cp, ns, stream())
     outs = _ops.bn_bwd_finish(part, part2, ns, float(P), mi, gamma, ss_mask, mi2, gamma2, sync, dgamma, dbeta, dgamma2,
                               dbeta2)
     return outs[0], outs[1], gout

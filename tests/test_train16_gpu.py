@@ -346,3 +346,32 @@ def test_bf16_eval_forward_through_the_engine_matches_infer16():
         want = infer16.Engine(m).video_features(video)
     rel = float((fv - want).norm() / want.norm())
     assert rel < 2e-2, rel
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_backward_data_epilogue_forms_the_batchnorm_backward_sums(case):
+    """conv_dgrad(bnr=(x, scale_shift, mean_invstd)): the epilogue's partial sums {sum g', sum g' xhat} with
+    g' = g * (x*s + h > 0) against the separate reduce pass over the SAME stored gradient, and dx unchanged."""
+    from selavi_amd import ops16
+    N, Cin, T, H, W, Cout, k, st, pd = case
+    g = torch.Generator().manual_seed(11 * Cin + Cout)
+    w = torch.randn(Cout, Cin, *k, generator=g) * (Cout * k[0] * k[1] * k[2]) ** -0.5
+    xsrc = _cl(_bf(torch.randn(N, Cin, T, H, W, generator=g)))
+    plan = ops16.plan_for(xsrc, _Conv(Cin, Cout, k, st, pd))
+    dy = _cl(_bf(torch.randn(N, Cout, *plan.out_dims, generator=g)))
+    _, wt = ops16.conv_w_transform(plan, w.cuda(), need_wf=False)
+    ss = torch.stack([torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3]).contiguous().cuda()
+    mi = torch.stack([torch.randn(Cin, generator=g) * 0.2, torch.rand(Cin, generator=g) + 0.5]).contiguous().cuda()
+    gamma = (torch.rand(Cin, generator=g) + 0.5).cuda()
+    dx0 = ops16.conv_dgrad(plan, dy, wt)
+    dx, part = ops16.conv_dgrad(plan, dy, wt, bnr=(xsrc, ss, mi))
+    assert torch.equal(dx, dx0) and part.shape == (Cin, plan.bnr_slots, 2)
+    outs = []
+    for p_ in (None, part):
+        dg, db = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+        b5, _, _ = ops16.bn_bwd(dx, xsrc, mi, gamma, ss_mask=ss, dgamma=dg, dbeta=db, part=p_)
+        outs.append((b5.cpu().double(), dg.cpu().double(), db.cpu().double()))
+    scale = float(outs[0][2].abs().max()) + float(outs[0][1].abs().max())
+    for a, b in zip(outs[0][1:], outs[1][1:]):                       # same addends, another summation order
+        np.testing.assert_allclose(b, a, rtol=2e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=2e-3, atol=1e-5 * (1 + float(outs[0][0].abs().max())))
