@@ -236,7 +236,7 @@ PEAK_BF16_MFMA_TF = 2500.0
 
 
 def hot_conv16_roofline(batch, T, dev):
-    """Dominant kernel of the 16-bit step: conv_cl16_kernel<9, PRO, EPI> on the layer-1 spatial conv
+    """Dominant kernel of the 16-bit step: conv_cl16_s3_kernel<9, PRO, EPI> (csrc/conv_cl16_s3.hip) on the layer-1 spatial conv
     Conv3d(64->144,(1,3,3)) (train mode: BatchNorm + ReLU prologue on load, statistics epilogue), timed with HIP events
     on its stream.  Algorithmic bytes = input + output in bf16 (64 + 144 channels x 2 B per position)."""
     from selavi_amd import ops16
@@ -325,7 +325,7 @@ def bf16_leg(a, rank, world, local, dev):
                      "frac": hot["bytes"] / hot["ms"] / 1e6 / PEAK_HBM_GBS,
                      # PMC bytes per launch at 16 clips x 16 frames (tools/pmc_traffic.sh), scaled to this launch's positions
                      "traffic": (lambda t: None if t is None else t * (min(B, 64) * T) / (16.0 * 16.0))(_pmc_traffic("hot_conv16_fwd")),
-                     "kernel": "conv_cl16_kernel<9,1,1> layer1 (1,3,3) 64->144 train forward at bs %d" % min(B, 64),
+                     "kernel": "conv_cl16_s3_kernel<9,1,1> (LDS-resident patch) layer1 (1,3,3) 64->144 train forward at bs %d" % min(B, 64),
                      "ms_per_launch": hot["ms"], "mfma_tflops": hot["flop"] / hot["ms"] / 1e9,
                      "mfma_frac": hot["flop"] / hot["ms"] / 1e9 / PEAK_BF16_MFMA_TF,
                      "note": "bf16: this conv's arithmetic intensity (128 FLOP/B) is below the ridge (312): HBM-bound"},

@@ -248,9 +248,14 @@ __global__ __launch_bounds__(256) void cl16_wgrad_reduce_kernel(const float* __r
     out = ((size_t)co * Cin + cc) * taps + tap;
   }
   const float* p = part + (size_t)co * ldp + col;
-  float s = 0.f;
-  for (int i = 0; i < slices; ++i) s += p[(size_t)i * slice_stride];
-  dw[out] = s;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};                 // four interleaved chains (the loads of one chain are dependent adds),
+  int i = 0;                                          // combined in a fixed order
+  for (; i + 4 <= slices; i += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] += p[(size_t)(i + u) * slice_stride];
+  }
+  for (; i < slices; ++i) s4[i & 3] += p[(size_t)i * slice_stride];
+  dw[out] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
 // ------------------------------------------------------------------------------------------ BatchNorm, channels last

@@ -109,7 +109,11 @@ import os
 
 from . import ops as _ops
 
-FUSE_BNR = os.environ.get("SELAVI_CL16_FUSE_BNR", "1") == "1"     # BatchNorm-backward sums from the backward-data epilogue
+# BatchNorm-backward sums from the backward-data epilogue (conv_dgrad(bnr=...), EPI 2): implemented and tested, OFF by
+# default -- in the step the epilogue's reads of x in accumulator layout (8-byte pieces, one row per lane) cost the
+# layer-1 backward-data launches +300 us against the 45-110 us of the separate coalesced reduce pass it replaces
+# (profiles/r02_notes.md); SELAVI_CL16_FUSE_BNR=1 switches it on.
+FUSE_BNR = os.environ.get("SELAVI_CL16_FUSE_BNR", "0") == "1"
 bn_train_finalize = _ops.bn_train_finalize
 bn_eval_params = _ops.bn_eval_params
 bnrelu_maxpool_fwd = _ops.bnrelu_maxpool_fwd        # the audio trunk stays on the fp32 kernels
@@ -223,7 +227,7 @@ class Plan16:
         self.wm, self.wn = _pick_w(self.Cout_p), _pick_w(self.taps * self.Cin_p)
         mtiles, ntiles = -(-self.Cout_p // (32 * self.wm)), -(-(self.taps * self.Cin_p) // (32 * self.wn))
         P = N * To * Ho * Wo
-        ksl = max(1, min(-(-768 // (mtiles * ntiles)), -(-P // 256)))
+        ksl = max(1, min(-(-768 // (mtiles * ntiles)), P // 2048))     # >= 64 K-steps per slice: the reduce reads every slice
         kper = -(-(-(-P // ksl)) // 32) * 32
         ksl = -(-P // kper)
         self.g_wgrad = np.array([N, Ti, Hi, Wi, self.Cin_p, self.Cin, To, Ho, Wo, self.Cout_p, st, sh, sw, pt, ph, pw,
