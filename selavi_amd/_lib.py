@@ -64,6 +64,10 @@ def load():
         raise SelaviHipError(
             f"{LIBPATH} is missing: run `python -m selavi_amd.build` (hipcc, gfx950). "
             "selavi_amd has no CPU fallback.")
+    # ONE HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and must be in the process first, so that the
+    # library's NEEDED entry resolves to that copy; loaded the other way round, the kernels of this library would launch
+    # through a second runtime (/opt/rocm's) that shares nothing with the tensors torch allocates
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIBPATH)
     _decls = parse_header()
     for name, (ret, args) in _decls.items():

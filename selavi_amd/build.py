@@ -23,7 +23,7 @@ def _digest():
     files = sorted(glob.glob(os.path.join(CSRC, "*")) +
                    glob.glob(os.path.join(HERE, "..", "include", "*.h")))
     for f in files:
-        h.update(f.encode())
+        h.update(os.path.basename(f).encode())        # (not the absolute path: the GPU box mounts the repo elsewhere)
         h.update(open(f, "rb").read())
     return h.hexdigest()
 

@@ -15,8 +15,11 @@ inline int fail(int code, const char* fmt, const char* a = "") {
   return code;
 }
 
+// (also drops a stale error another library left in this thread's HIP state: SLV_LAUNCH_CHECK reads hipGetLastError and
+// must only see what THIS entry point's launches produced)
 #define SLV_CHECK_ARG(cond, msg)                                              \
   do {                                                                        \
+    (void)hipGetLastError();                                                  \
     if (!(cond)) return ::slv::fail(-2, "%s: bad argument: " msg, __func__);  \
   } while (0)
 
