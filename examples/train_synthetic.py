@@ -40,6 +40,7 @@ def parse(argv=None):
     ap.add_argument("--wd", type=float, default=1e-5)
     ap.add_argument("--dump-path", default="")
     ap.add_argument("--bn-warmup", type=int, default=2)
+    ap.add_argument("--seed", type=int, default=31, help="opt.py:152")
     ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
                     help="bf16: the video trunk trains on the 16-bit MFMA path (main.py:151 --use_fp16)")
     ap.add_argument("--feature-pass", dest="feature_pass", choices=("fp32", "bf16"), default="fp32",
@@ -65,8 +66,8 @@ def main(argv=None):
         dist.init_process_group(os.environ.get("SELAVI_BENCH_DIST_BACKEND", "nccl"), rank=args.rank,
                                 world_size=args.world_size)
         group = dist.group.WORLD
-    torch.manual_seed(31)                                                   # opt.py:152
-    np.random.seed(31)
+    torch.manual_seed(args.seed)                                            # opt.py:152
+    np.random.seed(args.seed)
     ops.set_benchmark(True)                                                 # main.py:187
 
     dataset = SyntheticAVDataset(n=args.n, T=args.frames, S=args.size, F=args.mel[0], Tp=args.mel[1],

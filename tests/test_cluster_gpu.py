@@ -89,7 +89,7 @@ def test_cluster_round_matches_oracle_reenactment(hc, K):
         assert agree == 1.0, f"head {h}: {agree:.3f} agreement with the oracle"
 
 
-def _ddp_worker(rank, world, port, ret, wrap=False):
+def _ddp_worker(rank, world, port, ret, wrap=False, precision="fp32"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -101,6 +101,7 @@ def _ddp_worker(rank, world, port, ret, wrap=False):
         portable_init_(m, seed=31)
         step_ref.set_dropout_p(m, 0.0)
         m = m.cuda().train()
+        m.set_precision(precision)
         if wrap == "native":
             net = train.data_parallel(m, [0], kind="native")
         elif wrap:
@@ -187,6 +188,21 @@ def test_two_rank_native_data_parallel_is_bit_identical_to_ddp():
     differs = [k for k in ret[0][2] if ret[0][2][k] != ret_ddp[0][2][k]]
     assert not differs, f"{len(differs)} of {len(ret[0][2])} tensors differ from DDP: {differs[:6]}"
     assert ret[0][0] == ret_ddp[0][0] and ret[0][1] == ret_ddp[0][1]
+
+
+def test_two_rank_native_data_parallel_on_the_16bit_path_stays_in_lock_step():
+    """parallel.DataParallel + SyncBN with the video trunk on the bf16 kernels (fp32 weight gradients written straight
+    into the flat buckets by slv_cl16_wgrad, SyncBN sums from the bf16 statistics epilogue): after three steps every
+    parameter and BatchNorm buffer is bit-identical on both ranks, and the first loss is the fp32 run's to bf16 accuracy."""
+    import torch.multiprocessing as mp
+    ret, ret32 = mp.Manager().dict(), mp.Manager().dict()
+    mp.spawn(_ddp_worker, args=(2, 28600 + os.getpid() % 150, ret, "native", "bf16"), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, 28800 + os.getpid() % 150, ret32, "native"), nprocs=2, join=True)
+    diverged = [k for k in ret[0][2] if ret[0][2][k] != ret[1][2][k]]
+    assert not diverged, f"ranks diverged in {len(diverged)} tensors: {diverged[:6]}"
+    assert np.isfinite([ret[0][0], ret[0][1], ret[1][1]]).all()
+    for r in (0, 1):
+        assert abs(ret[r][0] - ret32[r][0]) <= 0.1 * abs(ret32[r][0]), (ret[r][0], ret32[r][0])
 
 
 def _nccl_worker(rank, port, ret):
