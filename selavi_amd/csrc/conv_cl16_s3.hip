@@ -134,28 +134,36 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
       }
     }
   };
+  // Weight pieces of this thread: fixed (K-chunk of the group, row, 16-byte slot) -> a per-thread byte offset inside a
+  // stage's weight block and a per-thread LDS offset, both computed ONCE; a stage adds one scalar (slab, group) offset
+  // in the buffer load's SGPR operand -- no per-stage vector address arithmetic, no table lookup (the timeline of the
+  // first version showed 1 150 of a stage's 3 800 cycles between "stage start" and "weight loads issued").
+  const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)wl, 0, (int)0x7FFFFFF0, 0x00020000);
+  unsigned awoff[AIT], asoff[AIT];
+  int akl[AIT];
+#pragma unroll
+  for (int i = 0; i < AIT; ++i) {
+    const int pc = tid + S3_THREADS * i;
+    const int kl = pc / (BM * 4), rem = pc - kl * (BM * 4), row = rem >> 2;
+    akl[i] = pc < APIECES ? kl : KCG;                                  // KCG: never live
+    awoff[i] = (unsigned)((kl * g.Mrows + m0) * 64 + rem * 16);       // bytes, inside [kc][Mrows][32] of one slab
+    asoff[i] = (unsigned)(kl * (BM * 64) + row * 64 + (((rem & 3) ^ cl_swz(row)) << 4));
+  }
+  const unsigned slab_bytes = (unsigned)(kcs * g.Mrows * 64), group_bytes = (unsigned)(KCG * g.Mrows * 64);
   auto load_a = [&](int cg, int t) __attribute__((always_inline)) {
-    const int slab = g.tap[t] >> 12;
+    const unsigned soff = (unsigned)t * slab_bytes + (unsigned)cg * group_bytes;      // taps are slabs 0..8 in order
+    const int live = min(KCG, kcs - cg * KCG);
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
-      const int pc = tid + S3_THREADS * i;
-      if (pc < APIECES) {
-        const int kl = pc / (BM * 4), rem = pc - kl * (BM * 4), kc = cg * KCG + kl;
-        ra[i] = (u32x4){0u, 0u, 0u, 0u};
-        if (kc < kcs && SLV_S3_ABL != 3) ra[i] = *(const u32x4*)(wl + ((size_t)(slab * kcs + kc) * g.Mrows + m0) * 32 + rem * 8);
-      }
+      const bool ok = akl[i] < live && SLV_S3_ABL != 3;
+      ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rwl, ok ? awoff[i] : 0xFFFFFFF0u, ok ? soff : 0u, 0));
     }
   };
   auto store_a = [&](int buf) __attribute__((always_inline)) {
     unsigned char* dst = ast0 + buf * AB;
 #pragma unroll
-    for (int i = 0; i < AIT; ++i) {
-      const int pc = tid + S3_THREADS * i;
-      if (pc < APIECES) {
-        const int kl = pc / (BM * 4), rem = pc - kl * (BM * 4), row = rem >> 2;
-        *(u32x4*)(dst + kl * (BM * 64) + row * 64 + (((rem & 3) ^ cl_swz(row)) << 4)) = ra[i];
-      }
-    }
+    for (int i = 0; i < AIT; ++i)
+      if (akl[i] < KCG) *(u32x4*)(dst + asoff[i]) = ra[i];
   };
   f32x4 acc[MT][2];
 #pragma unroll
@@ -172,21 +180,29 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
     store_a(0);
     __syncthreads();
   }
-  int cg = 0, t = 0;                                 // stage being COMPUTED
+#ifdef SLV_S3_TRACE      // per-stage timeline of wave 0 of the first 64 tiles: s_memtime at 5 points -> behind stat_sq's [Cout][tiles] floats (the caller allocates 32 KB more)
+#define S3_T(slot) if (trace) trace[(st * 5 + (slot))] = __builtin_amdgcn_s_memtime()
+  unsigned long long* trace = (EPI == 1 && tid == 0 && bx < 64) ? (unsigned long long*)(stat_sq + (size_t)g.Cout * gridDim.x) + (size_t)bx * 64 : nullptr;   // BEHIND the statistics
+#else
+#define S3_T(slot)
+#endif
+  int cg = 0, t = 0, th = 0, tw = 0;                 // stage being COMPUTED; (th, tw) = (t / 3, t % 3)
+  const int tsgn = ((((g.tap[0] >> 4) & 15) - 8 + g.boh) < 0) ? 1 : -1;      // forward: offsets -1..1 ascending; backward data: descending
   for (int rep = 0; rep < (SLV_S3_ABL == 8 ? 2 : 1); ++rep)      // ablation 8: the K loop twice
   for (int st = 0; st < nst; ++st) {
-    if (SLV_S3_ABL == 8 && st == 0) { cg = 0; t = 0; }
+    if (SLV_S3_ABL == 8 && st == 0) { cg = 0; t = 0; th = 0; tw = 0; }
     int ncg = cg, nt = t + 1;                        // the next stage
     if (nt == g.ntaps) {
       nt = 0;
       ++ncg;
     }
     const bool more = st + 1 < nst;
+    S3_T(0);
     if (more) load_a(ncg, nt);
     if (t == 0 && cg + 1 < groups) load_patch(cg + 1);
+    S3_T(1);
     {
-      const int tp = g.tap[t];
-      const int eh = ((tp >> 4) & 15) - 8 + g.boh, ew = ((tp >> 8) & 15) - 8 + g.bow;
+      const int eh = tsgn * (th - 1), ew = tsgn * (tw - 1);       // the 3 x 3 taps in slab order (s3_eligible checks it)
       const int roff = eh * W + ew;
       const unsigned bit = 1u << ((eh + 1) * 3 + ew + 1);
       const unsigned char* A = ast0 + (st & 1) * AB;
@@ -216,14 +232,21 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
         }
       }
     }
+    S3_T(2);
     if (more) store_a((st + 1) & 1);
+    S3_T(3);
     if (t == g.ntaps - 1 && cg + 1 < groups) {       // ONE patch buffer: every wave is done with this group's rows first
       __syncthreads();
       store_patch(cg + 1);
     }
     if (SLV_S3_ABL != 5) __syncthreads();
+    S3_T(4);
     cg = ncg;
     t = nt;
+    if (++tw == 3) {
+      tw = 0;
+      if (++th == 3) th = 0;
+    }
   }
   // ---- epilogue (cf. conv_cl16.hip): transposed tile [position][cout] through LDS, 16-byte stores along the channels
   __syncthreads();
@@ -340,12 +363,13 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
 // Does this launch fit the patch kernel?  Stride 1, lattice == input == output positions, every tap within one row /
 // column of the position, the patch (256 + 2W + 2 rows) within the loader's reach and the LDS.
 static bool s3_eligible(const ClConv& g) {
-  if (g.ntaps <= 0 || g.ntaps > 9) return false;
+  if (g.ntaps != 9) return false;
   if (g.Lt != g.Ti || g.Lh != g.Hi || g.Lw != g.Wi || g.To != g.Ti || g.Ho != g.Hi || g.Wo != g.Wi) return false;
   if (g.bmt != 1 || g.bmh != 1 || g.bmw != 1 || g.omt != 1 || g.omh != 1 || g.omw != 1 || g.oot || g.ooh || g.oow) return false;
-  for (int t = 0; t < g.ntaps; ++t) {
+  const int sgn = ((((g.tap[0] >> 4) & 15) - 8 + g.boh) < 0) ? 1 : -1;
+  for (int t = 0; t < 9; ++t) {        // tap t = weight slab t at offset sgn * (t / 3 - 1, t % 3 - 1): what the kernel computes
     const int dt = (g.tap[t] & 15) - 8 + g.bot, dh = ((g.tap[t] >> 4) & 15) - 8 + g.boh, dw = ((g.tap[t] >> 8) & 15) - 8 + g.bow;
-    if (dt != 0 || dh < -1 || dh > 1 || dw < -1 || dw > 1) return false;
+    if (dt != 0 || dh != sgn * (t / 3 - 1) || dw != sgn * (t % 3 - 1) || (g.tap[t] >> 12) != t) return false;
   }
   const int prow = S3_BN + 2 * g.Wi + 2;
   if (prow * 8 > S3_PIT * S3_THREADS) return false;

@@ -51,6 +51,8 @@ for name, Cin, T, H, W, Cout, k, st, pd in LAYERS:
     mi = torch.stack([torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)]).contiguous()
     flop = 2.0 * B * plan.out_dims[0] * plan.out_dims[1] * plan.out_dims[2] * Cout * Cin * k[0] * k[1] * k[2]
     tf = timeit(lambda: ops16.conv_fwd(plan, x, w, in_ss=ss, in_relu=ss is not None, wf=wf))
+    tf_plain = timeit(lambda: ops16.conv_fwd(plan, x, w, want_stats=False, wf=wf))          # no prologue, no statistics
+    tf_stats = timeit(lambda: ops16.conv_fwd(plan, x, w, want_stats=True, wf=wf))           # statistics only
     dxo = torch.empty_like(dy)
     ta = timeit(lambda: ops16.bn_bwd_apply(dy, y, b5, True, out=dxo))
     gam = torch.ones(Cout, device=dev)
@@ -61,6 +63,6 @@ for name, Cin, T, H, W, Cout, k, st, pd in LAYERS:
     nbytes = y.numel() * 2
     print(f"{name:14s} {flop/1e9:8.1f} | {tf:8.3f} {flop/tf/1e9:6.1f} | {td:8.3f} {flop/td/1e9:6.1f} | {tw:8.3f} {flop/tw/1e9:6.1f} | "
           f"{ta:6.3f} ({3*nbytes/ta/1e6:5.0f}) {tr:6.3f} ({2*nbytes/tr/1e6:5.0f}) {tact:6.3f} ({2*nbytes/tact/1e6:5.0f})"
-          f"  wgrad tile {plan.wm*32}x{plan.wn*32} slices {plan.g_wgrad[22]}")
+          f"  wgrad tile {plan.wm*32}x{plan.wn*32} slices {plan.g_wgrad[22]} | fwd plain {tf_plain:.3f} stats-only {tf_stats:.3f}")
     tot[0] += flop; tot[1] += tf; tot[2] += 0 if stem else td; tot[3] += tw
 print(f"sum over listed layers (each once): fwd {tot[1]:.3f} ms, dgrad {tot[2]:.3f} ms, wgrad {tot[3]:.3f} ms")

@@ -3,6 +3,12 @@
 # objects of the normal build with only that file recompiled; run on the GPU: tools/conv16_bench.py l1.spatial per variant.
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/abl
+if [ "$1" == "trace" ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -DSLV_S3_TRACE -c selavi_amd/csrc/conv_cl16_s3.hip -o /tmp/s3_trace.o
+  objs=$(ls selavi_amd/build/*.o | grep -v conv_cl16_s3)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/s3_trace.o -ldl -o tools/proto/libselavi_trace.so
+  exit 0
+fi
 if [ "$1" == "build" ]; then
   for v in 1 2 3 4 5 6 7 8; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -DSLV_S3_ABL=$v -c selavi_amd/csrc/conv_cl16_s3.hip -o /tmp/s3_abl$v.o &
