@@ -101,6 +101,36 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// BatchNorm statistics of a wave's OWN 32 rows of the transposed output tile in LDS ([position][cout] bf16 rows of
+// OROW bytes, written by this wave just before): per channel the sum and the sum of squares of the bf16-rounded outputs,
+// on the matrix cores instead of ~600 VALU instructions per wave.  ds_read_b64_tr_b16 delivers the tile as an MFMA
+// operand with K = the 32 positions (lane: channel = lane & 15, positions {4g..4g+3} and {16+4g..16+4g+3}, g = lane >> 4;
+// the K order is the same for both operands, which is all a sum over K needs):
+//   ones[16 x 32] * Y[32 x 16]   ->  every row = the column sums              (row 0: lanes 0..15, element 0)
+//   Y^T[16 x 32]  * Y[32 x 16]   ->  the Gram block, diagonal = sums of squares (lane n + 16 (n >> 2), element n & 3)
+// (products of two bf16 are exact in fp32: the sums differ from the VALU version only in the order of the additions).
+// sum / sq: this wave's [MT * 16] partials.
+template <int MT>
+__device__ __forceinline__ void wave_tile_stats(const unsigned char* rows, int orow, int lane, float* sum, float* sq) {
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const int fr = lane & 15, fk = lane >> 4;
+  const unsigned char* src = rows + (4 * fk + (fr >> 2)) * orow + 8 * (fr & 3);
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32 + 16 * orow));
+    const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const bf16x8 yv = __builtin_bit_cast(bf16x8, tmp);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yv, z, 0, 0, 0);
+    const f32x4 q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yv, yv, z, 0, 0, 0);
+    const int e = fr & 3;
+    const float qd = e == 0 ? q[0] : e == 1 ? q[1] : e == 2 ? q[2] : q[3];
+    if (fk == 0) sum[i * 16 + fr] = s[0];
+    if (fk == (fr >> 2)) sq[i * 16 + fr] = qd;
+  }
+}
 
 // csrc/conv_cl16_s3.hip: the LDS-resident-patch kernel for stride-1 (1,3,3) convs (forward and backward data)
 bool cl16_s3_applies(const ClConv& g);

@@ -155,12 +155,17 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
     bf16x8 b[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8*)(B + (wave * 32 + j * 16 + fr) * CL_ROWB + fsw);
+    // every fragment read of the K-step is issued before the first MFMA (left alone, the scheduler re-uses one fragment
+    // register and puts a full LDS round trip in front of every MFMA pair)
+    bf16x8 a[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const bf16x8 a = *(const bf16x8*)(A + (i * 16 + fr) * CL_ROWB + fsw);
+    for (int i = 0; i < MT; ++i) a[i] = *(const bf16x8*)(A + (i * 16 + fr) * CL_ROWB + fsw);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
-    }
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     if (s + 1 < ksteps) lstore((s + 1) & 1);
     __syncthreads();
   }
@@ -235,11 +240,6 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
       }
       const unsigned lo = pack_bf2(v[0], v[1]), hi = pack_bf2(v[2], v[3]);
       *(uint2*)(ot + pl * OROW + (i * 16 + fk * 4) * 2) = make_uint2(lo, hi);
-      if constexpr (EPI == 1) {
-        const float r0 = bf_lo(lo), r1 = bf_hi(lo), r2 = bf_lo(hi), r3 = bf_hi(hi);
-        ps[0] += r0; ps[1] += r1; ps[2] += r2; ps[3] += r3;
-        pq[0] += r0 * r0; pq[1] += r1 * r1; pq[2] += r2 * r2; pq[3] += r3 * r3;
-      }
       if constexpr (EPI == 2) {                          // BatchNorm-backward sums of the source layer (ClBnr)
         uint2 xr = make_uint2(0u, 0u);
         if ((op2 != 0xFFFFFFFFu) && co < g.Cout_p) xr = *(const uint2*)(bn.x + (size_t)op2 * g.Cout_p + co);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
         }
       }
     }
-    if constexpr (EPI >= 1) {                            // 16 positions per lane group -> lane fr == 0 of each group
+    if constexpr (EPI == 2) {                            // 16 positions per lane group -> lane fr == 0 of each group
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a = row16_sum(ps[r]), b = row16_sum(pq[r]);
@@ -264,6 +264,8 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
       }
     }
   }
+  if constexpr (EPI == 1)                                // statistics of this wave's 32 rows, on the matrix cores
+    wave_tile_stats<MT>(ot + wave * 32 * OROW, OROW, lane, red + (wave * 2 + 0) * BM, red + (wave * 2 + 1) * BM);
   __syncthreads();
   if constexpr (EPI >= 1) {                              // the 4 waves' partials in fixed order
     for (int i = tid; i < 2 * BM; i += 256) {

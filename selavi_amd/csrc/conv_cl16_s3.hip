@@ -70,6 +70,101 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
   const unsigned p0 = bx * S3_BN;
   const int kcs = g.Cin_p >> 5, groups = (kcs + KCG - 1) / KCG;
   const int nst = SLV_S3_ABL == 7 ? 0 : groups * g.ntaps;      // ablation 7: prologue + epilogue only
+  // ---- loaders
+  u32x4 rp[S3_PIT];
+  unsigned pvalid = 0;                               // bit i: patch piece i of this thread lies inside the tensor
+  // (the thread index goes through an empty asm in both patch functions: their per-piece offsets, row / slot numbers and
+  //  predicates are loop invariants that the compiler would otherwise keep in ~40 registers across the K loop)
+  auto load_patch = [&](int cg) __attribute__((always_inline)) {
+    pvalid = 0;
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int i = 0; i < S3_PIT; ++i) {
+      const int idx = tl + S3_THREADS * i, r = idx / SLOTS, s = idx - r * SLOTS;
+      const long long q = (long long)p0 - W - 1 + r;
+      const int c = cg * (KCG * 32) + s * 8;
+      const bool ok = r < prow && q >= 0 && q < (long long)P && c < g.Cin_p;
+      pvalid |= (unsigned)ok << i;
+      const unsigned off = (unsigned)q * (unsigned)(g.Cin_p * 2) + (unsigned)c * 2u;
+      rp[i] = SLV_S3_ABL == 6 ? (u32x4){off, 0u, 0u, 0u}
+                              : __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : 0xFFFFFFF0u, 0, 0));
+    }
+  };
+  auto store_patch = [&](int cg) __attribute__((always_inline)) {
+    unsigned char* dst = patch0;
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int i = 0; i < S3_PIT; ++i) {
+      const int idx = tl + S3_THREADS * i, r = idx / SLOTS, s = idx - r * SLOTS;
+      if (r < prow) {
+        u32x4 v = rp[i];
+        if constexpr (PRO == 1) {
+          float sc[8], sh[8];
+          const float* sp = pro + cg * (KCG * 32) + s * 8;
+          *(f32x4*)sc = *(const f32x4*)sp;
+          *(f32x4*)(sc + 4) = *(const f32x4*)(sp + 4);
+          *(f32x4*)sh = *(const f32x4*)(sp + g.Cin_p);
+          *(f32x4*)(sh + 4) = *(const f32x4*)(sp + g.Cin_p + 4);
+          const u32x4 t = affine_relu8(v, sc, sh);
+          v = ((pvalid >> i) & 1) ? t : (u32x4){0u, 0u, 0u, 0u};
+        }
+        *(u32x4*)(dst + r * ROWB + ((s ^ (r & (SLOTS - 1))) << 4)) = v;
+      }
+    }
+  };
+  // Weights go memory -> LDS directly (buffer_load_dwordx4 ... lds: no staging registers, no ds_write).  A stage's weight
+  // block is [K-chunk of the group][BM rows][64 bytes] in LDS: linear in the piece index pc = tid + 256 i, and a wave's
+  // 64 lanes of one instruction land in 1 KiB at M0 = block + i * 4096 + wave * 1024.  The swizzle moves to the source
+  // side: LDS position (row, slot s') receives the memory piece (row, s' ^ swz(row)), and swz(row) is the same for every
+  // i (BM % 16 == 0, 256 / 4 % 16 == 0).  Memory is [K-chunk][Mrows][64] (rows m0..m0+BM): ONE per-thread byte offset
+  // plus, in the SGPR operand, what the stage adds (slab, group, i * 4096, the chunk's row gap).
+  const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)wl, 0, (int)0x7FFFFFF0, 0x00020000);
+  constexpr int KPC = BM * 4;                                           // pieces per K-chunk
+  const unsigned kgap = (unsigned)((g.Mrows - BM) * 64);                // memory bytes between the chunks' row blocks
+  const unsigned vo0 = (unsigned)((tid >> 2) * 64 + (((tid & 3) ^ cl_swz(tid >> 2)) << 4) + m0 * 64);
+  constexpr int ISTR = (KPC % S3_THREADS) ? KPC / S3_THREADS : -1;      // the i whose pieces straddle the chunks
+  const unsigned vos = vo0 + ((ISTR >= 0 && tid + S3_THREADS * ISTR >= KPC) ? kgap : 0u);
+  const unsigned slab_bytes = (unsigned)(kcs * g.Mrows * 64), group_bytes = (unsigned)(KCG * g.Mrows * 64);
+  typedef __attribute__((address_space(3))) void* lds_void;
+  auto load_a = [&](int cg, int t, int buf) __attribute__((always_inline)) {
+    const unsigned soff = (unsigned)t * slab_bytes + (unsigned)cg * group_bytes;      // taps are slabs 0..8 in order
+    const int live = min(KCG, kcs - cg * KCG);
+    unsigned char* dst = ast0 + buf * AB + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const int lo = S3_THREADS * i, hi = lo + S3_THREADS - 1;
+      const bool strad = i == ISTR;
+      const int kl = strad ? (tid + lo >= KPC) : lo / KPC;              // K-chunk of the piece
+      const bool ok = kl < live && SLV_S3_ABL != 3;                     // a chunk past the tensor's channels: zeros
+      const unsigned so = soff + (unsigned)(i * (S3_THREADS * 16)) + ((!strad && lo >= KPC) ? kgap : 0u);
+      if (hi < APIECES || tid + lo < APIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_void)(dst + i * (S3_THREADS * 16)), 16, ok ? (strad ? vos : vo0) : 0xFFFFFFF0u, so, 0, 0);
+    }
+  };
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef SLV_S3_TRACE      // timeline of wave 0 of 64 tiles (SLV_S3_TRACE_T0 ..): s_memtime at 5 points per stage + 4 per tile -> behind stat_sq's [Cout][tiles] floats (the caller allocates 32 KB more)
+#ifndef SLV_S3_TRACE_T0
+#define SLV_S3_TRACE_T0 0
+#endif
+#define S3_T(slot) if (trace) trace[(st * 5 + (slot))] = __builtin_amdgcn_s_memtime()
+#define S3_TK(slot) if (trace) trace[(slot)] = __builtin_amdgcn_s_memtime()
+  unsigned long long* trace = (EPI == 1 && tid == 0 && bx >= SLV_S3_TRACE_T0 && bx < SLV_S3_TRACE_T0 + 64) ? (unsigned long long*)(stat_sq + (size_t)g.Cout * gridDim.x) + (size_t)(bx - SLV_S3_TRACE_T0) * 64 : nullptr;   // BEHIND the statistics
+#else
+#define S3_T(slot)
+#define S3_TK(slot)
+#endif
+  S3_TK(60);
+  // ---- prologue of the pipeline
+  if (nst > 0) {                                      // first patch and weight stage: in flight during the setup below
+    load_patch(0);
+    load_a(0, 0, 0);
+  }
   if constexpr (PRO == 1) {
     for (int i = tid; i < 2 * g.Cin_p; i += S3_THREADS) {
       const int c = i % g.Cin_p, which = i / g.Cin_p;
@@ -78,6 +173,7 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
   }
   // ---- fragment lanes: positions of this lane's two 16-position tiles, their tap-validity masks
   const int fr = lane & 15, fk = lane >> 4;
+  const int fsw = (fk ^ cl_swz(fr)) << 4;
   int prow_l[2];                                     // patch row of the position itself (tap offset 0)
   unsigned okm[2];                                   // bit (eh+1)*3 + (ew+1): the tap at offset (eh, ew) is inside the image
 #pragma unroll
@@ -96,96 +192,13 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
           if ((unsigned)(h + eh) < (unsigned)H && (unsigned)(w + ew) < (unsigned)W) m |= 1u << ((eh + 1) * 3 + ew + 1);
     okm[j] = m;
   }
-  // ---- loaders
-  u32x4 rp[S3_PIT], ra[AIT];
-  unsigned pvalid = 0;                               // bit i: patch piece i of this thread lies inside the tensor
-  auto load_patch = [&](int cg) __attribute__((always_inline)) {
-    pvalid = 0;
-#pragma unroll
-    for (int i = 0; i < S3_PIT; ++i) {
-      const int idx = tid + S3_THREADS * i, r = idx / SLOTS, s = idx - r * SLOTS;
-      const long long q = (long long)p0 - W - 1 + r;
-      const int c = cg * (KCG * 32) + s * 8;
-      const bool ok = r < prow && q >= 0 && q < (long long)P && c < g.Cin_p;
-      pvalid |= (unsigned)ok << i;
-      const unsigned off = (unsigned)q * (unsigned)(g.Cin_p * 2) + (unsigned)c * 2u;
-      rp[i] = SLV_S3_ABL == 6 ? (u32x4){off, 0u, 0u, 0u}
-                              : __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : 0xFFFFFFF0u, 0, 0));
-    }
-  };
-  auto store_patch = [&](int cg) __attribute__((always_inline)) {
-    unsigned char* dst = patch0;
-#pragma unroll
-    for (int i = 0; i < S3_PIT; ++i) {
-      const int idx = tid + S3_THREADS * i, r = idx / SLOTS, s = idx - r * SLOTS;
-      if (r < prow) {
-        u32x4 v = rp[i];
-        if constexpr (PRO == 1) {
-          float sc[8], sh[8];
-          const float* sp = pro + cg * (KCG * 32) + s * 8;
-          *(f32x4*)sc = *(const f32x4*)sp;
-          *(f32x4*)(sc + 4) = *(const f32x4*)(sp + 4);
-          *(f32x4*)sh = *(const f32x4*)(sp + g.Cin_p);
-          *(f32x4*)(sh + 4) = *(const f32x4*)(sp + g.Cin_p + 4);
-          const u32x4 t = affine_relu8(v, sc, sh);
-          v = ((pvalid >> i) & 1) ? t : (u32x4){0u, 0u, 0u, 0u};
-        }
-        *(u32x4*)(dst + r * ROWB + ((s ^ (r & (SLOTS - 1))) << 4)) = v;
-      }
-    }
-  };
-  // Weight pieces of this thread: fixed (K-chunk of the group, row, 16-byte slot) -> a per-thread byte offset inside a
-  // stage's weight block and a per-thread LDS offset, both computed ONCE; a stage adds one scalar (slab, group) offset
-  // in the buffer load's SGPR operand -- no per-stage vector address arithmetic, no table lookup (the timeline of the
-  // first version showed 1 150 of a stage's 3 800 cycles between "stage start" and "weight loads issued").
-  const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)wl, 0, (int)0x7FFFFFF0, 0x00020000);
-  unsigned awoff[AIT], asoff[AIT];
-  int akl[AIT];
-#pragma unroll
-  for (int i = 0; i < AIT; ++i) {
-    const int pc = tid + S3_THREADS * i;
-    const int kl = pc / (BM * 4), rem = pc - kl * (BM * 4), row = rem >> 2;
-    akl[i] = pc < APIECES ? kl : KCG;                                  // KCG: never live
-    awoff[i] = (unsigned)((kl * g.Mrows + m0) * 64 + rem * 16);       // bytes, inside [kc][Mrows][32] of one slab
-    asoff[i] = (unsigned)(kl * (BM * 64) + row * 64 + (((rem & 3) ^ cl_swz(row)) << 4));
-  }
-  const unsigned slab_bytes = (unsigned)(kcs * g.Mrows * 64), group_bytes = (unsigned)(KCG * g.Mrows * 64);
-  auto load_a = [&](int cg, int t) __attribute__((always_inline)) {
-    const unsigned soff = (unsigned)t * slab_bytes + (unsigned)cg * group_bytes;      // taps are slabs 0..8 in order
-    const int live = min(KCG, kcs - cg * KCG);
-#pragma unroll
-    for (int i = 0; i < AIT; ++i) {
-      const bool ok = akl[i] < live && SLV_S3_ABL != 3;
-      ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rwl, ok ? awoff[i] : 0xFFFFFFF0u, ok ? soff : 0u, 0));
-    }
-  };
-  auto store_a = [&](int buf) __attribute__((always_inline)) {
-    unsigned char* dst = ast0 + buf * AB;
-#pragma unroll
-    for (int i = 0; i < AIT; ++i)
-      if (akl[i] < KCG) *(u32x4*)(dst + asoff[i]) = ra[i];
-  };
-  f32x4 acc[MT][2];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int fsw = (fk ^ cl_swz(fr)) << 4;
-  // ---- prologue of the pipeline
   if (nst > 0) {
-    load_patch(0);
-    load_a(0, 0);
     if constexpr (PRO == 1) __syncthreads();
     store_patch(0);
-    store_a(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-#ifdef SLV_S3_TRACE      // per-stage timeline of wave 0 of the first 64 tiles: s_memtime at 5 points -> behind stat_sq's [Cout][tiles] floats (the caller allocates 32 KB more)
-#define S3_T(slot) if (trace) trace[(st * 5 + (slot))] = __builtin_amdgcn_s_memtime()
-  unsigned long long* trace = (EPI == 1 && tid == 0 && bx < 64) ? (unsigned long long*)(stat_sq + (size_t)g.Cout * gridDim.x) + (size_t)bx * 64 : nullptr;   // BEHIND the statistics
-#else
-#define S3_T(slot)
-#endif
+  S3_TK(61);
   int cg = 0, t = 0, th = 0, tw = 0;                 // stage being COMPUTED; (th, tw) = (t / 3, t % 3)
   const int tsgn = ((((g.tap[0] >> 4) & 15) - 8 + g.boh) < 0) ? 1 : -1;      // forward: offsets -1..1 ascending; backward data: descending
   for (int rep = 0; rep < (SLV_S3_ABL == 8 ? 2 : 1); ++rep)      // ablation 8: the K loop twice
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
     }
     const bool more = st + 1 < nst;
     S3_T(0);
-    if (more) load_a(ncg, nt);
+    if (more) load_a(ncg, nt, (st + 1) & 1);
     if (t == 0 && cg + 1 < groups) load_patch(cg + 1);
     S3_T(1);
     {
@@ -208,37 +221,66 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
       const unsigned char* A = ast0 + (st & 1) * AB;
       const unsigned char* Bp = patch0;
       const int live = min(KCG, kcs - cg * KCG);        // K-chunks of this group that exist
-#pragma unroll
-      for (int kl = 0; kl < KCG; ++kl) {
-        if (kl >= live) break;
-        bf16x8 b[2];
+      static_assert(KCG == 2, "the stage body below is written for two K-chunks per stage");
+      // Order inside a stage (fixed with sched_barrier: left alone, the scheduler re-uses ONE weight-fragment register
+      // and waits a full LDS round trip before every MFMA pair): all fragment reads of chunk 0 and the position
+      // fragments of chunk 1, then chunk 0's MFMA pairs, each followed by the read that refills its weight register
+      // with chunk 1's fragment, then the next stage's weights go to LDS (their global loads were issued at the top
+      // of the stage), then chunk 1's MFMAs with nothing left to wait for.
+      auto rdb = [&](int kl, int j) __attribute__((always_inline)) {
+        const int r = prow_l[j] + roff;
+        return SLV_S3_ABL == 2 ? (u32x4){(unsigned)r, 1u, 2u, 3u}
+                               : *(const u32x4*)(Bp + r * ROWB + (((kl * 4 + fk) ^ (r & (SLOTS - 1))) << 4));
+      };
+      auto rda = [&](int kl, int i) __attribute__((always_inline)) {
+        return SLV_S3_ABL == 2 ? __builtin_bit_cast(bf16x8, (u32x4){(unsigned)(i + roff), 5u, 6u, 7u})
+                               : *(const bf16x8*)(A + kl * (BM * 64) + (i * 16 + fr) * 64 + fsw);
+      };
+      auto mma = [&](int i, const bf16x8& av, const bf16x8* bv) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int r = prow_l[j] + roff;
-          u32x4 v = SLV_S3_ABL == 2 ? (u32x4){(unsigned)r, 1u, 2u, 3u}
-                                    : *(const u32x4*)(Bp + r * ROWB + (((kl * 4 + fk) ^ (r & (SLOTS - 1))) << 4));
-          if (!(okm[j] & bit)) v = (u32x4){0u, 0u, 0u, 0u};
-          b[j] = __builtin_bit_cast(bf16x8, v);
+          if (SLV_S3_ABL == 1) acc[i][j][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, av)[0] ^ __builtin_bit_cast(u32x4, bv[j])[0]);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[j], acc[i][j], 0, 0, 0);
         }
+      };
+      u32x4 bv0[2], bv1[2];
+      bf16x8 a[MT], b[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv0[j] = rdb(0, j);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = rda(0, i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(bf16x8, (okm[j] & bit) ? bv0[j] : (u32x4){0u, 0u, 0u, 0u});
+      if (live > 1) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const bf16x8 a = SLV_S3_ABL == 2 ? __builtin_bit_cast(bf16x8, (u32x4){(unsigned)(i + roff), 5u, 6u, 7u})
-                                           : *(const bf16x8*)(A + kl * (BM * 64) + (i * 16 + fr) * 64 + fsw);
+          mma(i, a[i], b);
+          if (i == MT - 1) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (SLV_S3_ABL == 1) acc[i][j][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, a)[0] ^ __builtin_bit_cast(u32x4, b[j])[0]);
-            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) bv1[j] = rdb(1, j);
           }
+          a[i] = rda(1, i);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        S3_T(2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(bf16x8, (okm[j] & bit) ? bv1[j] : (u32x4){0u, 0u, 0u, 0u});
+#pragma unroll
+        for (int i = 0; i < MT; ++i) mma(i, a[i], b);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) mma(i, a[i], b);
+        S3_T(2);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    S3_T(2);
-    if (more) store_a((st + 1) & 1);
     S3_T(3);
     if (t == g.ntaps - 1 && cg + 1 < groups) {       // ONE patch buffer: every wave is done with this group's rows first
       __syncthreads();
       store_patch(cg + 1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next stage's weights have landed in LDS
     if (SLV_S3_ABL != 5) __syncthreads();
     S3_T(4);
     cg = ncg;
@@ -248,6 +290,7 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
       if (++th == 3) th = 0;
     }
   }
+  S3_TK(62);
   // ---- epilogue (cf. conv_cl16.hip): transposed tile [position][cout] through LDS, 16-byte stores along the channels
   __syncthreads();
   unsigned char* ot = lds_raw;                          // [S3_BN][OROW]
@@ -304,11 +347,6 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
       }
       const unsigned lo = pack_bf2(v[0], v[1]), hi = pack_bf2(v[2], v[3]);
       *(uint2*)(ot + pl * OROW + (i * 16 + fk * 4) * 2) = make_uint2(lo, hi);
-      if constexpr (EPI == 1) {
-        const float r0 = bf_lo(lo), r1 = bf_hi(lo), r2 = bf_lo(hi), r3 = bf_hi(hi);
-        ps[0] += r0; ps[1] += r1; ps[2] += r2; ps[3] += r3;
-        pq[0] += r0 * r0; pq[1] += r1 * r1; pq[2] += r2 * r2; pq[3] += r3 * r3;
-      }
       if constexpr (EPI == 2) {                          // BatchNorm-backward sums of the source layer (ClBnr)
         uint2 xr = make_uint2(0u, 0u);
         if ((p < P) && co < g.Cout_p) xr = *(const uint2*)(bn.x + (size_t)p * g.Cout_p + co);
@@ -322,7 +360,7 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
         }
       }
     }
-    if constexpr (EPI >= 1) {
+    if constexpr (EPI == 2) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a = row16_sum(ps[r]), b = row16_sum(pq[r]);
@@ -333,6 +371,8 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
       }
     }
   }
+  if constexpr (EPI == 1)                                // statistics of this wave's 32 rows, on the matrix cores
+    wave_tile_stats<MT>(ot + wave * 32 * OROW, OROW, lane, red + (wave * 2 + 0) * BM, red + (wave * 2 + 1) * BM);
   __syncthreads();
   if constexpr (EPI >= 1) {                              // the waves' partials in fixed order
     for (int i = tid; i < 2 * BM; i += S3_THREADS) {
@@ -358,6 +398,10 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
     if (c_lo + pc * 8 < c_hi) val = *(const u32x4*)(ot + pl * OROW + pc * 16);
     if (SLV_S3_ABL != 4 || val[0] == 0x12345678u) *(u32x4*)(y + (size_t)p * g.Cout_p + c_lo + pc * 8) = val;
   }
+#ifdef SLV_S3_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  S3_TK(63);
+#endif
 }
 
 // Does this launch fit the patch kernel?  Stride 1, lattice == input == output positions, every tap within one row /

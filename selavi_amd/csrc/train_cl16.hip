@@ -202,15 +202,20 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad_kernel(const unsigned short
       const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       bfr[j] = __builtin_bit_cast(bf16x8, tmp);
     }
+    bf16x8 afr[WM];                                    // all fragment reads of the K-step before its first MFMA
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(A + fa + i * 32));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(A + fa + i * 32 + 16 * SA));
       const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      const bf16x8 afr = __builtin_bit_cast(bf16x8, tmp);
-#pragma unroll
-      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], acc[i][j], 0, 0, 0);
+      afr[i] = __builtin_bit_cast(bf16x8, tmp);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     if (more) lstore(buf ^ 1);
     __syncthreads();
     buf ^= 1;

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/abl
 if [ "$1" == "trace" ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -DSLV_S3_TRACE -c selavi_amd/csrc/conv_cl16_s3.hip -o /tmp/s3_trace.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -DSLV_S3_TRACE -DSLV_S3_TRACE_T0=${2:-0} -c selavi_amd/csrc/conv_cl16_s3.hip -o /tmp/s3_trace.o
   objs=$(ls selavi_amd/build/*.o | grep -v conv_cl16_s3)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/s3_trace.o -ldl -o tools/proto/libselavi_trace.so
   exit 0

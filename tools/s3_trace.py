@@ -27,10 +27,13 @@ raw = ssq[plan.Cout * plan.nblk:].view(torch.int64).cpu().numpy().reshape(64, 64
 tr = raw[:, :45].reshape(64, 9, 5).astype(np.float64)
 d = np.diff(tr, axis=2)                                 # issue loads | compute | store_a | barrier
 nxt = tr[:, 1:, 0] - tr[:, :-1, 4]
-names = ["issue weight loads", "fragment reads + 36 MFMA", "wait loads + LDS write", "barrier"]
+names = ["issue weight loads (LDS-DMA)", "chunk 0: reads + 18 MFMA + refills", "chunk 1: 18 MFMA", "wait loads + barrier"]
 print("cycles per stage (mean over stages 1..7 and 64 tiles; s_memtime ticks = shader cycles):")
 for i, n in enumerate(names):
-    print(f"  {n:28s} {d[:, 1:8, i].mean():8.0f}  (min {d[:, 1:8, i].min():.0f}, max {d[:, 1:8, i].max():.0f})")
-print(f"  {'loop back':28s} {nxt[:, 1:7].mean():8.0f}")
-print(f"  whole stage                  {(tr[:, 8, 4] - tr[:, 0, 0]).mean() / 9:8.0f}")
-print("  first tile, stage 0..8 totals:", (tr[0, :, 4] - tr[0, :, 0]).astype(int).tolist())
+    print(f"  {n:36s} {d[:, 1:8, i].mean():8.0f}  (min {d[:, 1:8, i].min():.0f}, max {d[:, 1:8, i].max():.0f})")
+print(f"  {'loop back':36s} {nxt[:, 1:7].mean():8.0f}")
+print(f"  whole stage                          {(tr[:, 8, 4] - tr[:, 0, 0]).mean() / 9:8.0f}")
+k = raw[:, 60:64].astype(np.float64)
+print(f"per tile: pipeline prologue (patch + first weights) {(k[:, 1] - k[:, 0]).mean():.0f}, K loop {(k[:, 2] - k[:, 1]).mean():.0f}, "
+      f"epilogue (transpose, statistics, stores landed) {(k[:, 3] - k[:, 2]).mean():.0f}")
+print("  tile 0, stage 0..8 totals:", (tr[0, :, 4] - tr[0, :, 0]).astype(int).tolist())
