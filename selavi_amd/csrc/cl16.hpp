@@ -139,4 +139,14 @@ int cl16_s3_try(const ClConv& g, int mt, const void* x, const void* wl, void* y,
                 const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr,
                 hipStream_t st);
 
+// csrc/wgrad_cl16_s3.hip: weight gradient of the stride-1 (1,3,3) convs with a rolling activation patch
+struct ClWgrad3 {
+  int N, T, H, W, Cin_p, Cin, Cout_p;
+  int mtiles, groups, kslices, kper;
+};
+bool wgrad3_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, int kt, int kh, int kw, int st, int sh, int sw,
+                 int pt, int ph, int pw, int To, int Ho, int Wo, int* wm, ClWgrad3* out);
+size_t wgrad3_ws_bytes(const ClWgrad3& g, int wm);
+void wgrad3_launch(const ClWgrad3& g, int wm, const void* dy, const void* x, const float* in_ss, float* part, hipStream_t st);
+
 }  // namespace slv

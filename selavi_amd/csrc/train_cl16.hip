@@ -511,7 +511,15 @@ int32_t slv_cl16_wgrad_words(void) { return slv::CLW_WORDS; }
 size_t slv_cl16_wgrad_ws_bytes(const int32_t* clw, int wm, int wn) {
   slv::ClWgrad g;
   memcpy(&g, clw, sizeof(g));
-  return (size_t)g.kslices * g.mtiles * wm * 32 * g.ntiles * wn * 32 * sizeof(float);
+  const size_t general = (size_t)g.kslices * g.mtiles * wm * 32 * g.ntiles * wn * 32 * sizeof(float);
+  slv::ClWgrad3 g3;
+  int wm3;
+  if (slv::wgrad3_plan(g.N, g.Ti, g.Hi, g.Wi, g.Cin_p, g.Cin, g.Cout_p, g.kt, g.kh, g.kw, g.st, g.sh, g.sw, g.pt, g.ph, g.pw,
+                       g.To, g.Ho, g.Wo, &wm3, &g3)) {
+    const size_t patch = slv::wgrad3_ws_bytes(g3, wm3);
+    return patch > general ? patch : general;
+  }
+  return general;
 }
 
 int slv_cl16_wgrad(const int32_t* clw, int wm, int wn, const void* dy_bf16, const void* x_bf16,
@@ -535,6 +543,21 @@ int slv_cl16_wgrad(const int32_t* clw, int wm, int wn, const void* dy_bf16, cons
   SLV_CHECK_ARG(ws_bytes >= slv_cl16_wgrad_ws_bytes(clw, wm, wn), "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
+  const int taps = g.kt * g.kh * g.kw;
+  {                                                                // stride-1 (1,3,3): the rolling-patch kernel
+    ClWgrad3 g3;
+    int wm3;
+    if (!patch_kw && wgrad3_plan(g.N, g.Ti, g.Hi, g.Wi, g.Cin_p, g.Cin, g.Cout_p, g.kt, g.kh, g.kw, g.st, g.sh, g.sw, g.pt,
+                                 g.ph, g.pw, g.To, g.Ho, g.Wo, &wm3, &g3)) {
+      wgrad3_launch(g3, wm3, dy_bf16, x_bf16, in_scale_shift, part, st);
+      SLV_LAUNCH_CHECK();
+      const size_t ldp3 = (size_t)g.Ncols;
+      hipLaunchKernelGGL(cl16_wgrad_reduce_kernel, dim3((g.Ncols + 255) / 256, Cout), dim3(256), 0, st, part, dw, Cout, g.Cin,
+                         taps, g.Cin_p, g3.kslices, (size_t)g3.mtiles * wm3 * 32 * ldp3, ldp3, 0, (unsigned)g.Ncols);
+      SLV_LAUNCH_CHECK();
+      return 0;
+    }
+  }
 #define SLV_WG(A_, B_) \
   if (wm == A_ && wn == B_) wgrad_launch<A_, B_>(g, dy_bf16, x_bf16, in_scale_shift, part, st)
   SLV_WG(2, 2); SLV_WG(2, 3); SLV_WG(2, 4); SLV_WG(2, 5);
@@ -543,7 +566,6 @@ int slv_cl16_wgrad(const int32_t* clw, int wm, int wn, const void* dy_bf16, cons
   SLV_WG(5, 2); SLV_WG(5, 3); SLV_WG(5, 4); SLV_WG(5, 5);
 #undef SLV_WG
   SLV_LAUNCH_CHECK();
-  const int taps = g.kt * g.kh * g.kw;
   const int Cin_w = patch_kw ? g.Cin / patch_kw : g.Cin;        // patch mode: g.Cin = kw * C patch channels in use
   const size_t ldp = (size_t)g.ntiles * wn * 32;
   hipLaunchKernelGGL(cl16_wgrad_reduce_kernel, dim3((g.Ncols + 255) / 256, Cout), dim3(256), 0, st, part, dw, Cout, Cin_w,

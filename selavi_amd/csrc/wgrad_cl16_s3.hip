@@ -1,0 +1,261 @@
+// Weight gradient of the stride-1 (1,3,3) convs of the 16-bit path (BASELINE configs[4]; the spatial convs of R(2+1)D:
+// /root/reference/model.py:147-176 builds torchvision's r2plus1d_18, main.py:296-299 runs its backward) with the
+// activation rows staged ONCE for the three taps of a kernel row.
+//
+// The general kernel (train_cl16.hip: cl16_wgrad_kernel) treats every (tap, channel chunk) column block on its own: the
+// position decode, the bounds checks and the BatchNorm + ReLU prologue of an activation piece are repeated for each of
+// the 9 taps -- 116 VALU instructions per 15 MFMAs in its K loop (7.7 : 1; the loop is VALU-bound).  Here a block owns
+//   (Cout tile of 32*WM rows) x (ONE kernel row eh, its 3 taps ew = -1, 0, 1) x (one 64-channel group) x (a K slice)
+// and keeps a rolling PATCH of activation rows in LDS: a K step of 32 positions adds 32 new rows (one 16-byte piece per
+// thread: decoded, checked and activated once) and the three taps read them at row offsets -1, 0, +1.
+//   * Padded row index: position q sits at patch row q + q / W, i.e. after every image row comes one ZERO row, so a tap
+//     that leaves the image to the left or right lands on zeros and a tap offset is a constant row offset
+//     eh * (W + 1) + ew: no per-tap masks.  (The index is taken relative to an origin some rows before the slice.)
+//   * Leaving the image at the top / bottom means reading the neighbouring frame's last / first row: with eh fixed per
+//     block those rows (h == H-1 for eh = -1, h == 0 for eh = +1) are zeroed when they are staged.
+//   * The patch is circular (128 rows of 160 bytes: three staging units of <= 40 rows are live), dY tiles are double
+//     buffered and arrive by LDS-DMA (buffer_load ... lds; two padding pieces per row keep the rows 32 bytes (mod 64)
+//     apart for the transpose reads), fragments come from ds_read_b64_tr_b16 exactly as in the general kernel.
+// Output: the same deterministic split-K partials [slice][rows][9 * Cin_p] that cl16_wgrad_reduce_kernel sums.
+#include "cl16.hpp"
+
+namespace slv {
+
+constexpr int W3_SP = 160, W3_PR = 128;          // patch row bytes (128 + 32), circular patch rows
+
+template <int WM, int PRO>
+__global__ __launch_bounds__(256, 2) void cl16_wgrad3_kernel(const unsigned short* __restrict__ dy,
+                                                             const unsigned short* __restrict__ x,
+                                                             const float* __restrict__ in_ss, float* __restrict__ part,
+                                                             ClWgrad3 g, FastDiv dW, FastDiv dH) {
+  constexpr int BM = 32 * WM, APC = BM / 8 + 2, SA = APC * 16, AIT = (32 * APC + 255) / 256;
+  constexpr int ABYTES = AIT * 4096;                              // one dY buffer (the DMA writes whole 1 KiB wave pieces)
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * ABYTES + W3_PR * W3_SP];
+  unsigned char* const patch = lds_raw + 2 * ABYTES;
+  typedef __attribute__((address_space(3))) void* lds_void;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  // XCD-aware bijective remap: consecutive units (same K slice: same dY and activation rows) share an XCD's L2
+  const unsigned total = gridDim.x, q8 = total >> 3, r8 = total & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  unsigned unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  const int ehi = unit % 3; unit /= 3;
+  const int grp = unit % g.groups; unit /= g.groups;
+  const int mt = unit % g.mtiles;
+  const unsigned slice = unit / g.mtiles;
+  const int eh = ehi - 1, m0 = mt * BM, c0 = grp * 64;
+  const int W = g.W, H = g.H;
+  const unsigned P = (unsigned)g.N * g.T * g.H * g.W;
+  const unsigned k_lo = slice * (unsigned)g.kper, k_hi = min(k_lo + (unsigned)g.kper, P);
+  const int nsteps = k_lo < k_hi ? (int)((k_hi - k_lo + 31) >> 5) : 0;
+  // origin of the relative row numbering: a whole number of image rows, far enough before the slice's first staged row
+  const int base_row = (int)fdiv(k_lo, dW) - (3 + 32 / W);
+  const int org = base_row * W;                                      // may be negative
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)(P * (unsigned)g.Cout_p * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(P * (unsigned)g.Cin_p * 2u), 0x00020000);
+
+  // ---- dY tile by LDS-DMA: piece pc = tid + 256 i -> LDS byte pc * 16 = row (pc / APC) * SA + column piece * 16
+  unsigned avo[AIT];
+#pragma unroll
+  for (int i = 0; i < AIT; ++i) {
+    const int pc = tid + 256 * i, row = pc / APC, col = pc - row * APC, cch = m0 + col * 8;
+    avo[i] = (col < APC - 2 && cch < g.Cout_p) ? (unsigned)(row * g.Cout_p * 2 + cch * 2) : 0xFFFFFFFFu;
+  }
+  auto dma_a = [&](unsigned k0, int buf) __attribute__((always_inline)) {
+    const unsigned kb = k0 * (unsigned)(g.Cout_p * 2);
+    unsigned char* dst = lds_raw + buf * ABYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i)
+      if (256 * (i + 1) <= 32 * APC || tid + 256 * i < 32 * APC)       // rows >= P: beyond the buffer -> zeros
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_void)(dst + i * 4096), 16, (int)(avo[i] == 0xFFFFFFFFu ? 0xFFFFFFF0u : avo[i] + kb), 0, 0, 0);
+  };
+
+  // ---- activation rows: staging unit u = the 32 rows q = k_lo + eh * W + 1 + 32 (u - 1) + j, one piece per thread
+  const int sj = tid >> 3, sc8 = tid & 7, scx = c0 + sc8 * 8;
+  const bool scv = scx < g.Cin_p;
+  float ps[8], ph[8];
+  if constexpr (PRO == 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool ok = scx + i < g.Cin;
+      ps[i] = ok ? in_ss[scx + i] : 0.f;
+      ph[i] = ok ? in_ss[g.Cin + scx + i] : 0.f;
+    }
+  }
+  u32x4 sreg;
+  int sslot;
+  bool sok, spad;
+  auto stage_load = [&](int u) __attribute__((always_inline)) {
+    const int q = (int)k_lo + eh * W + 1 + 32 * (u - 1) + sj;
+    bool ok = (unsigned)q < P && scv;
+    const unsigned qr = (unsigned)(q - org), rr = fdiv(qr, dW), wq = qr - rr * (unsigned)W;
+    if (eh != 0) {                                                   // the row above / below the image: zeros
+      const unsigned ar = ok ? (unsigned)((int)rr + base_row) : 0u;
+      const unsigned hq = ar - fdiv(ar, dH) * (unsigned)H;
+      if (hq == (eh > 0 ? 0u : (unsigned)(H - 1))) ok = false;
+    }
+    sreg = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                         rx, ok ? (unsigned)q * (unsigned)(g.Cin_p * 2) + (unsigned)scx * 2u : 0xFFFFFFF0u, 0, 0));
+    sslot = (int)((qr + rr) & (W3_PR - 1));
+    sok = ok;
+    spad = wq == (unsigned)(W - 1);
+  };
+  auto stage_store = [&]() __attribute__((always_inline)) {
+    u32x4 v = sreg;
+    if constexpr (PRO == 1) {
+      const u32x4 t = affine_relu8(v, ps, ph);
+      v = sok ? t : (u32x4){0u, 0u, 0u, 0u};
+    }
+    *(u32x4*)(patch + sslot * W3_SP + sc8 * 16) = v;
+    if (spad) *(u32x4*)(patch + ((sslot + 1) & (W3_PR - 1)) * W3_SP + sc8 * 16) = (u32x4){0u, 0u, 0u, 0u};
+  };
+
+  f32x4 acc[WM][3][2];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[i][e][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // transpose-read lanes (cf. cl16_wgrad_kernel): tile rows 4 fg + (fi >> 2) (+16), 4 columns at 4 (fi & 3)
+  const int fg = lane >> 4, fi = lane & 15;
+  const int rlo = 4 * fg + (fi >> 2);
+  const int fa = rlo * SA + (wm * WM * 16 + 4 * (fi & 3)) * 2;
+  const int fb = (wn * 32 + 4 * (fi & 3)) * 2;
+
+  if (nsteps > 0) {
+    stage_load(0);
+    dma_a(k_lo, 0);
+    stage_store();
+    stage_load(1);
+    stage_store();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    const unsigned k0 = k_lo + 32u * (unsigned)s;
+    stage_load(s + 2);
+    if (s + 1 < nsteps) dma_a(k0 + 32u, (s + 1) & 1);
+    {
+      const unsigned char* A = lds_raw + (s & 1) * ABYTES;
+      // patch rows of this lane's positions k0 + rlo and k0 + rlo + 16 for the tap row, column offset included
+      unsigned prow[2];
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        const unsigned pr = k0 + (unsigned)(rlo + 16 * hl) - (unsigned)org;
+        prow[hl] = pr + fdiv(pr, dW) + (unsigned)(eh * (W + 1));
+      }
+      bf16x8 a[WM], b[3][2];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(A + fa + i * 32));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(A + fa + i * 32 + 16 * SA));
+        const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        a[i] = __builtin_bit_cast(bf16x8, tmp);
+      }
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const unsigned char* blo = patch + ((prow[0] + (unsigned)(e - 1)) & (W3_PR - 1)) * W3_SP + fb;
+        const unsigned char* bhi = patch + ((prow[1] + (unsigned)(e - 1)) & (W3_PR - 1)) * W3_SP + fb;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(blo + c * 32));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bhi + c * 32));
+          const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          b[e][c] = __builtin_bit_cast(bf16x8, tmp);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[i][e][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[e][c], acc[i][e][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    stage_store();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // ---- partial tile of this K slice: part[slice][mtiles * BM][9 * Cin_p]; C/D: col = lane & 15, rows (lane >> 4) * 4 + r
+  const size_t ldp = (size_t)9 * g.Cin_p;
+  float* pt = part + ((size_t)slice * g.mtiles * BM + m0 + wm * WM * 16) * ldp;
+  if (c0 + wn * 32 < g.Cin_p) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            pt[(size_t)(i * 16 + fg * 4 + r) * ldp + (size_t)(ehi * 3 + e) * g.Cin_p + c0 + wn * 32 + c * 16 + fi] = acc[i][e][c][r];
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+// Does the patch kernel take this weight gradient, and with which tiling?  (kt, kh, kw) = (1, 3, 3), stride 1, padding
+// (0, 1, 1), W >= 4 (three staging units fit the circular patch).  SELAVI_CL16_WG3=0 sends everything to the general kernel.
+bool wgrad3_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, int kt, int kh, int kw, int st, int sh, int sw,
+                 int pt, int ph, int pw, int To, int Ho, int Wo, int* wm, ClWgrad3* out) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("SELAVI_CL16_WG3");
+    enabled = !(e && e[0] == '0');
+  }
+  if (!enabled) return false;
+  if (kt != 1 || kh != 3 || kw != 3 || st != 1 || sh != 1 || sw != 1 || pt != 0 || ph != 1 || pw != 1) return false;
+  if (To != T || Ho != H || Wo != W || W < 4) return false;
+  int best = 5;
+  long long best_rows = 1LL << 60;
+  for (int w = 5; w >= 2; --w) {                                  // least padding, then the larger tile
+    const long long rows = (long long)((Cout_p + 32 * w - 1) / (32 * w)) * 32 * w;
+    if (rows < best_rows) {
+      best_rows = rows;
+      best = w;
+    }
+  }
+  ClWgrad3 g;
+  g.N = N; g.T = T; g.H = H; g.W = W; g.Cin_p = Cin_p; g.Cin = Cin; g.Cout_p = Cout_p;
+  g.mtiles = (Cout_p + 32 * best - 1) / (32 * best);
+  g.groups = (Cin_p + 63) / 64;
+  const long long P = (long long)N * T * H * W;
+  const long long base = (long long)g.mtiles * g.groups * 3;
+  // ONE round of resident blocks: 2 per CU with WM = 4, 5 (> 168 registers), 3 with WM = 3, 4 with WM = 2 (a grid of
+  // 1.25 rounds runs at 62 %: measured with a target of 640 blocks on 512 slots); >= 64 K steps per slice
+  const long long slots = best >= 4 ? 512 : (best == 3 ? 768 : 1024);
+  long long ksl = slots / base;
+  if (ksl > P / 2048) ksl = P / 2048;
+  if (ksl < 1) ksl = 1;
+  long long kper = ((P + ksl - 1) / ksl + 31) / 32 * 32;
+  g.kper = (int)kper;
+  g.kslices = (int)((P + kper - 1) / kper);
+  *wm = best;
+  *out = g;
+  return true;
+}
+
+size_t wgrad3_ws_bytes(const ClWgrad3& g, int wm) {
+  return (size_t)g.kslices * g.mtiles * wm * 32 * 9 * g.Cin_p * sizeof(float);
+}
+
+template <int WM>
+static void wgrad3_launch_wm(const ClWgrad3& g, const void* dy, const void* x, const float* in_ss, float* part, hipStream_t st) {
+  const FastDiv dW = make_fastdiv(g.W), dH = make_fastdiv(g.H);
+  const unsigned blocks = (unsigned)(g.kslices * g.mtiles * g.groups * 3);
+  if (in_ss)
+    hipLaunchKernelGGL((cl16_wgrad3_kernel<WM, 1>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dy,
+                       (const unsigned short*)x, in_ss, part, g, dW, dH);
+  else
+    hipLaunchKernelGGL((cl16_wgrad3_kernel<WM, 0>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dy,
+                       (const unsigned short*)x, in_ss, part, g, dW, dH);
+}
+
+void wgrad3_launch(const ClWgrad3& g, int wm, const void* dy, const void* x, const float* in_ss, float* part, hipStream_t st) {
+  if (wm == 2) wgrad3_launch_wm<2>(g, dy, x, in_ss, part, st);
+  else if (wm == 3) wgrad3_launch_wm<3>(g, dy, x, in_ss, part, st);
+  else if (wm == 4) wgrad3_launch_wm<4>(g, dy, x, in_ss, part, st);
+  else wgrad3_launch_wm<5>(g, dy, x, in_ss, part, st);
+}
+
+}  // namespace slv

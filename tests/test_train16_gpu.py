@@ -128,6 +128,45 @@ def test_weight_gradient_matches_autograd(case):
     assert torch.equal(dw2, dw)                                      # fixed-order split-K: bit-reproducible
 
 
+PATCH_WGRAD_CASES = [  # N, Cin, T, H, W, Cout: stride-1 (1,3,3) layers -> the rolling-patch kernel (csrc/wgrad_cl16_s3.hip)
+    (1, 96, 3, 5, 7, 230),        # second 64-channel group half filled, two Cout tiles, 105 positions (not a multiple of 32)
+    (2, 45, 2, 6, 4, 64),         # W = 4: the narrowest image the circular patch takes; 45 -> 64 padded channels
+    (1, 64, 2, 4, 3, 96),         # W = 3: falls back to the general kernel
+    (2, 128, 4, 24, 24, 144),     # 4 608 positions: two K slices, rows cross frame and clip borders inside a slice
+    (1, 32, 1, 9, 33, 40),        # one image, W > 32 (a K step inside one image row), 32 channels = half a group
+]
+
+
+@pytest.mark.parametrize("case", PATCH_WGRAD_CASES)
+def test_weight_gradient_patch_kernel_shapes(case):
+    """The spatial convs' weight gradient (one block per kernel row: three taps share the staged activation rows; zero
+    rows between image rows stand for the left / right padding, the rows above / below an image are zeroed at staging)."""
+    from selavi_amd import ops16
+    N, Cin, T, H, W, Cout = case
+    k, st, pd = (1, 3, 3), (1, 1, 1), (0, 1, 1)
+    g = torch.Generator().manual_seed(3 * Cin + Cout + W)
+    x = _bf(torch.randn(N, Cin, T, H, W, generator=g))
+    ss = torch.stack([torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3]).contiguous()
+    xc = _cl(x)
+    plan = ops16.plan_for(xc, _Conv(Cin, Cout, k, st, pd))
+    dy = _bf(torch.randn(N, Cout, T, H, W, generator=g))
+    dyc = _cl(dy)
+    for pro in (False, True):
+        xa = x
+        if pro:
+            xa = _bf(torch.addcmul(ss[1].view(1, -1, 1, 1, 1).double(), x.double(), ss[0].view(1, -1, 1, 1, 1).double())
+                     .float().clamp_min(0))
+        w = torch.zeros(Cout, Cin, *k, dtype=torch.float64, requires_grad=True)
+        (want,) = torch.autograd.grad(F.conv3d(xa.double(), w, stride=st, padding=pd), w, dy.double())
+        dw = ops16.conv_wgrad(plan, dyc, xc, in_ss=ss.cuda() if pro else None, in_relu=pro)
+        got = dw.view(Cout, Cin, *k).double().cpu()
+        scale = float(want.abs().max())
+        err = (got - want).abs()
+        assert float(err.max()) <= (2e-3 if pro else 2e-5) * scale, (case, pro, float(err.max()), scale,
+                                                                      err.amax((0, 1)).flatten().tolist())
+    assert torch.equal(ops16.conv_wgrad(plan, dyc, xc, in_ss=ss.cuda(), in_relu=True), dw)
+
+
 def test_stem_patch_conv_forward_and_weight_gradient():
     """The (1,7,7) stem over 3 input channels through the W-patch layout: forward + statistics and the weight gradient
     mapped back to the reference's [45][3][1][7][7] layout."""
