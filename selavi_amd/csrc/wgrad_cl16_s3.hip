@@ -21,6 +21,9 @@
 
 namespace slv {
 
+#ifndef SLV_WG3_ABL
+#define SLV_WG3_ABL 0            // timing ablations (tools/build_variant.sh): 1 no MFMA, 2 no dY loads, 3 no activation loads
+#endif
 constexpr int W3_SP = 160, W3_PR = 128;          // patch row bytes (128 + 32), circular patch rows
 
 template <int WM, int PRO>
@@ -30,8 +33,15 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad3_kernel(const unsigned shor
                                                              ClWgrad3 g, FastDiv dW, FastDiv dH) {
   constexpr int BM = 32 * WM, APC = BM / 8 + 2, SA = APC * 16, AIT = (32 * APC + 255) / 256;
   constexpr int ABYTES = AIT * 4096;                              // one dY buffer (the DMA writes whole 1 KiB wave pieces)
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * ABYTES + W3_PR * W3_SP];
-  unsigned char* const patch = lds_raw + 2 * ABYTES;
+  constexpr int NAB = 3;                                           // dY buffers: the tile of step s + 2 is in flight during step s
+  // Two LDS objects and hand-issued reads of the first: the compiler orders every LDS read it can see behind LDS-DMA
+  // "that may alias" with s_waitcnt vmcnt(0) -- in front of the fragment reads of a step that is the whole memory latency
+  // of the requests the step has just issued (measured: 1 850 of a step's 3 070 cycles in "fragment reads + 30 MFMA").
+  // The dY buffers (the DMA's only target) are read with inline-asm ds_read_b64_tr_b16; the patch is a separate array
+  // that no DMA writes.  The real dependences are ordered by the s_waitcnt vmcnt + barrier at the end of a step.
+  __shared__ __attribute__((aligned(16))) unsigned char lds_a[NAB * ABYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char patch[W3_PR * W3_SP];
+  unsigned char* const lds_raw = lds_a;
   typedef __attribute__((address_space(3))) void* lds_void;
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -60,13 +70,20 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad3_kernel(const unsigned shor
     const int pc = tid + 256 * i, row = pc / APC, col = pc - row * APC, cch = m0 + col * 8;
     avo[i] = (col < APC - 2 && cch < g.Cout_p) ? (unsigned)(row * g.Cout_p * 2 + cch * 2) : 0xFFFFFFFFu;
   }
+  // 32 * APC is a multiple of 64: a wave's piece is inside the tile or entirely outside (only the last i can be): a wave
+  // issues AIT or AIT - 1 operations per tile, and the step's s_waitcnt counts with the wave's own number
+  constexpr bool PARTIAL = (32 * APC) % 256 != 0;
+  const bool last_in = !PARTIAL || wave * 64 + 256 * (AIT - 1) < 32 * APC;                   // wave-uniform
   auto dma_a = [&](unsigned k0, int buf) __attribute__((always_inline)) {
     const unsigned kb = k0 * (unsigned)(g.Cout_p * 2);
     unsigned char* dst = lds_raw + buf * ABYTES + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < AIT; ++i)
-      if (256 * (i + 1) <= 32 * APC || tid + 256 * i < 32 * APC)       // rows >= P: beyond the buffer -> zeros
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_void)(dst + i * 4096), 16, (int)(avo[i] == 0xFFFFFFFFu ? 0xFFFFFFF0u : avo[i] + kb), 0, 0, 0);
+    for (int i = 0; i < AIT; ++i) {
+      if (SLV_WG3_ABL == 2) continue;
+      if (i < AIT - 1 || last_in)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_void)(dst + i * 4096), 16,
+                                                 (int)(avo[i] == 0xFFFFFFFFu ? 0xFFFFFFF0u : avo[i] + kb), 0, 0, 0);
+    }
   };
 
   // ---- activation rows: staging unit u = the 32 rows q = k_lo + eh * W + 1 + 32 (u - 1) + j, one piece per thread
@@ -81,10 +98,13 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad3_kernel(const unsigned shor
       ph[i] = ok ? in_ss[g.Cin + scx + i] : 0.f;
     }
   }
-  u32x4 sreg;
-  int sslot;
-  bool sok, spad;
-  auto stage_load = [&](int u) __attribute__((always_inline)) {
+  struct Staged {
+    u32x4 reg;
+    int slot;
+    bool ok, pad;
+  };
+  Staged sg[2];                                                     // two units in flight (indexed with compile-time parities only)
+  auto stage_load = [&](int u, Staged& S) __attribute__((always_inline)) {
     const int q = (int)k_lo + eh * W + 1 + 32 * (u - 1) + sj;
     bool ok = (unsigned)q < P && scv;
     const unsigned qr = (unsigned)(q - org), rr = fdiv(qr, dW), wq = qr - rr * (unsigned)W;
@@ -93,20 +113,21 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad3_kernel(const unsigned shor
       const unsigned hq = ar - fdiv(ar, dH) * (unsigned)H;
       if (hq == (eh > 0 ? 0u : (unsigned)(H - 1))) ok = false;
     }
-    sreg = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                         rx, ok ? (unsigned)q * (unsigned)(g.Cin_p * 2) + (unsigned)scx * 2u : 0xFFFFFFF0u, 0, 0));
-    sslot = (int)((qr + rr) & (W3_PR - 1));
-    sok = ok;
-    spad = wq == (unsigned)(W - 1);
+    if (SLV_WG3_ABL == 3) S.reg = (u32x4){(unsigned)q, 1u, 2u, 3u};
+    else S.reg = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               rx, ok ? (unsigned)q * (unsigned)(g.Cin_p * 2) + (unsigned)scx * 2u : 0xFFFFFFF0u, 0, 0));
+    S.slot = (int)((qr + rr) & (W3_PR - 1));
+    S.ok = ok;
+    S.pad = wq == (unsigned)(W - 1);
   };
-  auto stage_store = [&]() __attribute__((always_inline)) {
-    u32x4 v = sreg;
+  auto stage_store = [&](const Staged& S) __attribute__((always_inline)) {
+    u32x4 v = S.reg;
     if constexpr (PRO == 1) {
       const u32x4 t = affine_relu8(v, ps, ph);
-      v = sok ? t : (u32x4){0u, 0u, 0u, 0u};
+      v = S.ok ? t : (u32x4){0u, 0u, 0u, 0u};
     }
-    *(u32x4*)(patch + sslot * W3_SP + sc8 * 16) = v;
-    if (spad) *(u32x4*)(patch + ((sslot + 1) & (W3_PR - 1)) * W3_SP + sc8 * 16) = (u32x4){0u, 0u, 0u, 0u};
+    *(u32x4*)(patch + S.slot * W3_SP + sc8 * 16) = v;
+    if (S.pad) *(u32x4*)(patch + ((S.slot + 1) & (W3_PR - 1)) * W3_SP + sc8 * 16) = (u32x4){0u, 0u, 0u, 0u};
   };
 
   f32x4 acc[WM][3][2];
@@ -121,22 +142,29 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad3_kernel(const unsigned shor
   const int rlo = 4 * fg + (fi >> 2);
   const int fa = rlo * SA + (wm * WM * 16 + 4 * (fi & 3)) * 2;
   const int fb = (wn * 32 + 4 * (fi & 3)) * 2;
+  const unsigned a_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds_a;   // LDS byte address
 
-  if (nsteps > 0) {
-    stage_load(0);
-    dma_a(k_lo, 0);
-    stage_store();
-    stage_load(1);
-    stage_store();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  for (int s = 0; s < nsteps; ++s) {
+  // Pipeline: at the top of step s the dY tile of step s + 2 (three buffers, LDS-DMA) and the activation rows of unit
+  // s + 3 (registers; written to the patch at the end of step s + 1) are requested: both have more than a full step to
+  // arrive.  Vector memory operations complete in order and a wave issues a fixed number of them per step (1 + its DMA
+  // operations), so "at most that many outstanding" at the end of step s means the dY tile of step s + 1 has landed.
+#ifdef SLV_WG3_TRACE   // s_memtime at 6 points of steps 8..15 of blocks 0..31 (wave 0) -> the first 32 * 64 uint64 of `part` (timing only!)
+#define W3_T(slot) if (tr_on && s >= 8 && s < 16) trace[(s - 8) * 6 + (slot)] = __builtin_amdgcn_s_memtime()
+  const bool tr_on = tid == 0 && blockIdx.x < 32;
+  unsigned long long* trace = (unsigned long long*)part + (size_t)blockIdx.x * 64;
+  if (tr_on) trace[60] = 0x1234u + (unsigned long long)nsteps;
+#else
+#define W3_T(slot)
+#endif
+  auto step = [&](int s, int ab, Staged& Snew, const Staged& Sold) __attribute__((always_inline)) {
     const unsigned k0 = k_lo + 32u * (unsigned)s;
-    stage_load(s + 2);
-    if (s + 1 < nsteps) dma_a(k0 + 32u, (s + 1) & 1);
+    const int ab2 = ab == 0 ? 2 : ab - 1;                            // (s + 2) % 3
+    W3_T(0);
+    stage_load(s + 3, Snew);
+    W3_T(1);
+    dma_a(k0 + 64u, ab2);                                            // past the slice: rows nobody reads (past P: zeros)
+    W3_T(2);
     {
-      const unsigned char* A = lds_raw + (s & 1) * ABYTES;
       // patch rows of this lane's positions k0 + rlo and k0 + rlo + 16 for the tap row, column offset included
       unsigned prow[2];
 #pragma unroll
@@ -145,12 +173,12 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad3_kernel(const unsigned shor
         prow[hl] = pr + fdiv(pr, dW) + (unsigned)(eh * (W + 1));
       }
       bf16x8 a[WM], b[3][2];
+      u32x2 alo[WM], ahi[WM];
+      const unsigned aaddr = a_lds + (unsigned)(ab * ABYTES + fa);
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(A + fa + i * 32));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(A + fa + i * 32 + 16 * SA));
-        const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        a[i] = __builtin_bit_cast(bf16x8, tmp);
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(alo[i]) : "v"(aaddr), "n"(i * 32));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[i]) : "v"(aaddr), "n"(i * 32 + 16 * SA));
       }
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
@@ -164,22 +192,66 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad3_kernel(const unsigned shor
           b[e][c] = __builtin_bit_cast(bf16x8, tmp);
         }
       }
+      // the hand-issued reads are invisible to the compiler's counters: wait for them here, with the registers as
+      // operands so that no use moves above the wait
+      if constexpr (WM == 5)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]),
+                     "+v"(alo[3]), "+v"(ahi[3]), "+v"(alo[4]), "+v"(ahi[4]));
+      else if constexpr (WM == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]),
+                     "+v"(alo[3]), "+v"(ahi[3]));
+      else if constexpr (WM == 3)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]));
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const u32x4 t = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]};
+        a[i] = __builtin_bit_cast(bf16x8, t);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int e = 0; e < 3; ++e)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) acc[i][e][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[e][c], acc[i][e][c], 0, 0, 0);
+          for (int c = 0; c < 2; ++c) {
+            if (SLV_WG3_ABL == 1) acc[i][e][c][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, a[i])[0] ^ __builtin_bit_cast(u32x4, b[e][c])[0]);
+            else acc[i][e][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[e][c], acc[i][e][c], 0, 0, 0);
+          }
       __builtin_amdgcn_sched_barrier(0);
     }
-    stage_store();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W3_T(3);
+    stage_store(Sold);                                               // unit s + 2, requested one step ago
+    W3_T(4);
+    // (not __syncthreads(): its release fence makes the compiler wait for ALL vector memory operations, the DMA of step
+    //  s + 2 included; lgkmcnt(0): this wave's patch writes are done before the barrier publishes them)
+    if (last_in) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SLV_WG3_ABL == 2 ? 1 : 1 + AIT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SLV_WG3_ABL == 2 ? 1 : AIT) : "memory");
+    W3_T(5);
+  };
+  if (nsteps > 0) {
+    stage_load(0, sg[0]);
+    dma_a(k_lo, 0);
+    dma_a(k_lo + 32u, 1);
+    stage_store(sg[0]);
+    stage_load(1, sg[0]);
+    stage_store(sg[0]);
+    stage_load(2, sg[1]);                                            // stored at the end of step 0
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");               // everything but that last request
     __syncthreads();
+  }
+  for (int s = 0; s < nsteps; s += 2) {                              // s % 3 cycles 0, 2, 1 over the pairs
+    const int ab = s % 3;
+    step(s, ab, sg[0], sg[1]);
+    if (s + 1 < nsteps) step(s + 1, ab == 2 ? 0 : ab + 1, sg[1], sg[0]);
   }
   // ---- partial tile of this K slice: part[slice][mtiles * BM][9 * Cin_p]; C/D: col = lane & 15, rows (lane >> 4) * 4 + r
   const size_t ldp = (size_t)9 * g.Cin_p;
   float* pt = part + ((size_t)slice * g.mtiles * BM + m0 + wm * WM * 16) * ldp;
+#ifdef SLV_WG3_TRACE
+  if (acc[0][0][0][0] == 123.456f)
+#endif
   if (c0 + wn * 32 < g.Cin_p) {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
