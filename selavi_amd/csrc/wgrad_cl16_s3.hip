@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad3_kernel(const unsigned shor
       const unsigned aaddr = a_lds + (unsigned)(ab * ABYTES + fa);
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(alo[i]) : "v"(aaddr), "n"(i * 32));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[i]) : "v"(aaddr), "n"(i * 32 + 16 * SA));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(alo[i]) : "v"(aaddr), "n"(i * 32) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[i]) : "v"(aaddr), "n"(i * 32 + 16 * SA) : "memory");
       }
 #pragma unroll
       for (int e = 0; e < 3; ++e) {

@@ -128,6 +128,31 @@ def test_weight_gradient_matches_autograd(case):
     assert torch.equal(dw2, dw)                                      # fixed-order split-K: bit-reproducible
 
 
+@pytest.mark.parametrize("case", [(2, 144, 4, 14, 14, 64), (2, 64, 3, 28, 28, 144), (1, 256, 2, 7, 7, 460)])
+def test_patch_conv_kernels_are_bit_reproducible(case):
+    """The same launch repeated gives the same bits: forward + statistics, backward data and weight gradient of the
+    stride-1 (1,3,3) layers (odd 32-channel chunk counts included: a hand-scheduled variant of the patch kernel raced there)."""
+    from selavi_amd import ops16
+    N, Cin, T, H, W, Cout = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = ops16.to_channels_last16(torch.randn(N, Cin, T, H, W, device=dev, generator=g))
+    plan = ops16.plan_for(x, _Conv(Cin, Cout, (1, 3, 3), (1, 1, 1), (0, 1, 1)))
+    w = torch.randn(Cout, Cin, 1, 3, 3, device=dev, generator=g) * 0.05
+    wf, wt = ops16.conv_w_transform(plan, w)
+    ss = torch.stack([torch.rand(Cin, device=dev, generator=g) + 0.5, torch.randn(Cin, device=dev, generator=g) * 0.1]).contiguous()
+    dy = ops16.to_channels_last16(torch.randn(N, Cout, T, H, W, device=dev, generator=g))
+    ref = None
+    for _ in range(8):
+        y, s1, s2 = ops16.conv_fwd(plan, x, w, in_ss=ss, in_relu=True, want_stats=True, wf=wf)
+        cur = (y.clone(), s1.clone(), s2.clone(), ops16.conv_dgrad(plan, dy, wt).clone(),
+               ops16.conv_wgrad(plan, dy, x, in_ss=ss, in_relu=True).clone())
+        if ref is None:
+            ref = cur
+        for a, b in zip(cur, ref):
+            assert torch.equal(a, b)
+
+
 PATCH_WGRAD_CASES = [  # N, Cin, T, H, W, Cout: stride-1 (1,3,3) layers -> the rolling-patch kernel (csrc/wgrad_cl16_s3.hip)
     (1, 96, 3, 5, 7, 230),        # second 64-channel group half filled, two Cout tiles, 105 positions (not a multiple of 32)
     (2, 45, 2, 6, 4, 64),         # W = 4: the narrowest image the circular patch takes; 45 -> 64 padded channels
