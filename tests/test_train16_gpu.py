@@ -396,6 +396,48 @@ def test_bf16_training_step_against_fp32_step():
     assert l16 == l16b and torch.equal(w16, w16b)
 
 
+def test_cfg5_full_size_step_on_the_16bit_path():
+    """BASELINE configs[4] at its full per-GPU size -- 128 clips x 32 frames x 112 x 112, 1 x 129 x 100 log-mel, K = 309,
+    10 heads -- on the 16-bit path: tensors beyond 4 GB (batch slices), 12.8 M positions per layer-1 launch.  There is no
+    oracle at this size; the properties: the loss of the first step equals the fp32 HIP step's on the same weights and
+    batch to bf16 accuracy and starts near ln K, the step is bit-reproducible, the BatchNorm running statistics of both
+    precisions agree, and a second step on the same batch lowers the loss."""
+    from selavi_amd import model as smodel, optim, train
+    if torch.cuda.get_device_properties(0).total_memory < 150 * 2 ** 30:
+        pytest.skip("needs the MI355X's HBM")
+    B, T, S, hc, K = 128, 32, 112, 10, 309
+    dev = torch.device("cuda:0")
+    res = {}
+    for tag in ("bf16", "bf16b", "fp32"):
+        torch.manual_seed(31)
+        m = smodel.load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', use_mlp=True, num_classes=K,
+                              pretrained=False, norm_feat=False, use_max_pool=False, headcount=hc).to(dev)
+        m.set_precision("fp32" if tag == "fp32" else "bf16")
+        m.train()
+        opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+        g = torch.Generator(device=dev).manual_seed(99)
+        video = torch.randn(B, 3, T, S, S, device=dev, generator=g)
+        audio = torch.randn(B, 1, 129, 100, device=dev, generator=g)
+        sl = torch.randint(0, K, (4096, hc), device=dev, generator=g)
+        sel = torch.randint(0, 4096, (B,), device=dev, generator=g)
+        torch.manual_seed(5)                                  # the dropout masks of the heads
+        losses = [float(train.train_step(m, opt, video, audio, sl, sel, hc))]
+        bn = m.video_network.base.layer1[0].conv1[0][1]
+        rm, rv = bn.running_mean.clone(), bn.running_var.clone()              # after ONE step, both precisions
+        if tag != "fp32":
+            losses.append(float(train.train_step(m, opt, video, audio, sl, sel, hc)))
+        res[tag] = (losses, rm, rv, m.video_network.base.layer4[1].conv2[0][3].weight.detach().clone())
+        del m, opt, video, audio
+        torch.cuda.empty_cache()
+    l16, l32 = res["bf16"][0], res["fp32"][0]
+    assert np.isfinite(l16).all() and abs(l16[0] - np.log(K)) < 0.25, l16
+    assert abs(l16[0] - l32[0]) <= 5e-3 * l32[0], (l16, l32)
+    assert l16[1] < l16[0], l16
+    assert res["bf16"][0] == res["bf16b"][0] and torch.equal(res["bf16"][3], res["bf16b"][3])
+    np.testing.assert_allclose(res["bf16"][1].cpu(), res["fp32"][1].cpu(), rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(res["bf16"][2].cpu(), res["fp32"][2].cpu(), rtol=2e-2, atol=2e-3)
+
+
 def test_bf16_eval_forward_through_the_engine_matches_infer16():
     """Eval mode on the training backend (BatchNorm applied on load) against the fused-epilogue inference engine: the
     same arithmetic up to where the roundings sit."""
