@@ -192,30 +192,21 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad3_kernel(const unsigned shor
           b[e][c] = __builtin_bit_cast(bf16x8, tmp);
         }
       }
-      // the hand-issued reads are invisible to the compiler's counters: wait for them here, with the registers as
-      // operands so that no use moves above the wait
-      if constexpr (WM == 5)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]),
-                     "+v"(alo[3]), "+v"(ahi[3]), "+v"(alo[4]), "+v"(ahi[4]));
-      else if constexpr (WM == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]),
-                     "+v"(alo[3]), "+v"(ahi[3]));
-      else if constexpr (WM == 3)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]));
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]));
+      // The hand-issued reads are invisible to the compiler's counters, but every MFMA also takes a patch fragment, and
+      // those reads are the compiler's own, issued AFTER the hand-issued ones (the asm's "memory" clobber keeps them
+      // there): LDS operations return in order, so the compiler's wait for b[e][c] covers every a[i].  Tap-major MFMA
+      // order: the first MFMAs start when the first patch fragment is in, not after all 22 reads.
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         const u32x4 t = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]};
         a[i] = __builtin_bit_cast(bf16x8, t);
       }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+      for (int e = 0; e < 3; ++e)
 #pragma unroll
-        for (int e = 0; e < 3; ++e)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
+          for (int i = 0; i < WM; ++i) {
             if (SLV_WG3_ABL == 1) acc[i][e][c][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, a[i])[0] ^ __builtin_bit_cast(u32x4, b[e][c])[0]);
             else acc[i][e][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[e][c], acc[i][e][c], 0, 0, 0);
           }
