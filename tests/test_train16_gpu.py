@@ -17,6 +17,11 @@ CASES = [  # N, Cin, T, H, W, Cout, k, stride, pad        the conv families of t
     (2, 45, 3, 9, 9, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),         # stem temporal (45 -> 64 padded input channels)
     (1, 512, 2, 7, 7, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # layer-4 spatial
     (1, 921, 2, 5, 5, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0)),       # layer-4 temporal (921 -> 928)
+    # temporal convs over 8 / 16 / 32 frames (a [frames][pixels]-tiled variant of the patch kernel was tried on these and
+    # measured no faster than the general kernel: profiles/r02_notes.md)
+    (2, 144, 16, 4, 6, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    (1, 64, 8, 8, 8, 230, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    (1, 230, 32, 2, 6, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
 ]
 
 
