@@ -252,26 +252,28 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(bf16x8, (okm[j] & bit) ? bv0[j] : (u32x4){0u, 0u, 0u, 0u});
-      if (live > 1) {
+      // ONE copy of chunk 0's MFMAs for both cases (a second copy under `live == 1` made the register allocator rename
+      // the accumulators per path and reconcile them with 72 v_mov per stage at the loop's back edge: a quarter of
+      // the kernel's VALU instructions, on a kernel whose SIMDs spend 52 % of their cycles issuing VALU)
+      const bool two = live > 1;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          mma(i, a[i], b);
+      for (int i = 0; i < MT; ++i) {
+        mma(i, a[i], b);
+        if (two) {
           if (i == MT - 1) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) bv1[j] = rdb(1, j);
           }
           a[i] = rda(1, i);
-          __builtin_amdgcn_sched_barrier(0);
         }
-        S3_T(2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      S3_T(2);
+      if (two) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(bf16x8, (okm[j] & bit) ? bv1[j] : (u32x4){0u, 0u, 0u, 0u});
 #pragma unroll
         for (int i = 0; i < MT; ++i) mma(i, a[i], b);
-      } else {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) mma(i, a[i], b);
-        S3_T(2);
       }
       __builtin_amdgcn_sched_barrier(0);
     }

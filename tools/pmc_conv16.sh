@@ -8,9 +8,11 @@ i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
            "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS" \
-           "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+           "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+           "TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCC_WRITE_REQ_sum TA_BUSY_avr TA_TA_BUSY_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
+           "TA_BUFFER_LOAD_WAVEFRONTS_sum TA_BUFFER_STORE_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/p$i -o p -- python tools/conv16_bench.py l1.spatial 3 16 > $out/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/p$i -o p -- python tools/conv16_bench.py l1.spatial 3 ${2:-16} > $out/p$i.log 2>&1
 done
 python - "$out" <<'PY'
 import csv, glob, collections, sys
@@ -19,7 +21,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{out}/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "conv_cl16" not in k and "cl16_wgrad_kernel" not in k: continue
+        if "conv_cl16" not in k and "cl16_wgrad" not in k: continue
         name = k.replace("void slv::", "").split("(")[0] + " grid=" + r.get("Grid_Size", "")
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(f"{out}/pmc_conv16.txt", "w") as fo:
