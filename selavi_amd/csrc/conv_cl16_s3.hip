@@ -82,9 +82,9 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
 #pragma unroll
     for (int i = 0; i < S3_PIT; ++i) {
       const int idx = tl + S3_THREADS * i, r = idx / SLOTS, s = idx - r * SLOTS;
-      const long long q = (long long)p0 - W - 1 + r;
+      const int q = (int)p0 - W - 1 + r;               // 32-bit on purpose (P * Cin_p * 2 < 2^32: the host checks the tensor size)
       const int c = cg * (KCG * 32) + s * 8;
-      const bool ok = r < prow && q >= 0 && q < (long long)P && c < g.Cin_p;
+      const bool ok = r < prow && (unsigned)q < P && c < g.Cin_p;
       pvalid |= (unsigned)ok << i;
       const unsigned off = (unsigned)q * (unsigned)(g.Cin_p * 2) + (unsigned)c * 2u;
       rp[i] = SLV_S3_ABL == 6 ? (u32x4){off, 0u, 0u, 0u}
