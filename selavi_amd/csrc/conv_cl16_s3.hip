@@ -183,14 +183,10 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
     prow_l[j] = pl + W + 1;
     const unsigned q = p / (unsigned)W;
     const int w = p - q * W, h = q % (unsigned)H;
-    unsigned m = 0;
-    if (p < P)
-#pragma unroll
-      for (int eh = -1; eh <= 1; ++eh)
-#pragma unroll
-        for (int ew = -1; ew <= 1; ++ew)
-          if ((unsigned)(h + eh) < (unsigned)H && (unsigned)(w + ew) < (unsigned)W) m |= 1u << ((eh + 1) * 3 + ew + 1);
-    okm[j] = m;
+    // rows of the 3 x 3 mask that exist (eh = -1, 0, 1 -> bits 0-2, 3-5, 6-8) AND its columns that exist (ew -> bit 0, 1, 2 of each row)
+    const unsigned rows = (h > 0 ? 0x007u : 0u) | 0x038u | (h < H - 1 ? 0x1C0u : 0u);
+    const unsigned cols = (w > 0 ? 0x049u : 0u) | 0x092u | (w < W - 1 ? 0x124u : 0u);
+    okm[j] = p < P ? rows & cols : 0u;
   }
   if (nst > 0) {
     if constexpr (PRO == 1) __syncthreads();
@@ -391,14 +387,20 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
   const int c_lo = m0, c_hi = min(m0 + BM, g.Cout_p);
   const int c_end = (by == gridDim.y - 1) ? g.Cout_p : c_hi;
   const int pieces = (c_end - c_lo) >> 3;
-  const float inv_pieces = 1.f / (float)pieces;
-  for (int idx = tid; idx < S3_BN * pieces; idx += S3_THREADS) {
-    const int pl = (int)(((float)idx + 0.5f) * inv_pieces), pc = idx - pl * pieces;   // exact: idx < 2^15
-    const unsigned p = p0 + pl;
-    if (p >= P) continue;
-    u32x4 val = {0u, 0u, 0u, 0u};
-    if (c_lo + pc * 8 < c_hi) val = *(const u32x4*)(ot + pl * OROW + pc * 16);
-    if (SLV_S3_ABL != 4 || val[0] == 0x12345678u) *(u32x4*)(y + (size_t)p * g.Cout_p + c_lo + pc * 8) = val;
+  // a thread keeps its 16-byte column piece and walks down the rows: rpp = threads / pieces rows per pass (one division
+  // per thread instead of index arithmetic per store; P * Cout_p * 2 < 2^32, so 32-bit byte offsets)
+  const int rpp = S3_THREADS / pieces, pl0 = tid / pieces, pc = tid - pl0 * pieces;
+  if (pl0 < rpp) {
+    const bool cval = c_lo + pc * 8 < c_hi;
+    const unsigned char* src = ot + pl0 * OROW + pc * 16;
+    unsigned char* yb = (unsigned char*)y;
+    unsigned off = ((p0 + (unsigned)pl0) * (unsigned)g.Cout_p + (unsigned)(c_lo + pc * 8)) * 2u;
+    const unsigned dstep = (unsigned)(rpp * g.Cout_p * 2);
+    for (int pl = pl0; pl < S3_BN && p0 + (unsigned)pl < P; pl += rpp, src += rpp * OROW, off += dstep) {
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if (cval) val = *(const u32x4*)src;
+      if (SLV_S3_ABL != 4 || val[0] == 0x12345678u) *(u32x4*)(yb + off) = val;
+    }
   }
 #ifdef SLV_S3_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
