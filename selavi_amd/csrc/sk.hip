@@ -32,7 +32,16 @@ struct SkWs {
   int Kp;
 };
 
-static inline int kpad(int K) { return ((K + 63) / 64) * 64; }
+// Row width of the per-block partial sums: 64 x the KJ the kernels are DISPATCHED with (SK_DISPATCH_KJ rounds
+// ceil(K / 64) up to an instantiated value: 3 -> 4, 6 -> 7, 9..11 -> 12), not 64 x ceil(K / 64): block_reduce_cols
+// writes KJ * 64 entries per block, and with the narrower rows a block overwrote the first columns of its neighbour's
+// partials for 128 < K <= 192, 320 < K <= 384, 512 < K <= 704 (found by the K = 700 edge case going through 2 000
+// iterations; the reference's K = 309 and 400 have KJ = ceil(K / 64) and were never affected).
+static inline int kj_dispatched(int K) {
+  const int kj = (K + 63) / 64;
+  return kj <= 2 ? kj : kj <= 4 ? 4 : kj <= 5 ? 5 : kj <= 7 ? 7 : kj <= 8 ? 8 : 12;
+}
+static inline int kpad(int K) { return kj_dispatched(K) * 64; }
 
 static inline SkWs carve(void* ws, int K, int grid) {
   SkWs w;

@@ -50,7 +50,9 @@ def test_optimize_L_sk_gpu_matches_reference_golden(golden_dir, name):
         np.testing.assert_array_equal(args.dist[head].cpu().numpy().ravel(), g["dist_after"][head])
 
 
-@pytest.mark.parametrize("N,K", [(1, 5), (7, 1), (65, 64), (513, 65), (1000, 309), (300, 512), (257, 700), (96, 768)])
+@pytest.mark.parametrize("N,K", [(1, 5), (7, 1), (65, 64), (513, 65), (1000, 309), (300, 512), (257, 700), (96, 768),
+                                 # ceil(K / 64) = 3, 6, 9: dispatched with the next instantiated column count (4, 7, 12)
+                                 (2100, 150), (2100, 330), (2100, 520), (4200, 640)])
 def test_edge_shapes_match_oracle(N, K):
     from selavi_amd import sk_utils
     PS = synth_PS(N, K, 1.5, 77 + N)
