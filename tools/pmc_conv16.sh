@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ / LDS / TCP counters of the bf16 conv kernels on the layer-1 spatial conv (tools/conv16_bench.py l1.spatial), one
-# rocprofv3 --pmc pass per counter group (kernel trace only).  Output: gpurun_out/$1/pmc_conv16.txt
+# rocprofv3 --pmc pass per counter group (kernel trace only; each pass under its own timeout: a pass with TA_* / TCP_*STALL*
+# counters hung the profiler for the whole gpurun limit once).  Output: gpurun_out/$1/pmc_conv16.txt
 out=gpurun_out/${1:-pmc16}
 mkdir -p $out
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
@@ -8,11 +9,9 @@ i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
            "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS" \
-           "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
-           "TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCC_WRITE_REQ_sum TA_BUSY_avr TA_TA_BUSY_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
-           "TA_BUFFER_LOAD_WAVEFRONTS_sum TA_BUFFER_STORE_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_ANY"; do
+           "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/p$i -o p -- python tools/conv16_bench.py l1.spatial 3 ${2:-16} > $out/p$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/p$i -o p -- python tools/conv16_bench.py l1.spatial 3 ${2:-16} > $out/p$i.log 2>&1
 done
 python - "$out" <<'PY'
 import csv, glob, collections, sys
