@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
                                                            const float* __restrict__ scale_shift,   // [2][Cout] or null
                                                            const unsigned short* __restrict__ res,  // output-shaped or null
                                                            int relu, float* __restrict__ stat_sum,
-                                                           float* __restrict__ stat_sq, ClBnr bn, ClConv g) {
+                                                           float* __restrict__ stat_sq, ClBnr bn, ClConv g, FastDiv dLw, FastDiv dLh, FastDiv dLt, FastDiv dGx) {
   constexpr int BM = MT * 16;
   constexpr int APIECES = BM * 4, AITER = (APIECES + 255) / 256;
   constexpr int OROW = BM * 2 + 16;                   // bytes per position row of the transposed output tile (+16: banks)
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
     const unsigned nb = gridDim.x * gridDim.y, lin = blockIdx.x + blockIdx.y * gridDim.x, q8 = nb >> 3, r8 = nb & 7,
                    xcd = lin & 7, loc = lin >> 3;
     const unsigned unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    by = unit / gridDim.x;
+    by = fdiv(unit, dGx);
     bx = unit - by * gridDim.x;
   }
   const int m0 = by * BM;
@@ -67,10 +67,10 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const unsigned p = bx * CL_BN + (tid >> 2) + 64 * i;
-    unsigned q = p;
-    const int lw = q % g.Lw; q /= g.Lw;
-    const int lh = q % g.Lh; q /= g.Lh;
-    const int lt = q % g.Lt; q /= g.Lt;      // q = clip
+    // (divisions by multiply + shift: a division by a runtime value is ~25 VALU instructions, and this kernel's SIMDs
+    //  spend 55-66 % of their cycles issuing VALU -- profiles/r02_pmc_conv16.txt)
+    const unsigned q1 = fdiv(p, dLw), q2 = fdiv(q1, dLh), q = fdiv(q2, dLt);      // q = clip
+    const int lw = p - q1 * g.Lw, lh = q1 - q2 * g.Lh, lt = q2 - q * g.Lt;
     bt[i] = lt * g.bmt + g.bot;
     bh[i] = lh * g.bmh + g.boh;
     bw[i] = lw * g.bmw + g.bow;
@@ -180,11 +180,10 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
   unsigned* opos = (unsigned*)(lds_raw + CL_BN * OROW + 12 * BM * 4);  // [CL_BN] output position (row index) or ~0
   if (tid < CL_BN) {
     const unsigned p = bx * CL_BN + tid;
-    unsigned q = p, o = 0xFFFFFFFFu;
+    unsigned o = 0xFFFFFFFFu;
     if (p < P) {
-      const int lw = q % g.Lw; q /= g.Lw;
-      const int lh = q % g.Lh; q /= g.Lh;
-      const int lt = q % g.Lt; q /= g.Lt;
+      const unsigned q1 = fdiv(p, dLw), q2 = fdiv(q1, dLh), q = fdiv(q2, dLt);
+      const int lw = p - q1 * g.Lw, lh = q1 - q2 * g.Lh, lt = q2 - q * g.Lt;
       o = ((q * g.To + lt * g.omt + g.oot) * g.Ho + lh * g.omh + g.ooh) * g.Wo + lw * g.omw + g.oow;
     }
     opos[tid] = o;
@@ -283,14 +282,21 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
   const int c_lo = m0, c_hi = min(m0 + BM, g.Cout_p);
   const int c_end = (by == gridDim.y - 1) ? g.Cout_p : c_hi;
   const int pieces = (c_end - c_lo) >> 3;                 // 16-byte pieces per position (channel counts are multiples of 8)
-  const float inv_pieces = 1.f / (float)pieces;
-  for (int idx = tid; idx < CL_BN * pieces; idx += 256) {
-    const int pl = (int)(((float)idx + 0.5f) * inv_pieces), pc = idx - pl * pieces;   // exact: idx < 2^15
-    const unsigned op = opos[pl];
-    if (op == 0xFFFFFFFFu) continue;
-    u32x4 val = {0u, 0u, 0u, 0u};
-    if (c_lo + pc * 8 < c_hi) val = *(const u32x4*)(ot + pl * OROW + pc * 16);
-    *(u32x4*)(y + (size_t)op * g.Cout_p + c_lo + pc * 8) = val;
+  // a thread keeps its 16-byte column piece and walks down the rows, rpp = 256 / pieces rows per pass (one division per
+  // thread instead of index arithmetic per store; P_out * Cout_p * 2 < 2^32: 32-bit byte offsets)
+  const int rpp = 256 / pieces, pl0 = tid / pieces, pc = tid - pl0 * pieces;
+  if (pl0 < rpp) {
+    const bool cval = c_lo + pc * 8 < c_hi;
+    const unsigned char* src = ot + pl0 * OROW + pc * 16;
+    unsigned char* yb = (unsigned char*)y;
+    const unsigned coff = (unsigned)(c_lo + pc * 8) * 2u, rowb = (unsigned)g.Cout_p * 2u;
+    for (int pl = pl0; pl < CL_BN; pl += rpp, src += rpp * OROW) {
+      const unsigned op = opos[pl];
+      if (op == 0xFFFFFFFFu) continue;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if (cval) val = *(const u32x4*)src;
+      *(u32x4*)(yb + op * rowb + coff) = val;
+    }
   }
 }
 
@@ -394,7 +400,8 @@ static int cl16_launch(const slv::ClConv& g, int mt, const void* x, const void* 
 #define SLV_CL16(MT_, PRO_, EPI_)                                                                                     \
   hipLaunchKernelGGL((conv_cl16_kernel<MT_, PRO_, EPI_>), grid, dim3(256), 0, (hipStream_t)stream,                    \
                      (const unsigned short*)x, (const unsigned short*)wl, (unsigned short*)y, in_ss, scale_shift,     \
-                     (const unsigned short*)res, relu, stat_sum, stat_sq, bnr, g)
+                     (const unsigned short*)res, relu, stat_sum, stat_sq, bnr, g, make_fastdiv(g.Lw), make_fastdiv(g.Lh), \
+                     make_fastdiv(g.Lt), make_fastdiv(grid.x))
 #define SLV_CL16_MT(MT_)                              \
   do {                                                \
     if (epi == 2) SLV_CL16(MT_, 0, 2);                \
