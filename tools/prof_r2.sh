@@ -15,3 +15,7 @@ rm -rf $out/bench
 rocprofv3 --kernel-trace --stats -d $out/step16 -- python tools/step16_bench.py 16 16 10 bf16 > $out/step16.log 2>&1
 python tools/rocprof_summary.py $out/step16 100000 > $out/step16_kernel_summary.txt
 rm -rf $out/step16
+# the 16-bit step at BASELINE configs[4]'s per-GPU shape (128 clips x 32 frames)
+rocprofv3 --kernel-trace --stats -d $out/step16_cfg5 -- python tools/step16_bench.py 128 32 3 bf16 > $out/step16_cfg5.log 2>&1
+python tools/rocprof_summary.py $out/step16_cfg5 100000 > $out/step16_cfg5_kernel_summary.txt
+rm -rf $out/step16_cfg5
