@@ -226,12 +226,20 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
         const unsigned op = op2;
         uint2 rr = make_uint2(0u, 0u);
         if (res && op != 0xFFFFFFFFu && co < g.Cout_p) rr = *(const uint2*)(res + (size_t)op * g.Cout_p + co);
+        if (!scale_shift && !relu) {      // backward data: the accumulator (+ addend) as it is -- rows >= Cout have zero weights
+#pragma unroll                            // and the addend's padding channels are zero (the full path below costs ~45 VALU per 4 x 2 outputs)
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[i][j][r];
+            if (res) v[r] += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
+          }
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float t = acc[i][j][r] * sc[r] + sh[r];
-          if (res) t += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
-          if (relu) t = fmaxf(t, 0.f);
-          v[r] = (co + r < g.Cout) ? t : 0.f;                         // padding channels stay zero
+          for (int r = 0; r < 4; ++r) {
+            float t = acc[i][j][r] * sc[r] + sh[r];
+            if (res) t += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
+            if (relu) t = fmaxf(t, 0.f);
+            v[r] = (co + r < g.Cout) ? t : 0.f;                         // padding channels stay zero
+          }
         }
       } else {
 #pragma unroll

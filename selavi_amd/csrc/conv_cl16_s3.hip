@@ -332,12 +332,20 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
       if constexpr (EPI != 1) {
         uint2 rr = make_uint2(0u, 0u);
         if (res && p < P && co < g.Cout_p) rr = *(const uint2*)(res + (size_t)p * g.Cout_p + co);
+        if (!scale_shift && !relu) {      // backward data: the accumulator (+ addend) as it is (cf. conv_cl16.hip)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float tt = acc[i][j][r] * sc[r] + sh[r];
-          if (res) tt += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
-          if (relu) tt = fmaxf(tt, 0.f);
-          v[r] = (co + r < g.Cout) ? tt : 0.f;
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[i][j][r];
+            if (res) v[r] += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float tt = acc[i][j][r] * sc[r] + sh[r];
+            if (res) tt += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
+            if (relu) tt = fmaxf(tt, 0.f);
+            v[r] = (co + r < g.Cout) ? tt : 0.f;
+          }
         }
       } else {
 #pragma unroll
