@@ -235,10 +235,10 @@ __global__ __launch_bounds__(256, MT >= 8 ? 3 : 4) void conv_cl16_kernel(const u
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float t = acc[i][j][r] * sc[r] + sh[r];
+            float t = __builtin_fmaf(acc[i][j][r], sc[r], sh[r]);     // (scale, shift are zero for channels >= Cout, the residual's padding is zero: no select)
             if (res) t += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
             if (relu) t = fmaxf(t, 0.f);
-            v[r] = (co + r < g.Cout) ? t : 0.f;                         // padding channels stay zero
+            v[r] = t;
           }
         }
       } else {

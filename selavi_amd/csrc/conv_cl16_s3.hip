@@ -341,10 +341,10 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float tt = acc[i][j][r] * sc[r] + sh[r];
+            float tt = __builtin_fmaf(acc[i][j][r], sc[r], sh[r]);     // (scale, shift are zero for channels >= Cout, the residual's padding is zero: no select)
             if (res) tt += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
             if (relu) tt = fmaxf(tt, 0.f);
-            v[r] = (co + r < g.Cout) ? tt : 0.f;
+            v[r] = tt;
           }
         }
       } else {
