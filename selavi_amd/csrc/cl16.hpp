@@ -149,4 +149,15 @@ bool wgrad3_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, int
 size_t wgrad3_ws_bytes(const ClWgrad3& g, int wm);
 void wgrad3_launch(const ClWgrad3& g, int wm, const void* dy, const void* x, const float* in_ss, float* part, hipStream_t st);
 
+// csrc/wgrad_cl16_t.hip: weight gradient of the stride-1 (3,1,1) convs, one pass over the activations for the three taps
+struct ClWgradT {
+  int N, T, HW, Cin_p, Cin, Cout_p;
+  int PB;                              // 32-pixel blocks per frame
+  int mtiles, groups, kslices, sper;   // Cout tiles, channel groups, slices of sper steps (step = column * (T + 1) + frame)
+};
+bool wgrad_t_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, int kt, int kh, int kw, int st, int sh, int sw,
+                  int pt, int ph, int pw, int To, int Ho, int Wo, int* wm, int* nc, ClWgradT* out);
+size_t wgrad_t_ws_bytes(const ClWgradT& g, int wm);
+void wgrad_t_launch(const ClWgradT& g, int wm, int nc, const void* dy, const void* x, const float* in_ss, float* part, hipStream_t st);
+
 }  // namespace slv

@@ -519,6 +519,13 @@ size_t slv_cl16_wgrad_ws_bytes(const int32_t* clw, int wm, int wn) {
     const size_t patch = slv::wgrad3_ws_bytes(g3, wm3);
     return patch > general ? patch : general;
   }
+  slv::ClWgradT gt;
+  int wmt, nct;
+  if (slv::wgrad_t_plan(g.N, g.Ti, g.Hi, g.Wi, g.Cin_p, g.Cin, g.Cout_p, g.kt, g.kh, g.kw, g.st, g.sh, g.sw, g.pt, g.ph, g.pw,
+                        g.To, g.Ho, g.Wo, &wmt, &nct, &gt)) {
+    const size_t col = slv::wgrad_t_ws_bytes(gt, wmt);
+    return col > general ? col : general;
+  }
   return general;
 }
 
@@ -554,6 +561,20 @@ int slv_cl16_wgrad(const int32_t* clw, int wm, int wn, const void* dy_bf16, cons
       const size_t ldp3 = (size_t)g.Ncols;
       hipLaunchKernelGGL(cl16_wgrad_reduce_kernel, dim3((g.Ncols + 255) / 256, Cout), dim3(256), 0, st, part, dw, Cout, g.Cin,
                          taps, g.Cin_p, g3.kslices, (size_t)g3.mtiles * wm3 * 32 * ldp3, ldp3, 0, (unsigned)g.Ncols);
+      SLV_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  {                                                                // stride-1 (3,1,1): the column-order kernel
+    ClWgradT gt;
+    int wmt, nct;
+    if (!patch_kw && wgrad_t_plan(g.N, g.Ti, g.Hi, g.Wi, g.Cin_p, g.Cin, g.Cout_p, g.kt, g.kh, g.kw, g.st, g.sh, g.sw, g.pt,
+                                  g.ph, g.pw, g.To, g.Ho, g.Wo, &wmt, &nct, &gt)) {
+      wgrad_t_launch(gt, wmt, nct, dy_bf16, x_bf16, in_scale_shift, part, st);
+      SLV_LAUNCH_CHECK();
+      const size_t ldpt = (size_t)g.Ncols;
+      hipLaunchKernelGGL(cl16_wgrad_reduce_kernel, dim3((g.Ncols + 255) / 256, Cout), dim3(256), 0, st, part, dw, Cout, g.Cin,
+                         taps, g.Cin_p, gt.kslices, (size_t)gt.mtiles * wmt * 32 * ldpt, ldpt, 0, (unsigned)g.Ncols);
       SLV_LAUNCH_CHECK();
       return 0;
     }

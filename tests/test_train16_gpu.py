@@ -197,6 +197,46 @@ def test_weight_gradient_patch_kernel_shapes(case):
     assert torch.equal(ops16.conv_wgrad(plan, dyc, xc, in_ss=ss.cuda(), in_relu=True), dw)
 
 
+COLUMN_WGRAD_CASES = [  # N, Cin, T, H, W, Cout: stride-1 (3,1,1) layers -> the column-order kernel (csrc/wgrad_cl16_t.hip)
+    (4, 64, 16, 16, 16, 64),      # 544 steps in 8 slices: slices start inside columns, cross columns and clips
+    (2, 144, 3, 7, 9, 64),        # 63 pixels per frame: a full and a 31-pixel block; (WM, NC) = (2, 5), the layer-1 shape
+    (1, 230, 2, 5, 5, 128),       # two frames (every frame has a missing neighbour), 25 pixels, 230 -> 256 channels in 4 groups
+    (1, 96, 5, 6, 6, 460),        # three Cout tiles of 160, second channel group half filled
+    (3, 45, 4, 8, 8, 45),         # 45 -> 64 padded channels on both sides
+]
+
+
+@pytest.mark.parametrize("case", COLUMN_WGRAD_CASES)
+def test_weight_gradient_column_kernel_shapes(case):
+    """The temporal convs' weight gradient: positions contracted column by column (32 pixels through all frames, a virtual
+    zero frame between columns), the three taps from a ring of staged frame tiles -- every activation row read once."""
+    from selavi_amd import ops16
+    N, Cin, T, H, W, Cout = case
+    k, st, pd = (3, 1, 1), (1, 1, 1), (1, 0, 0)
+    g = torch.Generator().manual_seed(3 * Cin + Cout + T)
+    x = _bf(torch.randn(N, Cin, T, H, W, generator=g))
+    ss = torch.stack([torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3]).contiguous()
+    xc = _cl(x)
+    plan = ops16.plan_for(xc, _Conv(Cin, Cout, k, st, pd))
+    dy = _bf(torch.randn(N, Cout, T, H, W, generator=g))
+    dyc = _cl(dy)
+    for pro in (False, True):
+        xa = x
+        if pro:
+            xa = _bf(torch.addcmul(ss[1].view(1, -1, 1, 1, 1).double(), x.double(), ss[0].view(1, -1, 1, 1, 1).double())
+                     .float().clamp_min(0))
+        w = torch.zeros(Cout, Cin, *k, dtype=torch.float64, requires_grad=True)
+        (want,) = torch.autograd.grad(F.conv3d(xa.double(), w, stride=st, padding=pd), w, dy.double())
+        dw = ops16.conv_wgrad(plan, dyc, xc, in_ss=ss.cuda() if pro else None, in_relu=pro)
+        got = dw.view(Cout, Cin, *k).double().cpu()
+        scale = float(want.abs().max())
+        err = (got - want).abs()
+        assert float(err.max()) <= (2e-3 if pro else 2e-5) * scale, (case, pro, float(err.max()), scale,
+                                                                      err.amax((0, 1)).flatten().tolist())
+    for _ in range(3):                                               # fixed-order split-K, no races: bit-reproducible
+        assert torch.equal(ops16.conv_wgrad(plan, dyc, xc, in_ss=ss.cuda(), in_relu=True), dw)
+
+
 def test_stem_patch_conv_forward_and_weight_gradient():
     """The (1,7,7) stem over 3 input channels through the W-patch layout: forward + statistics and the weight gradient
     mapped back to the reference's [45][3][1][7][7] layout."""
