@@ -343,8 +343,8 @@ int slv_avgpool_cl16(const void* x_bf16, float* y, int64_t N, int64_t S, int C, 
  * slv_cl16_wgrad: dw[Cout][Cin][taps] (fp32, reference layout) = sum_pos dy[pos][co] * act(x)[pos*stride+tap-pad][ci];
  *   clw: slv_cl16_wgrad_words() int32 = {N, Ti, Hi, Wi, Cin_p, Cin, To, Ho, Wo, Cout_p, st, sh, sw, pt, ph, pw, kt, kh, kw,
  *   Ncols, mtiles, ntiles, kslices, kper}; tile = (32*wm) x (32*wn), wm, wn in 2..5; deterministic split-K through `ws`.
- *   Stride-1 (1,3,3) layers run on the rolling-patch kernel (csrc/wgrad_cl16_s3.hip; its own tiling and K slices:
- *   slv_cl16_wgrad_ws_bytes covers both kernels); the result does not depend on which kernel ran beyond fp32 summation order.
+ *   Stride-1 (1,3,3) layers run on the rolling-patch kernel (csrc/wgrad_cl16_s3.hip), stride-1 (3,1,1) layers on the
+ *   column-order kernel (csrc/wgrad_cl16_t.hip); each has its own tiling and K slices (slv_cl16_wgrad_ws_bytes covers all); the result does not depend on which kernel ran beyond fp32 summation order.
  * slv_cl16_bn_*: channels-last bf16 versions of slv_bn_act / slv_bn_bwd_reduce / slv_bn_bwd_apply on [P][Cp]. */
 int32_t slv_cl16_conv_words(void);
 int32_t slv_cl16_conv_nblk(const int32_t* clconv);
