@@ -284,9 +284,9 @@ bool wgrad3_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, int
   g.groups = (Cin_p + 63) / 64;
   const long long P = (long long)N * T * H * W;
   const long long base = (long long)g.mtiles * g.groups * 3;
-  // ONE round of resident blocks: 2 per CU with WM = 4, 5 (> 168 registers), 3 with WM = 3, 4 with WM = 2 (a grid of
+  // ONE round of resident blocks: 2 per CU with WM = 3, 4, 5 (> 168 registers), 3 with WM = 2 (a grid of
   // 1.25 rounds runs at 62 %: measured with a target of 640 blocks on 512 slots); >= 64 K steps per slice
-  const long long slots = best >= 4 ? 512 : (best == 3 ? 768 : 1024);
+  const long long slots = best >= 3 ? 512 : 768;      // registers: 234 / 206 / 176 -> 2 blocks per CU, 148 (WM = 2) -> 3
   long long ksl = slots / base;
   if (ksl > P / 2048) ksl = P / 2048;
   if (ksl < 1) ksl = 1;

@@ -262,7 +262,10 @@ bool wgrad_t_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, in
   const long long steps = (long long)N * g.PB * (T + 1);
   if (steps >= (1LL << 30)) return false;
   const long long base = (long long)g.mtiles * g.groups;
-  long long ksl = 512 / base;                                     // one round of resident blocks (2 per CU)
+  // one round of resident blocks: 2 per CU for (2,5) and (5,2) (199-203 / 177 registers), 3 for (4,2) (149 registers,
+  // 48 KB LDS), 4 for (2,2) (97 registers, 36 KB)
+  const long long slots = (w == 2 && c == 2) ? 1024 : (w == 4 ? 768 : 512);
+  long long ksl = slots / base;
   if (ksl > steps / 64) ksl = steps / 64;                        // >= 64 steps per slice
   if (ksl < 1) ksl = 1;
   g.sper = (int)((steps + ksl - 1) / ksl);
