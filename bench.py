@@ -39,7 +39,7 @@ FWD_MB_PER_CLIP = 518.1 + 3.38          # sum over convs of (in + out
 def _pmc_traffic(key):
     """Measured HBM bytes/launch recorded by the PMC passes of this round (tools/pmc_traffic.sh ->
     profiles/r01_pmc.json; None if not recorded)."""
-    for name in ("r02_pmc.json", "r01_pmc.json"):
+    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             v = d.get(key)
@@ -50,18 +50,22 @@ def _pmc_traffic(key):
     return None
 
 
-def _rocprof_in_step(kernel, grid):
+def _rocprof_in_step(kernel, grid, files=("r03_bench_kernel_summary.txt", "r02_bench_kernel_summary.txt",
+                                           "r01_bench_kernel_summary_final.txt")):
     """Average duration (ms) of `kernel [grid]` INSIDE the training step, from the committed rocprofv3 --kernel-trace
-    summary of this very command (profiles/r02_bench_kernel_summary.txt, tools/prof_r2.sh; r01's as a fallback): the
-    isolated launch timed live by hot_conv_roofline runs alone on the chip, in the step it shares the CUs with the
-    weight-gradient side stream and the audio trunk.  None if no summary is committed."""
+    summary of this very command (profiles/r03_bench_kernel_summary.txt, tools/prof_r3.sh; earlier rounds' as a
+    fallback): the isolated launch timed live by hot_conv_roofline runs alone on the chip, in the step it shares the CUs
+    with the weight-gradient side stream and the audio trunk.  A FROZEN figure (the committed trace was taken on another
+    box of the pool, +-3 % run to run; rocprofv3 cannot wrap the bench from inside): the live figures of the line are
+    ms_per_launch and ms_per_step.  None if no summary is committed."""
     import re
-    for name in ("r02_bench_kernel_summary.txt", "r01_bench_kernel_summary_final.txt"):
+    for name in files:
         try:
             for line in open(os.path.join(ROOT, "profiles", name)):
                 m = re.match(r"\s*[\d.]+\s+[\d.]+\s+(\d+)\s+([\d.]+)\s+\d+\s+\d+\s+\d+\s+(.*?)\s*\[(\d+)\]\s*$", line)
                 if m and m.group(3).startswith(kernel) and int(m.group(4)) == grid:
-                    return dict(ms=float(m.group(2)) / 1e3, launches=int(m.group(1)), source="profiles/" + name)
+                    return dict(ms=float(m.group(2)) / 1e3, launches=int(m.group(1)), source="profiles/" + name,
+                                frozen="committed rocprofv3 trace of this command, not measured by this run")
         except OSError:
             continue
     return None
@@ -78,7 +82,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-cfg5", action="store_true", help="skip the 16-bit leg (BASELINE configs[4])")
     ap.add_argument("--cfg5-batch", type=int, default=CFG5["batch"], help="per-GPU batch of the 16-bit leg (cfg5: 128)")
-    ap.add_argument("--cfg5-steps", type=int, default=5)
+    ap.add_argument("--cfg5-steps", type=int, default=15)
+    ap.add_argument("--cfg5-warmup", type=int, default=3)
     return ap.parse_args()
 
 
@@ -235,6 +240,9 @@ FWD_MB_PER_CLIP_T32_BF16 = 1036.2 / 2 + 3.38           # video bytes halve in bf
 PEAK_BF16_MFMA_TF = 2500.0
 
 
+HOT16_KERNEL = "conv_cl16_s3_kernel<9, 1, 1>"
+
+
 def hot_conv16_roofline(batch, T, dev):
     """Dominant kernel of the 16-bit step: conv_cl16_s3_kernel<9, PRO, EPI> (csrc/conv_cl16_s3.hip) on the layer-1 spatial conv
     Conv3d(64->144,(1,3,3)) (train mode: BatchNorm + ReLU prologue on load, statistics epilogue), timed with HIP events
@@ -282,15 +290,18 @@ def bf16_leg(a, rank, world, local, dev):
     selflabels = torch.randint(0, K, (4096, hc), device=dev, generator=g)
     selected = torch.randint(0, 4096, (B,), device=dev, generator=g)
     torch.cuda.reset_peak_memory_stats(dev)
-    for _ in range(2):
+    for _ in range(max(a.cfg5_warmup, 1)):
         loss = train.train_step(net, opt, video, audio, selflabels, selected, hc)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     steps = a.cfg5_steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # per-step times without host syncs
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
         loss = train.train_step(net, opt, video, audio, selflabels, selected, hc)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -301,14 +312,17 @@ def bf16_leg(a, rank, world, local, dev):
         dt = t.item()
     peak = torch.cuda.max_memory_allocated(dev)
     ms = dt / steps * 1e3
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    ms_median, ms_min = per_step[len(per_step) // 2], per_step[0]
     with torch.no_grad():
-        m(video, audio)
-        torch.cuda.synchronize()
-        tf0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(2):
             m(video, audio)
         torch.cuda.synchronize()
-        fwd_ms = (time.perf_counter() - tf0) / 3 * 1e3
+        tf0 = time.perf_counter()
+        for _ in range(5):
+            m(video, audio)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - tf0) / 5 * 1e3
     hot = hot_conv16_roofline(min(B, 64), T, dev)
     step_tf = 3 * FWD_GFLOP_PER_CLIP_T32 * B / ms
     step_gbs = 3 * FWD_MB_PER_CLIP_T32_BF16 * B / ms
@@ -316,7 +330,9 @@ def bf16_leg(a, rank, world, local, dev):
     del m, net, opt
     return {
         "metric": "clips/sec (video+audio fwd/bwd + loss + SGD), 16-bit MFMA path", "value": world * B * steps / dt,
-        "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": 2, "ms_per_step": ms, "dtype": "bf16",
+        "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": max(a.cfg5_warmup, 1), "ms_per_step": ms,
+        # per-step durations between HIP events on the step's stream (rank 0's): the leg's spread
+        "ms_per_step_median": ms_median, "ms_per_step_min": ms_min, "ms_per_step_max": per_step[-1], "dtype": "bf16",
         "config": {"workload": "cfg5: R(2+1)D-18 in bf16 (fp32 master weights, fp32 BN statistics) + ResNet-9/heads fp32, "
                                "per-GPU bs=%d, 32x112x112 video, 1x129x100 log-mel, K=309, headcount=10" % B,
                    "global_batch": world * B, "parallelism": "dp%d" % world, "loss_last_step": loss_v,
@@ -328,6 +344,13 @@ def bf16_leg(a, rank, world, local, dev):
                      "kernel": "conv_cl16_s3_kernel<9,1,1> (LDS-resident patch) layer1 (1,3,3) 64->144 train forward at bs %d" % min(B, 64),
                      "ms_per_launch": hot["ms"], "mfma_tflops": hot["flop"] / hot["ms"] / 1e9,
                      "mfma_frac": hot["flop"] / hot["ms"] / 1e9 / PEAK_BF16_MFMA_TF,
+                     # the same kernel inside the cfg5 step (full 128 x 32-frame launch; frozen figure, see _rocprof_in_step)
+                     "in_step": (lambda r: None if r is None else dict(
+                         r, achieved=B * T * 56 * 56 * (64 + 144) * 2.0 / r["ms"] / 1e6,
+                         frac=B * T * 56 * 56 * (64 + 144) * 2.0 / r["ms"] / 1e6 / PEAK_HBM_GBS))(
+                         _rocprof_in_step(HOT16_KERNEL, (B * T * 56 * 56 + 127) // 128,
+                                          ("r03_step16_cfg5_kernel_summary.txt", "r02_step16_cfg5_kernel_summary.txt"))
+                         if B == CFG5["batch"] else None),
                      "note": "bf16: this conv's arithmetic intensity (128 FLOP/B) is below the ridge (312): HBM-bound"},
         "step_roofline": {"mfma": {"achieved": step_tf, "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s per GPU",
                                    "frac": step_tf / PEAK_BF16_MFMA_TF},
@@ -367,6 +390,28 @@ def cpu_baseline(batch):
     return dict(value=batch / dt, unit="clips/s", cores=cores, kind="port",
                 sample=f"cfg2-shaped full step (fwd+loss+bwd+SGD) at batch {batch}, 1 warm-up + {n} timed steps, "
                        f"torch {torch.__version__} CPU fp32, {dt:.2f} s/step")
+
+
+def sk_cpu_baseline(iters=40):
+    """The SK half of BASELINE's metric on the host: the oracle's loop (oracle/sk_ref.py <- src/sk_utils.py:400-406, numpy
+    fp64, two matrix-vector products over P per iteration) at the VGG-Sound size, `iters` iterations of the loop itself
+    (the oracle reports the loop's wall time; the power / label steps around it are not counted)."""
+    import numpy as np
+    from oracle import sk_ref
+    N, K = CFG2["N"], CFG2["K"]
+    rng = np.random.default_rng(5)
+    PS = rng.random((N, K)) * 0.5 + 0.5           # the loop's cost does not depend on the values (dense fp64 gemv)
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count()
+    sk_ref.optimize_L_sk(PS, max_iter=2, tol=-1.0)                   # warm-up (allocator, page cache, BLAS threads)
+    info = sk_ref.optimize_L_sk(PS, max_iter=iters, tol=-1.0)[2]     # tol < 0: exactly `iters` iterations
+    per = info["loop_s"] / info["iters"]
+    return dict(value=1.0 / per, unit="SK iterations/s", cores=cores, kind="port",
+                sample=f"oracle/sk_ref.optimize_L_sk loop, N={N}, K={K}, {iters} iterations (numpy {np.__version__} fp64 "
+                       f"gemv, {per * 1e3:.0f} ms/iteration)")
 
 
 def main():
@@ -462,6 +507,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.cpu_batch)
+        if sk is not None:
+            sk["cpu_baseline"] = sk_cpu_baseline()
 
     if rank == 0:
         step_tflops = 3 * FWD_GFLOP_PER_CLIP * B / ms_step          # per GPU, algorithmic

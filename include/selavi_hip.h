@@ -31,6 +31,7 @@ typedef void* slv_stream_t; /* hipStream_t */
 /* ---------------------------------------------------------------- library ------------------ */
 int32_t slv_version(void);                /* ABI version, bumps on any signature change          */
 const char* slv_last_error(void);      /* thread-local, valid until the next failing call      */
+int32_t slv_stale_hip_errors(void);    /* HIP errors found pending at entry (left by other work; reported on stderr, cleared) */
 int slv_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len);
 
 /* ---------------------------------------------------------------- communicator (RCCL over xGMI) -
@@ -197,7 +198,10 @@ int slv_bn_stats_finalize(const float* psum, const float* psq, int nblk, double 
                           float momentum, float eps, float* mean_invstd, float* scale_shift, int C,
                           slv_stream_t stream);
 /* SyncBN in one call on one stream: partials -> fp64 sums (sums_scratch, 2C doubles) -> all-reduce over `comm` ->
- * finalize with count_local * world.  The backward twin folds slv_bn_bwd_sums + all-reduce + slv_bn_bwd_finalize. */
+ * finalize with count_local * world.  The backward twin folds slv_bn_bwd_sums + all-reduce + slv_bn_bwd_finalize.
+ * ASSUMES EQUAL PER-RANK COUNTS (count_global = count_local * world): true for the training step -- the reference's
+ * loader drops the ragged last batch (main.py:94-101 drop_last=True) and every rank feeds the same clip shape; a caller
+ * with ragged per-rank batches must use slv_bn_partials_to_sums + slv_comm_allreduce_f64 (count included) + slv_bn_finalize. */
 int slv_bn_sync_finalize(slv_comm_t comm, const float* psum, const float* psq, int nblk, double count_local,
                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                          float eps, float* mean_invstd, float* scale_shift, int C, double* sums_scratch,
@@ -272,6 +276,10 @@ int slv_heads_ce_total(const float* loss_rows, int64_t n, float scale, float* to
  * with counter (e / 4, offset) under key `seed`; 1.0 iff word >= p * 2^32.  Pure function of (seed, offset, e). */
 int slv_dropout_masks(uint64_t seed, uint64_t offset, float p, float* m1, int64_t n1, float* m2 /* nullable */,
                       int64_t n2, slv_stream_t stream);
+/* The same draw with (seed, offset) = state[0], state[1] read on the DEVICE, followed by state[1] += 1: the form a HIP
+ * graph replays with fresh masks (host scalars are frozen into a captured launch; train.GraphedStep). */
+int slv_dropout_masks_dev(uint64_t* state /* device, 2 words */, float p, float* m1, int64_t n1, float* m2 /* nullable */,
+                          int64_t n2, slv_stream_t stream);
 int slv_heads_linear_bwd_w(const float* dout, const float* x, int shared_x, int hc, const float* mask,
                            float mask_scale, float* dW /* [G][OUT][IN] */, float* dbias /* nullable */,
                            int G, int B, int IN, int OUT, slv_stream_t stream);

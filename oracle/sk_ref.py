@@ -63,6 +63,8 @@ def optimize_L_sk(PS, lamb=20, K_dist=None, max_iter=2000, tol=1e-1, check_every
     c = 1.0 / N
     err, counter = 1e6, 0
     alpha = None
+    import time
+    t_loop = time.perf_counter()                 # (bench.py's cpu_baseline of the SK half times this loop)
     while err > tol and counter < max_iter:      # :400
         alpha = r / (beta.T @ PS).T              # :401
         beta_new = c / (PS @ alpha)              # :402
@@ -70,6 +72,7 @@ def optimize_L_sk(PS, lamb=20, K_dist=None, max_iter=2000, tol=1e-1, check_every
             err = float(np.sum(np.abs(beta.squeeze() / beta_new.squeeze() - 1.0)))
         beta = beta_new
         counter += 1
+    t_loop = time.perf_counter() - t_loop
     PS *= beta                                   # :411
     PS *= alpha.T                                # :412
     newL = np.argmax(PS, 1)                      # :413
@@ -79,7 +82,7 @@ def optimize_L_sk(PS, lamb=20, K_dist=None, max_iter=2000, tol=1e-1, check_every
         sol = np.nansum(np.log(PS[np.arange(N), newL]))   # :418
     cost = -(1.0 / lamb) * sol / N               # :419
     return cost, newL.astype(np.int64), dict(iters=counter, err=err, alpha=alpha.ravel().copy(),
-                                             beta=beta.ravel().copy())
+                                             beta=beta.ravel().copy(), loop_s=t_loop)
 
 
 def optimize_L_sk_sharded(PS, world, lamb=20, K_dist=None, max_iter=2000, tol=1e-1):

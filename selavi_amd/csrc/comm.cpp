@@ -35,11 +35,17 @@ static int load_api(const char* path_hint) {
   std::lock_guard<std::mutex> lk(g_api_mutex);
   if (g_api.handle) return 0;
   void* h = nullptr;
-  const char* tried[4] = {path_hint, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  if (path_hint && path_hint[0]) {
+    // an explicit path is loaded as named (never replaced by a librccl that happens to be in the process already:
+    // PyTorch-ROCm brings one) and must load
+    h = dlopen(path_hint, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(-5, "slv_comm: cannot load the named librccl: %s", dlerror());
+    snprintf(g_api.path, sizeof(g_api.path), "%s", path_hint);
+  }
+  const char* tried[3] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
   // 1. a copy that is already in the process (RTLD_NOLOAD), 2. load by name / path
   for (int pass = 0; pass < 2 && !h; ++pass)
-    for (int i = 0; i < 4 && !h; ++i) {
-      if (!tried[i] || !tried[i][0]) continue;
+    for (int i = 0; i < 3 && !h; ++i) {
       h = dlopen(tried[i], RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
       if (h) snprintf(g_api.path, sizeof(g_api.path), "%s", tried[i]);
     }

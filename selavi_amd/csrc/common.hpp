@@ -15,11 +15,19 @@ inline int fail(int code, const char* fmt, const char* a = "") {
   return code;
 }
 
-// (also drops a stale error another library left in this thread's HIP state: SLV_LAUNCH_CHECK reads hipGetLastError and
-// must only see what THIS entry point's launches produced)
+// An error another library (or an earlier asynchronous launch) left in this thread's HIP state must not be blamed on
+// THIS entry point's launches (SLV_LAUNCH_CHECK reads hipGetLastError), so the entry clears it -- but not silently: the
+// first few are reported on stderr with the entry point that found them, and counted (slv_stale_hip_errors()).
+extern int g_stale_hip_errors;
+inline void note_pending_hip_error(const char* fn) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return;
+  if (g_stale_hip_errors++ < 8)
+    fprintf(stderr, "libselavi_hip: %s found a pending HIP error left by earlier work: %s\n", fn, hipGetErrorString(e));
+}
 #define SLV_CHECK_ARG(cond, msg)                                              \
   do {                                                                        \
-    (void)hipGetLastError();                                                  \
+    ::slv::note_pending_hip_error(__func__);                                  \
     if (!(cond)) return ::slv::fail(-2, "%s: bad argument: " msg, __func__);  \
   } while (0)
 

@@ -416,6 +416,13 @@ __global__ __launch_bounds__(S3_THREADS, 2 * S3_NW / 4 >= 2 ? 2 : 2) void conv_c
 #endif
 }
 
+static size_t s3_lds_bytes(int mt, int prow, int cin_p, bool pro) {
+  const size_t bm = (size_t)mt * 16, kcg = 2;
+  const size_t k_loop = (size_t)prow * kcg * 64 + 2 * bm * kcg * 64 + (pro ? 2 * (size_t)cin_p * 4 : 0);
+  const size_t epi = (size_t)S3_BN * (bm * 2 + 16) + (size_t)(4 + 2 * S3_NW) * bm * 4;
+  return k_loop > epi ? k_loop : epi;
+}
+
 // Does this launch fit the patch kernel?  Stride 1, lattice == input == output positions, every tap within one row /
 // column of the position, the patch (256 + 2W + 2 rows) within the loader's reach and the LDS.
 static bool s3_eligible(const ClConv& g) {
@@ -429,6 +436,9 @@ static bool s3_eligible(const ClConv& g) {
   }
   const int prow = S3_BN + 2 * g.Wi + 2;
   if (prow * 8 > S3_PIT * S3_THREADS) return false;
+  // the LDS budget belongs to the eligibility (the same answer at plan time -- slv_cl16_conv_nblk -- and at launch, for
+  // every tile height and with the prologue table): a launch that does not fit goes to the general kernel
+  if (s3_lds_bytes(9, prow, g.Cin_p, true) > 160 * 1024) return false;
   return true;
 }
 
@@ -436,12 +446,9 @@ template <int MT, int PRO, int EPI>
 static int s3_launch_one(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss,
                          const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq,
                          const ClBnr& bnr, hipStream_t st) {
-  constexpr int BM = MT * 16, KCG = 2;
+  constexpr int BM = MT * 16;
   const int prow = S3_BN + 2 * g.Wi + 2;
-  const size_t k_loop = (size_t)prow * KCG * 64 + 2 * (size_t)BM * KCG * 64 + (PRO ? 2 * (size_t)g.Cin_p * 4 : 0);
-  const size_t epi = (size_t)S3_BN * (BM * 2 + 16) + (size_t)(4 + 2 * S3_NW) * BM * 4;
-  const size_t lds = k_loop > epi ? k_loop : epi;
-  if (lds > 160 * 1024) return fail(-2, "%s: the patch does not fit the LDS", "slv_cl16_conv");
+  const size_t lds = s3_lds_bytes(MT, prow, g.Cin_p, PRO != 0);      // <= 160 KB: s3_eligible checked the largest variant
   static bool attr_set = false;                          // per instantiation; idempotent, so a race is harmless
   if (!attr_set) {
     SLV_HIP(hipFuncSetAttribute((const void*)conv_cl16_s3_kernel<MT, PRO, EPI>,

@@ -155,11 +155,18 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+// state != nullptr: (seed, offset) are read from device memory -- the form a HIP graph can replay with fresh masks (kernel
+// arguments are frozen at capture; dropout_state_advance_kernel, captured behind this launch, bumps the offset)
 __global__ __launch_bounds__(256) void dropout_masks_kernel(unsigned long long seed, unsigned long long offset,
+                                                            const unsigned long long* __restrict__ state,
                                                             unsigned thresh, float* __restrict__ m1, size_t n1,
                                                             float* __restrict__ m2, size_t n2) {
   const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;      // one Philox block = 4 elements per thread
   if (blk * 4 >= n1 + n2) return;
+  if (state) {
+    seed = state[0];
+    offset = state[1];
+  }
   unsigned r[4];
   philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), (unsigned)offset, (unsigned)(offset >> 32), (unsigned)seed,
                 (unsigned)(seed >> 32), r);
@@ -171,6 +178,8 @@ __global__ __launch_bounds__(256) void dropout_masks_kernel(unsigned long long s
     else if (e < n1 + n2) m2[e - n1] = keep;
   }
 }
+
+__global__ void dropout_state_advance_kernel(unsigned long long* state) { state[1] += 1ull; }
 
 // dW[g][n][k] = sum_b dout[g][b][n] * Xm(g)[b][k] ; dbias[g][n] = sum_b dout[g][b][n]
 template <bool MASK>
@@ -397,7 +406,20 @@ int slv_dropout_masks(uint64_t seed, uint64_t offset, float p, float* m1, int64_
   const unsigned thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
   const size_t blocks4 = ((size_t)(n1 + n2) + 3) / 4;
   hipLaunchKernelGGL(dropout_masks_kernel, dim3((unsigned)((blocks4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (unsigned long long)seed, (unsigned long long)offset, thresh, m1, (size_t)n1, m2, (size_t)n2);
+                     (unsigned long long)seed, (unsigned long long)offset, (const unsigned long long*)nullptr, thresh, m1,
+                     (size_t)n1, m2, (size_t)n2);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_dropout_masks_dev(uint64_t* state, float p, float* m1, int64_t n1, float* m2, int64_t n2, slv_stream_t stream) {
+  SLV_CHECK_ARG(state && m1 && n1 > 0 && n2 >= 0 && (m2 || n2 == 0) && p >= 0.f && p < 1.f, "bad argument");
+  const double t = (double)(p * 4294967296.0f);
+  const unsigned thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+  const size_t blocks4 = ((size_t)(n1 + n2) + 3) / 4;
+  hipLaunchKernelGGL(dropout_masks_kernel, dim3((unsigned)((blocks4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     0ull, 0ull, (const unsigned long long*)state, thresh, m1, (size_t)n1, m2, (size_t)n2);
+  hipLaunchKernelGGL(dropout_state_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)state);
   SLV_LAUNCH_CHECK();
   return 0;
 }

@@ -15,6 +15,7 @@
 
 namespace slv {
 thread_local char g_err[512] = {0};
+int g_stale_hip_errors = 0;
 
 struct SkCtrl {       // lives at the head of the workspace (64 bytes)
   int counter;        // iterations executed so far (the reference's _counter)
@@ -505,6 +506,7 @@ extern "C" {
 
 int32_t slv_version(void) { return 1; }
 const char* slv_last_error(void) { return slv::g_err; }
+int32_t slv_stale_hip_errors(void) { return slv::g_stale_hip_errors; }
 
 int slv_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len) {
   int dev = 0;

@@ -73,16 +73,22 @@ class AVModel(nn.Module):             # model.py:169-252
     # ---- SyncBN (main.py:117-118 converts every BN; here it is a switch on the fused BN kernels)
     def set_sync_bn(self, mode, group=None):
         """mode: 'auto' (sync iff torch.distributed is initialised with world_size > 1), True, False."""
+        self.video_network.base.sync_tag, self.audio_network.base.sync_tag = "bn", "bn_audio"
+        sync_audio = None
         if mode is True:
             from .comm import sync_pair
-            sync = sync_pair(group)           # RCCL behind the C ABI when the backend is nccl, else the torch group
+            # RCCL behind the C ABI when the backend is nccl, else the torch group.  The audio trunk issues its exchanges
+            # from its own stream next to the video trunk's: with the native path it gets a communicator of its own
+            # (collectives on one RCCL communicator serialise in issue order, whatever stream they are on)
+            sync_audio = sync_pair(group, "bn_audio" if self.overlap_audio else "bn")
+            sync = sync_pair(group, "bn")
         elif mode == "auto":
-            sync = "auto"
+            sync = sync_audio = "auto"
         else:
             sync = None
         self._sync = sync
         self.video_network.base.sync = sync
-        self.audio_network.base.sync = sync
+        self.audio_network.base.sync = sync_audio
         for h in self._heads():
             h.sync = sync
 

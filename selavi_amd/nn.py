@@ -216,7 +216,7 @@ def _sync_of(mod):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             from .comm import sync_pair
-            return sync_pair(None)
+            return sync_pair(None, getattr(mod, "sync_tag", "bn"))
         return None
     return s
 
@@ -335,6 +335,39 @@ def _dropout_stream():
     return int(v[0]) & 0xFFFFFFFFFFFFFFFF, int(v[1]) & 0xFFFFFFFFFFFFFFFF
 
 
+_DROPOUT_DEV_STATE = {}
+
+
+def dropout_device_state(device, create=False):
+    """[seed, offset] of the dropout Philox in DEVICE memory (int64 x 2) for captured steps: a HIP graph freezes the host
+    scalars of ``slv_dropout_masks`` into the launch, so every replay would reuse the capture-time masks;
+    ``slv_dropout_masks_dev`` reads the pair on the device and advances the offset behind each draw.  Seeded from torch's
+    default CPU generator (``torch.manual_seed`` controls it).  Created OUTSIDE the capture (train.GraphedStep)."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _DROPOUT_DEV_STATE.get(key)
+    if st is None and create:
+        seed, off = _dropout_stream()
+        st = _DROPOUT_DEV_STATE[key] = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed,
+                                                     off - (1 << 64) if off >= (1 << 63) else off],
+                                                    dtype=torch.int64, device=dev)
+    return st
+
+
+def _draw_dropout_masks(p, m1, m2, st):
+    """Both masks in one launch of the library's own Philox (not torch's generator).  Eager: key / offset are host
+    scalars from torch's CPU generator; while the stream is being captured into a graph: the device-resident pair."""
+    n2 = m2.numel() if m2 is not None else 0
+    if torch.cuda.is_current_stream_capturing():
+        state = dropout_device_state(m1.device)
+        if state is None:
+            raise RuntimeError("dropout under graph capture needs nn.dropout_device_state(device, create=True) before "
+                               "the capture (train.GraphedStep does it)")
+        C.slv_dropout_masks_dev(ptr(state), float(p), ptr(m1), m1.numel(), ptr(m2), n2, st)
+    else:
+        C.slv_dropout_masks(*_dropout_stream(), float(p), ptr(m1), m1.numel(), ptr(m2), n2, st)
+
+
 class HeadSpec:
     def __init__(self, heads, hc, single, has_hidden, training, sync, masks=None, grad_sink=None):
         self.heads, self.hc, self.single, self.has_hidden = heads, hc, single, has_hidden
@@ -388,9 +421,9 @@ class HeadsFunction(torch.autograd.Function):
             if train and p > 0:
                 if spec.masks is not None:
                     m1, m2 = spec.masks
-                else:                       # both masks in one launch of the library's own Philox (not torch's generator)
+                else:
                     m1, m2 = f32(G, B, IN), f32(G, B, HID)
-                    C.slv_dropout_masks(*_dropout_stream(), float(p), ptr(m1), m1.numel(), ptr(m2), m2.numel(), st)
+                    _draw_dropout_masks(p, m1, m2, st)
                 msc = 1.0 / (1.0 - p)
             W1 = ops.PtrArray([l.weight for l in lin1])
             h = f32(G, B, HID)
@@ -425,7 +458,7 @@ class HeadsFunction(torch.autograd.Function):
                     m1 = spec.masks[0]
                 else:
                     m1 = f32(G, B, IN)
-                    C.slv_dropout_masks(*_dropout_stream(), float(p), ptr(m1), m1.numel(), 0, 0, st)
+                    _draw_dropout_masks(p, m1, None, st)
                 msc = 1.0 / (1.0 - p)
             W, bb = ops.PtrArray([l.weight for l in lin]), ops.PtrArray([l.bias for l in lin])
             logits = f32(G, B, K)

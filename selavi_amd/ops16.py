@@ -1,4 +1,6 @@
-"""Host side of the 16-bit MFMA path (first kernel: csrc/conv_cl16.hip).  Experimental, opt-in, forward only.
+"""Host side of the 16-bit MFMA path (csrc/conv_cl16*.hip, train_cl16.hip, wgrad_cl16*.hip): eval forward
+(``Conv16`` / infer16.py) AND training (``plan_for`` / ``conv_fwd`` / ``conv_dgrad`` / ``conv_wgrad`` / BatchNorm kernels, the
+backend ``engine.Ctx.ops`` of ``AVModel.set_precision("bf16")``).  Opt-in: every bit-exactness claim stays with fp32.
 
 Activations are bf16 channels-last ``[N, T, H, W, Cp]`` torch tensors (Cp = channels rounded up to 32, padding
 channels zero); weights are re-laid-out once per layer (``Conv16.from_weight``).  The epilogue applies a per-channel

@@ -19,21 +19,41 @@ import torch.distributed as dist
 _ALIGN = 64          # floats: every gradient view starts on a 256-byte boundary
 
 
+_SIDE_GROUPS = {}
+
+
+def _side_group(backend):
+    """The second process group the default group's buckets travel on (one per process, created collectively once)."""
+    g = _SIDE_GROUPS.get(backend)
+    if g is None:
+        g = _SIDE_GROUPS[backend] = dist.new_group(ranks=list(range(dist.get_world_size())), backend=backend)
+    return g
+
+
 class GradSink:
     """Flat gradient buffers per autograd node + their asynchronous all-reduce."""
 
     def __init__(self, group=None, own_group=None):
-        """own_group (default on, SELAVI_DP_OWN_GROUP=0 switches it off): the buckets travel on a process group of
-        their own -- a second RCCL communicator and stream.  Collectives on one communicator serialise, and the
-        SyncBN exchanges of the layers still running backward (tiny, on the critical path) would otherwise queue
-        behind layer4's 100 MB bucket."""
+        """The buckets travel on a communicator and a stream of their OWN: collectives on one communicator serialise,
+        and the SyncBN exchanges of the layers still running backward (tiny, on the critical path) would otherwise
+        queue behind layer4's 100 MB bucket.
+
+        * native path (comm.NativeComm applies: backend nccl, or SELAVI_NATIVE_COMM=force): the library's own RCCL
+          communicator "grad" (``slv_comm_allreduce_f32(average=1)``) on a dedicated HIP stream -- together with the
+          SyncBN communicators ONE RCCL runtime serves the step, torch.distributed only bootstraps;
+        * otherwise a torch process group: for the default group a second one is created (``own_group``, default on,
+          SELAVI_DP_OWN_GROUP=0 switches it off; ``dist.new_group`` is collective over ALL ranks of the default group,
+          so it is only done there), cached per rank set; a caller that passes a sub-group passes the group the
+          buckets shall use."""
         import os
+        from .comm import NativeComm
         if own_group is None:
             own_group = os.environ.get("SELAVI_DP_OWN_GROUP", "1") == "1"
         backend = dist.get_backend(group)
-        if own_group and dist.get_world_size(group) > 1:
-            ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
-            group = dist.new_group(ranks=ranks, backend=backend)       # collective over the default group's ranks
+        self.native = NativeComm.for_group(group, "grad")
+        self.stream = None
+        if self.native is None and own_group and dist.get_world_size(group) > 1 and (group is None or group is dist.group.WORLD):
+            group = _side_group(backend)
         self.group = group
         self.world = dist.get_world_size(group)
         self.avg = backend == "nccl"              # RCCL averages in the collective; gloo: sum, then one scale per buffer
@@ -80,6 +100,20 @@ class GradSink:
         self.reduce([flat])
 
     def reduce(self, tensors):
+        if self.native is not None:               # RCCL behind the C ABI, on the buckets' own stream
+            cur = torch.cuda.current_stream()
+            if self.stream is None:
+                self.stream = torch.cuda.Stream()
+            self.stream.wait_stream(cur)          # the node's kernels have written the views
+            with torch.cuda.stream(self.stream):
+                for t in tensors:
+                    self.native.allreduce_avg_f32_(t)
+                    t.record_stream(self.stream)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            self.pending.append((ev, None))
+            torch.autograd.Variable._execution_engine.queue_callback(self.finalize)
+            return
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         for t in tensors:
             self.pending.append((dist.all_reduce(t, op=op, group=self.group, async_op=True), t))
@@ -90,6 +124,9 @@ class GradSink:
     def finalize(self):
         pending, self.pending = self.pending, []
         for work, t in pending:
+            if t is None:                         # native path: an event on the buckets' stream
+                torch.cuda.current_stream().wait_event(work)
+                continue
             work.wait()
             if not self.avg:
                 t.mul_(1.0 / self.world)

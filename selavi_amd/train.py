@@ -98,6 +98,8 @@ class GraphedStep:
                 train_step(model, optimizer, video, audio, selflabels, selected, headcount)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        from . import nn as snn
+        snn.dropout_device_state(video.device, create=True)     # Dropout(0.3) draws fresh masks on every replay
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):

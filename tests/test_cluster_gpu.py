@@ -121,7 +121,9 @@ def _ddp_worker(rank, world, port, ret, wrap=False, precision="fp32"):
             import hashlib
             hs = {k: hashlib.sha256(v.detach().cpu().numpy().tobytes()).hexdigest()[:16]
                   for k, v in sorted(m.state_dict().items())}
-            ret[rank] = (first, float(loss), hs)
+            from selavi_amd.comm import NativeComm
+            ret[rank] = (first, float(loss), hs, len(NativeComm._cache))      # communicators behind the C ABI (0 on gloo)
+            NativeComm.destroy_all()
             return
         sd = m.state_dict()
         ret[rank] = (float(loss), {k: sd[k].flatten()[:32].cpu().numpy().copy() for k in (

@@ -553,6 +553,49 @@ def test_graphed_step_replays_bit_identically_to_eager():
 
 
 @pytest.mark.gpu
+def test_graphed_step_draws_fresh_dropout_masks_on_every_replay():
+    """Dropout(0.3) under train.GraphedStep: the Philox key / offset live in device memory (slv_dropout_masks_dev) and the
+    captured launch advances the offset, so replays draw DIFFERENT masks (host scalars would be frozen into the graph).
+    (a) the captured draw against the numpy Philox oracle at offset, offset + 1, offset + 2; (b) a captured step with
+    lr = 0 (weights frozen, same batch): the loss still changes from replay to replay -- only the masks can do that."""
+    from oracle.philox_ref import dropout_mask
+    from selavi_amd import model as smodel, nn as snn, optim, train
+    from selavi_amd._lib import C, ptr, stream
+    state = torch.tensor([31, 5], dtype=torch.int64, device="cuda")
+    m1, m2 = torch.empty(4099, device="cuda"), torch.empty(513, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=side):
+        C.slv_dropout_masks_dev(ptr(state), 0.3, ptr(m1), m1.numel(), ptr(m2), m2.numel(), stream())
+    for k in range(3):
+        gr.replay()
+        torch.cuda.synchronize()
+        want = dropout_mask(31, 5 + k, 0.3, 4099 + 513)
+        np.testing.assert_array_equal(m1.cpu().numpy(), want[:4099])
+        np.testing.assert_array_equal(m2.cpu().numpy(), want[4099:])
+    assert state.tolist() == [31, 8]
+
+    torch.manual_seed(7)
+    m = smodel.load_model(use_mlp=True, num_classes=12, norm_feat=False, headcount=2)
+    portable_init_(m, seed=31)
+    m = m.cuda().train()                            # Dropout(0.3) as the reference has it (model.py:79,85)
+    opt = optim.SGD(m.parameters(), lr=0.0, momentum=0.9, weight_decay=0.0)
+    video = portable_fill_(torch.empty(4, 3, 4, 32, 32), 5).cuda()
+    audio = portable_fill_(torch.empty(4, 1, 40, 36), 6).cuda()
+    sl = torch.from_numpy((np.arange(64 * 2).reshape(64, 2) * 7919 % 12).astype(np.int64)).cuda()
+    sel = torch.tensor([3, 17, 42, 63]).cuda()
+    gs = train.GraphedStep(m, opt, video, audio, sl, sel, 2, warmup=2)
+    st0 = snn.dropout_device_state(video.device).clone()
+    losses = []
+    for _ in range(4):
+        losses.append(float(gs.replay()))
+    torch.cuda.synchronize()
+    assert len(set(losses)) == 4, losses            # frozen masks would repeat one value
+    assert (snn.dropout_device_state(video.device) - st0).tolist() == [0, 4]
+
+
+@pytest.mark.gpu
 def test_dropout_masks_are_philox_bit_exact_and_loss_total():
     """slv_dropout_masks against the numpy Philox4x32-10 oracle (bit-exact, both masks of one launch, ragged sizes),
     and the in-library loss mean against the per-row losses."""

@@ -1,0 +1,161 @@
+"""The native RCCL paths of the library at WORLD > 1 without a multi-GPU box.
+
+RCCL refuses two ranks on one device, and the test boxes have one GPU.  ``tests/rccl_double/`` is a test double of
+librccl (the seven symbols csrc/comm.cpp resolves, implemented over a file mapped by both ranks, sums in rank order);
+``SELAVI_RCCL_LIB`` hands it to ``slv_comm_load`` and ``SELAVI_NATIVE_COMM=force`` routes SyncBN, the sharded
+Sinkhorn-Knopp loop and the gradient buckets through ``slv_comm_*`` although torch.distributed (bootstrap only) is gloo.
+Covered with two ranks: the communicator's collectives, ``slv_bn_sync_finalize`` / ``slv_bn_bwd_sync_finalize`` against
+the torch.distributed path (bit-identical), ``slv_sk_iterate_sharded`` against the executed reference's goldens
+(bit-exact), and the whole data-parallel step (SyncBN from the main stream AND the audio side stream, weight-gradient
+side streams, autograd's thread, the gradient buckets on their own communicator) against the gloo rig (bit-identical).
+Reference behaviour: /root/reference/main.py:117-118,156-160, utils.py:133-146, src/sk_utils.py:287-348."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DOUBLE_SRC = os.path.join(HERE, "rccl_double", "rccl_double.cpp")
+DOUBLE_LIB = os.path.join(HERE, "rccl_double", "librccl_double.so")
+
+
+def build_double(force=False):
+    """g++ (host code only) against the HIP runtime and RCCL's header; in-tree so that it travels to the GPU box."""
+    if force or not os.path.exists(DOUBLE_LIB) or os.path.getmtime(DOUBLE_LIB) < os.path.getmtime(DOUBLE_SRC):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__",
+                               "-I/opt/rocm/include", DOUBLE_SRC, "-o", DOUBLE_LIB,
+                               "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
+    return DOUBLE_LIB
+
+
+@pytest.fixture
+def double_env(monkeypatch):
+    monkeypatch.setenv("SELAVI_RCCL_LIB", build_double())
+    monkeypatch.setenv("SELAVI_NATIVE_COMM", "force")
+    monkeypatch.setenv("SLV_DBL_TIMEOUT_S", "90")
+
+
+def _collectives_worker(rank, world, port, ret):
+    import ctypes
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from selavi_amd import ops
+        from selavi_amd._lib import C, ptr, stream
+        from selavi_amd.comm import NativeComm
+        comm = NativeComm.for_group(None)
+        assert comm is not None and comm.world == world and comm.rank == rank and "rccl_double" in comm.library()
+        comm2 = NativeComm.for_group(None, "grad")            # a second communicator of the same runtime
+        assert comm2 is not None and comm2.h.value != comm.h.value
+        # ---- collectives: sums in rank order, identical on both ranks
+        g = torch.Generator(device="cuda").manual_seed(100 + rank)
+        checks = {}
+        for dt, n in ((torch.float64, 619), (torch.float32, 3_000_001), (torch.int64, 4097)):
+            if dt == torch.int64:
+                mine = torch.randint(-1000, 1000, (n,), device="cuda", generator=g)
+            else:
+                mine = torch.randn(n, device="cuda", generator=g, dtype=dt)
+            both = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)                       # gloo: the test's own ground truth
+            want = both[0].clone()
+            for r in range(1, world):
+                want = want + both[r]
+            got = mine.clone()
+            comm.allreduce_(got)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), dt
+            checks[str(dt)] = got[:8].cpu().numpy().copy()
+            if dt == torch.float32:
+                avg = mine.clone()
+                comm2.allreduce_avg_f32_(avg)
+                torch.cuda.synchronize()
+                assert torch.equal(avg, want * 0.5)
+        mine = torch.arange(1000, device="cuda", dtype=torch.int32) + 10_000 * rank
+        recv = torch.empty(world * 1000, device="cuda", dtype=torch.int32)
+        C.slv_comm_allgather(comm.h, ptr(mine), ptr(recv), 4000, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(recv, torch.cat([torch.arange(1000, device="cuda", dtype=torch.int32) + 10_000 * r for r in range(world)]))
+        b = torch.full((777,), float(rank + 1), device="cuda")
+        C.slv_comm_broadcast(comm.h, ptr(b), 777 * 4, 1, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(b, torch.full((777,), 2.0, device="cuda"))
+        # ---- SyncBN in one call (slv_bn_sync_finalize / slv_bn_bwd_sync_finalize) == the torch.distributed path
+        Cc, nblk = 45, 37
+        ps, pq = torch.randn(Cc, nblk, device="cuda", generator=g), torch.rand(Cc, nblk, device="cuda", generator=g) * 9
+        gh = torch.Generator(device="cuda").manual_seed(7)   # parameters are replicated
+        gamma, beta = torch.rand(Cc, device="cuda", generator=gh) + 0.5, torch.randn(Cc, device="cuda", generator=gh)
+        outs = []
+        for where in (comm, None):                            # None: the default (gloo) group through dist.all_reduce
+            rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+            mi, ss = ops.bn_train_finalize(ps, pq, 1000.0, gamma, beta, rm, rv, 0.1, 1e-5, sync=(where, world))
+            torch.cuda.synchronize()
+            outs.append(torch.cat([mi.flatten(), ss.flatten(), rm, rv]))
+        assert torch.equal(outs[0], outs[1])
+        part = torch.randn(Cc, 11, 2, device="cuda", generator=g)
+        o2 = []
+        for where in (comm, None):
+            dg, db = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+            b5 = ops.bn_bwd_finish(part, None, 11, 1000.0, mi, gamma, ss, None, None, (where, world), dg, db, None, None)[0]
+            torch.cuda.synchronize()
+            o2.append(torch.cat([b5.flatten(), dg, db]))
+        assert torch.equal(o2[0], o2[1])
+        ret[rank] = (checks, outs[0].cpu().numpy().copy(), o2[0].cpu().numpy().copy())
+        NativeComm.destroy_all()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_native_collectives_and_one_call_syncbn(double_env):
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_collectives_worker, args=(2, 27100 + os.getpid() % 400, ret), nprocs=2, join=True)
+    for k in ret[0][0]:
+        np.testing.assert_array_equal(ret[0][0][k], ret[1][0][k])
+    np.testing.assert_array_equal(ret[0][1], ret[1][1])          # the ranks finalise the same statistics, bit for bit
+    np.testing.assert_array_equal(ret[0][2], ret[1][2])
+
+
+@pytest.mark.parametrize("name", ["sk_ave_peaked", "sk_gauss_per_head", "sk_vggsound_full"])
+def test_two_rank_sk_iterate_sharded_matches_reference_golden(double_env, golden_dir, name):
+    """slv_sk_iterate_sharded (pass, local reduce, all-reduce of K+1 doubles over the library's communicator, update:
+    one host call per batch of iterations) on two ranks: labels bit-exact against the executed reference."""
+    import torch.multiprocessing as mp
+    from tests.test_sk_gpu import _digest, _sharded_worker
+    ret = mp.Manager().dict()
+    mp.spawn(_sharded_worker, args=(2, 27500 + os.getpid() % 400, name, golden_dir, ret, True), nprocs=2, join=True)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    L = np.concatenate([ret[0][1], ret[1][1]])
+    assert ret[0][4] and ret[1][4], "the solve did not go through the native communicator"
+    assert ret[0][2] == ret[1][2] == int(g["iters"])
+    assert _digest(L) == bytes(g["digest"]).decode()
+    assert ret[0][0] == ret[1][0] and abs(ret[0][0] - float(g["cost"])) <= 1e-9 * abs(float(g["cost"]))
+    np.testing.assert_array_equal(ret[0][3], ret[1][3])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_rank_native_step_is_bit_identical_to_the_gloo_rig(monkeypatch, precision):
+    """parallel.DataParallel + SyncBN for three steps on two ranks, once with every exchange on the library's own
+    communicators (SyncBN from the main and the audio stream, buckets through slv_comm_allreduce_f32(average)), once
+    with torch.distributed/gloo carrying them: every parameter and buffer bit-identical, between the ranks and between
+    the two transports (both add the same two addends; x0.5 is exact)."""
+    import torch.multiprocessing as mp
+    from tests.test_cluster_gpu import _ddp_worker
+    ret_gloo, ret_nat = mp.Manager().dict(), mp.Manager().dict()
+    mp.spawn(_ddp_worker, args=(2, 26100 + os.getpid() % 300, ret_gloo, "native", precision), nprocs=2, join=True)
+    monkeypatch.setenv("SELAVI_RCCL_LIB", build_double())
+    monkeypatch.setenv("SELAVI_NATIVE_COMM", "force")
+    monkeypatch.setenv("SLV_DBL_TIMEOUT_S", "90")
+    mp.spawn(_ddp_worker, args=(2, 26500 + os.getpid() % 300, ret_nat, "native", precision), nprocs=2, join=True)
+    assert ret_nat[0][3] >= 3 and ret_nat[0][3] == ret_nat[1][3], "native communicators were expected (bn, bn_audio, grad)"
+    assert ret_gloo[0][3] == 0
+    diverged = [k for k in ret_nat[0][2] if ret_nat[0][2][k] != ret_nat[1][2][k]]
+    assert not diverged, f"ranks diverged in {len(diverged)} tensors: {diverged[:6]}"
+    differs = [k for k in ret_nat[0][2] if ret_nat[0][2][k] != ret_gloo[0][2][k]]
+    assert not differs, f"{len(differs)} of {len(ret_nat[0][2])} tensors differ from the gloo rig: {differs[:6]}"
+    assert ret_nat[0][0] == ret_gloo[0][0] and ret_nat[0][1] == ret_gloo[0][1]

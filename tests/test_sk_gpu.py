@@ -111,7 +111,7 @@ def test_roundtrip_properties_full_size():
 
 # ---- row-sharded solve with the HIP kernels on TWO ranks (two processes sharing the one GPU of the test box, gloo for
 # the K+1 fp64 all-reduce): the N_local < N_global form of slv_sk_begin / slv_sk_pass_reduce / slv_sk_update / slv_sk_labels
-def _sharded_worker(rank, world, port, name, golden_dir, ret):
+def _sharded_worker(rank, world, port, name, golden_dir, ret, want_native=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -131,7 +131,11 @@ def _sharded_worker(rank, world, port, name, golden_dir, ret):
         cost, L = sk_utils.optimize_L_sk_gpu(args, shard, head, None, group=dist.group.WORLD, N_global=N)
         info = sk_utils.optimize_L_sk_gpu.last_info
         assert sk_utils._HIP.name == "hip"
-        ret[rank] = (cost, L.cpu().numpy().copy(), info["iters"], info["alpha"].cpu().numpy().copy())
+        from selavi_amd.comm import NativeComm
+        native = len(NativeComm._cache) > 0       # tests/test_native_comm_gpu.py: the library's own communicator carried it
+        assert native == bool(want_native)
+        ret[rank] = (cost, L.cpu().numpy().copy(), info["iters"], info["alpha"].cpu().numpy().copy(), native)
+        NativeComm.destroy_all()
     finally:
         dist.destroy_process_group()
 
