@@ -139,6 +139,14 @@ int cl16_s3_try(const ClConv& g, int mt, const void* x, const void* wl, void* y,
                 const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr,
                 hipStream_t st);
 
+// csrc/conv_cl16_tr.hip: stride-1 temporal (3,1,1) convs of the narrow layers, weights resident in registers, one wave
+// per workgroup walking 32-pixel columns frame by frame
+bool cl16_tr_applies(const ClConv& g);
+int cl16_tr_columns(const ClConv& g);            // statistics partials per channel when this kernel takes the launch
+bool cl16_tr_forward(const ClConv& g);
+int cl16_tr_try(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, const float* scale_shift,
+                const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr, hipStream_t st);
+
 // csrc/wgrad_cl16_s3.hip: weight gradient of the stride-1 (1,3,3) convs with a rolling activation patch
 struct ClWgrad3 {
   int N, T, H, W, Cin_p, Cin, Cout_p;

@@ -610,7 +610,11 @@ def test_backward_data_epilogue_forms_the_batchnorm_backward_sums(case):
     gamma = (torch.rand(Cin, generator=g) + 0.5).cuda()
     dx0 = ops16.conv_dgrad(plan, dy, wt)
     dx, part = ops16.conv_dgrad(plan, dy, wt, bnr=(xsrc, ss, mi))
-    assert torch.equal(dx, dx0) and part.shape == (Cin, plan.bnr_slots, 2)
+    # (dx0 may come from another kernel than the fused launch -- the column kernel of csrc/conv_cl16_tr.hip has no fused
+    #  sums -- so the two agree up to the order of the fp32 additions: a last-place flip of a few bf16 values)
+    dd = (dx.float() - dx0.float()).abs()
+    assert float(dd.max()) <= 2.0 ** -7 * float(dx0.float().abs().max()) and float((dd > 0).float().mean()) < 0.02
+    assert part.shape == (Cin, plan.bnr_slots, 2)
     outs = []
     for p_ in (None, part):
         dg, db = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
