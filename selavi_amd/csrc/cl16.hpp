@@ -132,6 +132,40 @@ __device__ __forceinline__ void wave_tile_stats(const unsigned char* rows, int o
   }
 }
 
+// The same statistics ACCUMULATED IN REGISTERS (persistent kernels: csrc/conv_cl16_tr.hip, conv_cl16_sr.hip): accS[i] +=
+// column sums (meaningful in lanes fk == 0: channel i * 16 + fr), accQ[i] += sums of squares (lanes fk == fr >> 2).
+// All transpose reads first, then 2 MT independent MFMAs (distinct results: they pipeline), then a branch-free pick of the
+// Gram diagonal.
+template <int MT>
+__device__ __forceinline__ void wave_rows32_stats_acc(const unsigned char* rows, int orow, int lane, float* accS, float* accQ) {
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const int fr = lane & 15, fk = lane >> 4;
+  const unsigned char* src = rows + (4 * fk + (fr >> 2)) * orow + 8 * (fr & 3);
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+  bf16x8 yv[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32 + 16 * orow));
+    const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    yv[i] = __builtin_bit_cast(bf16x8, tmp);
+  }
+  f32x4 sm[MT], q[MT];
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    sm[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yv[i], z, 0, 0, 0);
+    q[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yv[i], yv[i], z, 0, 0, 0);
+  }
+  const bool e1 = fr & 1, e2 = fr & 2;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const float qa = e1 ? q[i][1] : q[i][0], qb = e1 ? q[i][3] : q[i][2];
+    accS[i] += sm[i][0];
+    accQ[i] += e2 ? qb : qa;
+  }
+}
+
 // csrc/conv_cl16_s3.hip: the LDS-resident-patch kernel for stride-1 (1,3,3) convs (forward and backward data)
 bool cl16_s3_applies(const ClConv& g);
 int cl16_s3_positions();
@@ -145,6 +179,13 @@ bool cl16_tr_applies(const ClConv& g);
 int cl16_tr_columns(const ClConv& g);            // statistics partials per channel when this kernel takes the launch
 bool cl16_tr_forward(const ClConv& g);
 int cl16_tr_try(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, const float* scale_shift,
+                const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr, hipStream_t st);
+
+// csrc/conv_cl16_sr.hip: the layer-1 spatial conv 64 -> 144 (1,3,3), weights resident in registers, three MFMA waves + one
+// data-movement wave per workgroup, persistent over 8 x 8-pixel tiles
+bool cl16_sr_applies(const ClConv& g);
+int cl16_sr_slots(const ClConv& g);              // statistics partials per channel (= workgroups) when it takes the launch
+int cl16_sr_try(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, const float* scale_shift,
                 const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr, hipStream_t st);
 
 // csrc/wgrad_cl16_s3.hip: weight gradient of the stride-1 (1,3,3) convs with a rolling activation patch

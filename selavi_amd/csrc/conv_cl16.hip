@@ -398,6 +398,10 @@ static int cl16_launch(const slv::ClConv& g, int mt, const void* x, const void* 
                        const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq,
                        const slv::ClBnr& bnr, slv_stream_t stream, const char* fn) {
   using namespace slv;
+  {   // layer-1 spatial conv 64 -> 144: weights resident in registers, data-movement wave (csrc/conv_cl16_sr.hip)
+    const int r = cl16_sr_try(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, bnr, (hipStream_t)stream);
+    if (r != 0) return r < 0 ? r : 0;
+  }
   {   // stride-1 (3,1,1) convs of the narrow layers: weights resident in registers (csrc/conv_cl16_tr.hip)
     const int r = cl16_tr_try(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, bnr, (hipStream_t)stream);
     if (r != 0) return r < 0 ? r : 0;
@@ -506,6 +510,7 @@ int slv_cl16_conv(const int32_t* clconv, int mt, const void* x_bf16, const void*
 int32_t slv_cl16_conv_nblk(const int32_t* clconv) {
   slv::ClConv g;
   memcpy(&g, clconv, sizeof(g));
+  if (slv::cl16_sr_applies(g)) return slv::cl16_sr_slots(g);      // one partial per persistent workgroup
   if (slv::cl16_tr_applies(g) && slv::cl16_tr_forward(g)) return slv::cl16_tr_columns(g);      // one partial per 32-pixel column
   const long long P = (long long)g.N * g.Lt * g.Lh * g.Lw;
   const int bn = slv::cl16_s3_applies(g) ? slv::cl16_s3_positions() : slv::CL_BN;     // positions per tile of the kernel that runs

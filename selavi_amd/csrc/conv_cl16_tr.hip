@@ -261,22 +261,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
         for (int i = lane * 16; i < TR_PX * orow; i += 64 * 16)
           if (i / orow >= valid) *(u32x4*)(ost + i) = (u32x4){0u, 0u, 0u, 0u};
       }
-      typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-      const unsigned char* srcs = ost + (4 * fk + (fr >> 2)) * orow + 8 * (fr & 3);
-      const bf16x8 ones = __builtin_bit_cast(bf16x8, (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(srcs + i * 32));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(srcs + i * 32 + 16 * orow));
-        const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const bf16x8 yv = __builtin_bit_cast(bf16x8, tmp);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yv, z, 0, 0, 0);
-        const f32x4 q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yv, yv, z, 0, 0, 0);
-        const int e = fr & 3;
-        accS[i] += sm[0];                             // (meaningful in lanes fk == 0: channel i * 16 + fr)
-        accQ[i] += e == 0 ? q[0] : e == 1 ? q[1] : e == 2 ? q[2] : q[3];      // (lanes fk == fr >> 2)
-      }
+      wave_rows32_stats_acc<MT>(ost, orow, lane, accS, accQ);
     }
     {
       const unsigned obase = (cc.pos0 + (unsigned)cc.t * HW) * out_row + opiece * 16u;
@@ -334,6 +319,13 @@ bool cl16_tr_applies(const ClConv& g) {
     seen |= 1 << (d + 1);
   }
   if (seen != 7) return false;
+  {
+    static const int only_kc = []() {                 // diagnostic: restrict the kernel to one channel-chunk count
+      const char* e = getenv("SELAVI_CL16_TR_ONLY_KC");
+      return e ? atoi(e) : 0;
+    }();
+    if (only_kc && g.Cin_p / 32 != only_kc) return false;
+  }
   if ((g.Mrows & 15) || !tr_shape(g.Mrows / 16, g.Cin_p / 32) || g.Cout_p > 160) return false;
   if ((long long)g.N * g.Ti * g.Hi * g.Wi * (g.Cin_p > g.Cout_p ? g.Cin_p : g.Cout_p) * 2 >= 0xFFFFFFF0LL) return false;
   return true;
