@@ -166,6 +166,40 @@ __device__ __forceinline__ void wave_rows32_stats_acc(const unsigned char* rows,
   }
 }
 
+// The same with the MFMAs as inline asm on VGPR operands / results (csrc/conv_cl16_sr.hip): a kernel that pins 216
+// registers of resident weights in the accumulator file through "a" operands must not let the compiler claim AGPRs for a
+// builtin MFMA's result -- the allocator then evicts the resident fragments to scratch and copies them back per MFMA.
+// (asm: the wait between the MFMAs and the first VALU read of their results is explicit.)
+template <int MT>
+__device__ __forceinline__ void wave_rows32_stats_acc_asm(const unsigned char* rows, int orow, int lane, float* accS, float* accQ) {
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const int fr = lane & 15, fk = lane >> 4;
+  const unsigned char* src = rows + (4 * fk + (fr >> 2)) * orow + 8 * (fr & 3);
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+  bf16x8 yv[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32 + 16 * orow));
+    const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    yv[i] = __builtin_bit_cast(bf16x8, tmp);
+  }
+  f32x4 sm[MT], q[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(sm[i]) : "v"(ones), "v"(yv[i]));
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=v"(q[i]) : "v"(yv[i]));
+  }
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // 8-pass XDL result -> VALU read
+  const bool e1 = fr & 1, e2 = fr & 2;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const float qa = e1 ? q[i][1] : q[i][0], qb = e1 ? q[i][3] : q[i][2];
+    accS[i] += sm[i][0];
+    accQ[i] += e2 ? qb : qa;
+  }
+}
+
 // csrc/conv_cl16_s3.hip: the LDS-resident-patch kernel for stride-1 (1,3,3) convs (forward and backward data)
 bool cl16_s3_applies(const ClConv& g);
 int cl16_s3_positions();

@@ -10,11 +10,14 @@
 //     9 taps x 2 chunks x 3 tiles = 54 A fragments = 216 registers, in the accumulator half of the register file
 //     (asm MFMAs with an "a" operand) -- for the kernel's lifetime.  Per tile: 72 ds_read_b128 of the input patch
 //     (one base register, every tap / chunk / fragment an immediate offset), 216 MFMAs, the bf16 tile into LDS;
+//     the tile's epilogue rides BETWEEN the MFMAs of the next tile (two accumulator sets): round to bf16 through a
+//     private LDS stage, BatchNorm statistics of the rounded values as per-lane running sums, the 96-byte segment of
+//     every pixel's channel row to memory (wave 2: 128 bytes, with the 16 padding channels);
 //   * wave 3 is the data-movement wave: it fetches the 10 x 10-pixel patch of the NEXT tile (16-byte pieces, each lane
-//     a fixed channel piece, so BatchNorm + ReLU coefficients stay in registers), applies BatchNorm + ReLU once per
-//     element, writes zeros for the halo outside the image (no per-tap masks anywhere), stores the PREVIOUS tile's
-//     output in whole 320-byte channel rows, and takes the BatchNorm statistics of that tile on its own matrix core;
-//   * patch and output tile are double buffered in LDS (one workgroup per CU: 92 KB of the 160), ONE barrier per tile.
+//     a fixed channel piece, so BatchNorm + ReLU coefficients stay in registers; border handling from four precomputed
+//     bit masks), applies BatchNorm + ReLU once per element and writes zeros for the halo outside the image (no per-tap
+//     masks anywhere);
+//   * the patch is double buffered in LDS (one workgroup per CU: 79 KB of the 160), ONE barrier per tile.
 // LDS patch: pixel (py, px) of the 10 x 10 patch at ((py * 16 + px) * 160) bytes -- pitch 16, rows of 128 + 32 bytes:
 // found by enumeration to be conflict-free for ds_read_b128 fragments whose 16 positions are 2 tile rows x 8 columns,
 // for every tap shift, without any XOR (so taps stay immediates).
@@ -28,21 +31,39 @@ constexpr int SR_PW = SR_T + 2;                       // patch edge
 constexpr int SR_PITCH = 16, SR_ROWB = 160;           // LDS patch geometry (see above)
 constexpr int SR_PATCH = SR_PW * SR_PITCH * SR_ROWB;  // 25 600 B
 constexpr int SR_CIN = 64, SR_COUT = 144, SR_COUTP = 160;
-constexpr int SR_OROW = SR_COUTP * 2 + 16;            // bytes per pixel row of the output stage
-constexpr int SR_OST = SR_T * SR_T * SR_OROW;         // 21 504 B
-constexpr int SR_LDS = 2 * SR_PATCH + 2 * SR_OST;
+constexpr int SR_OROW = 128 + 16;                     // bytes per pixel row of a wave's output stage (<= 64 channels)
+constexpr int SR_OST = SR_T * SR_T * SR_OROW;         // 9 216 B per MFMA wave
+constexpr int SR_LDS = 2 * SR_PATCH + 3 * SR_OST;
 constexpr int SR_NIT = (SR_PW * SR_PW + 7) / 8;       // 13 load instructions cover the patch (8 rows of 8 pieces each)
 
+#ifndef SLV_SR_ABL
+#define SLV_SR_ABL 0      // timing ablations (results wrong): 1 no MFMAs (a VALU xor keeps the operands alive), 2 no global
+#endif                    // patch loads, 3 no output stores, 4 no epilogue at all, 5 no sched_barrier between MFMA groups
 __device__ __forceinline__ void sr_mfma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+#if SLV_SR_ABL == 1
+  acc[0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, b)[0]);
+  asm volatile("" :: "a"(a));
+#else
   asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+#endif
 }
 __device__ __forceinline__ void sr_mfma0(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+#if SLV_SR_ABL == 1
+  acc = (f32x4){__builtin_bit_cast(float, __builtin_bit_cast(u32x4, b)[0]), 0.f, 0.f, 0.f};
+  asm volatile("" :: "a"(a));
+#else
   asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(a), "v"(b));
+#endif
 }
 __device__ __forceinline__ void sr_barrier() {        // LDS traffic of this wave complete, then the workgroup barrier;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // global loads / stores stay in flight across it
   __builtin_amdgcn_s_barrier();
 }
+
+struct SrTile {
+  int y0, x0;
+  unsigned fpos;                                      // position of the frame's pixel (0, 0)
+};
 
 // PRO 1: rows are read as relu(x * s + h).  EPI 1: per-channel sum / sum of squares of the rounded outputs, one partial
 // per workgroup: stat_sum / stat_sq [Cout][gridDim.x].
@@ -55,11 +76,20 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
                                                              ClConv g, int ntiles, int th, int tw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const patch = lds;                   // [2][SR_PATCH]
-  unsigned char* const ost = lds + 2 * SR_PATCH;      // [2][64][SR_OROW]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, fk = lane >> 4;
   const int nt = blockIdx.x < (unsigned)ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int H = g.Hi, W = g.Wi;
+  auto tile_of = [&](int k) __attribute__((always_inline)) {
+    SrTile t;
+    const int id = blockIdx.x + k * gridDim.x;
+    const int per = th * tw, f = id / per, rem = id - f * per, ty = rem / tw;
+    t.y0 = ty * SR_T;
+    t.x0 = (rem - ty * tw) * SR_T;
+    t.fpos = (unsigned)f * H * W;
+    return t;
+  };
 
   if (wave < 3) {
     // ======================================================================== MFMA waves
@@ -71,50 +101,136 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
 #pragma unroll
         for (int i = 0; i < 3; ++i)
           A[t][c][i] = *(const bf16x8*)(wl + ((size_t)((t * 2 + c) * SR_COUT + (wave * 3 + i) * 16 + fr) * 32 + fk * 8));
+    const unsigned Ptot = (unsigned)g.N * g.Ti * H * W;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)(Ptot * (SR_COUTP * 2u)), 0x00020000);
+    // the wave's own output stage: 64 pixels x its channel segment (wave 2: its 48 channels + the 16 padding channels
+    // 144..159, which stay zero), written and read by this wave only
+    unsigned char* const ost = lds + 2 * SR_PATCH + wave * SR_OST;
+    for (int i = lane * 16; i < SR_OST; i += 64 * 16) *(u32x4*)(ost + i) = (u32x4){0u, 0u, 0u, 0u};
+    const int npc = wave == 2 ? 8 : 6;                // 16-byte pieces of the segment per pixel
+    const int ppi = 64 / npc;                         // pixels one store instruction covers (10 or 8)
+    const int spiece = lane % npc, spx = lane / npc;
+    const bool sact = lane < ppi * npc;
     // lane part of a fragment read: position fr of fragment nn is tile pixel (2 nn + (fr >> 3), fr & 7)
     const int lbase = (((fr >> 3) * SR_PITCH + (fr & 7)) * SR_ROWB) + fk * 16;
-    const int obase = fr * SR_OROW + ((wave * 3) * 16 + fk * 4) * 2;
-    sr_barrier();                                     // patch 0 is in LDS
-    for (int n = 0; n < nt; ++n) {
-      const unsigned char* src = patch + (n & 1) * SR_PATCH + lbase;
-      f32x4 acc[3][4];
+    const int obase = fr * SR_OROW + fk * 8;
+    // BatchNorm statistics: per-lane running sums of the ROUNDED outputs and their squares (channel (3 wave + i) * 16 +
+    // 4 fk + r, over this lane's pixel column fr), reduced over the 16 lanes of a DPP row once, at the end of the kernel
+    float stS[3][4], stQ[3][4];
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          bf16x8 b[4];
+      for (int r = 0; r < 4; ++r) stS[i][r] = stQ[i][r] = 0.f;
+    // The epilogue of tile n - 1 (round to bf16 through the wave's LDS stage, statistics, 7-8 stores) is cut into 30
+    // ITEMS that ride between the MFMAs of tile n, one item after every 7th MFMA (two accumulator sets, the loop
+    // unrolled by two).  An in-order wave cannot issue past a waiting MFMA: work placed BEHIND a block of MFMAs runs with
+    // the matrix pipe idle (measured: the epilogue behind the block, or in 18 slices behind the 18 MFMA groups, cost a
+    // quarter of the tile time either way), work placed BETWEEN MFMAs rides in the 12 idle issue cycles of each.
+    u32x4 carry = {0u, 0u, 0u, 0u};
+    unsigned carry_off = 0xFFFFFFF0u;
+    constexpr int SR_ITEMS = 28, SR_EVERY = 7;
+    auto drain_item = [&](int it, f32x4 (&pv)[3][4], const SrTile& tl) __attribute__((always_inline)) {
+      if (it < 12) {                                  // items 0-11: one accumulator tile -> bf16 -> LDS stage
+        const int i = it >> 2, nn = it & 3;
+        const unsigned lo = pack_bf2(pv[i][nn][0], pv[i][nn][1]), hi = pack_bf2(pv[i][nn][2], pv[i][nn][3]);
+        *(uint2*)(ost + obase + nn * 16 * SR_OROW + i * 32) = make_uint2(lo, hi);
+        if constexpr (EPI == 1) {
+          float v[4] = {bf_lo(lo), bf_hi(lo), bf_lo(hi), bf_hi(hi)};
+          if (tl.y0 + SR_T > H || tl.x0 + SR_T > W) { // ragged tile (rare): pixels outside the image count as zero
+            const int pp = nn * 16 + fr;
+            if (tl.y0 + (pp >> 3) >= H || tl.x0 + (pp & 7) >= W) v[0] = v[1] = v[2] = v[3] = 0.f;
+          }
 #pragma unroll
-          for (int nn = 0; nn < 4; ++nn)
-            b[nn] = *(const bf16x8*)(src + ((2 * nn + t / 3) * SR_PITCH + (t % 3)) * SR_ROWB + c * 64);
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int nn = 0; nn < 4; ++nn) {
-              if (t == 0 && c == 0) sr_mfma0(acc[i][nn], A[t][c][i], b[nn]);
-              else sr_mfma(acc[i][nn], A[t][c][i], b[nn]);
-            }
+          for (int r = 0; r < 4; ++r) {
+            stS[i][r] += v[r];
+            stQ[i][r] = __builtin_fmaf(v[r], v[r], stQ[i][r]);
+          }
         }
+      } else if (it < SR_ITEMS) {                     // items 12-27: store k = read its pieces, then issue it
+        const int k = (it - 12) >> 1;
+        if (k * ppi < SR_T * SR_T) {                  // (out-of-range offsets drop the store: no branches per lane)
+          if (((it - 12) & 1) == 0) {
+            const int p = k * ppi + spx;
+            const int yy = tl.y0 + (p >> 3), xx = tl.x0 + (p & 7);
+            const bool ok = sact && p < SR_T * SR_T && yy < H && xx < W;
+            carry = *(const u32x4*)(ost + (p < SR_T * SR_T ? p : 0) * SR_OROW + spiece * 16);
+            carry_off = (ok && SLV_SR_ABL != 3)
+                            ? (tl.fpos + (unsigned)(yy * W + xx)) * (SR_COUTP * 2u) + (unsigned)(wave * 96 + spiece * 16)
+                            : 0xFFFFFFF0u;
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(carry, ry, carry_off, 0, 0);
+          }
+        }
+      }
+    };
+    auto tile_step = [&](int n, f32x4 (&acc)[3][4], f32x4 (&pv)[3][4]) __attribute__((always_inline)) {
+      const unsigned char* src = patch + (n & 1) * SR_PATCH + lbase;
+      const bool drain = n > 0 && SLV_SR_ABL != 4;
+      const SrTile tl = tile_of(n > 0 ? n - 1 : 0);
+      // 18 MFMA groups (tap, chunk); the fragments of group g + 1 are requested before the MFMAs of group g (two
+      // register sets), so that no MFMA waits for an LDS read
+      bf16x8 b[2][4];
+      auto read_b = [&](int gi, bf16x8* to) __attribute__((always_inline)) {
+        const int t = gi >> 1, c = gi & 1;
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+          to[nn] = *(const bf16x8*)(src + ((2 * nn + t / 3) * SR_PITCH + (t % 3)) * SR_ROWB + c * 64);
+      };
+      read_b(0, b[0]);
+#pragma unroll
+      for (int gi = 0; gi < 18; ++gi) {
+        if (gi + 1 < 18) read_b(gi + 1, b[(gi + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int nn = 0; nn < 4; ++nn) {
+            if (gi == 0) sr_mfma0(acc[i][nn], A[gi >> 1][gi & 1][i], b[gi & 1][nn]);
+            else sr_mfma(acc[i][nn], A[gi >> 1][gi & 1][i], b[gi & 1][nn]);
+            const int m = gi * 12 + i * 4 + nn;       // MFMA index within the tile
+            if (m % SR_EVERY == SR_EVERY - 1 && m / SR_EVERY < SR_ITEMS) {
+              if (drain) drain_item(m / SR_EVERY, pv, tl);
+              if (SLV_SR_ABL != 5) __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+      }
+      sr_barrier();                                   // the patch buffer is free: the data-movement wave may refill it
+    };
+    f32x4 accA[3][4], accB[3][4];
+    sr_barrier();                                     // patch 0 is in LDS
+    for (int n = 0; n < nt; n += 2) {
+      tile_step(n, accA, accB);
+      if (n + 1 < nt) tile_step(n + 1, accB, accA);
+    }
+    if (nt > 0) {                                     // the last tile's epilogue
       asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // 8-pass XDL result -> VALU read
-      unsigned char* dst = ost + (n & 1) * SR_OST + obase;
+      const SrTile tl = tile_of(nt - 1);
+      if ((nt - 1) & 1) {
+#pragma unroll
+        for (int it = 0; it < SR_ITEMS; ++it) drain_item(it, accB, tl);
+      } else {
+#pragma unroll
+        for (int it = 0; it < SR_ITEMS; ++it) drain_item(it, accA, tl);
+      }
+    }
+    if constexpr (EPI == 1) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn) {
-          const unsigned lo = pack_bf2(acc[i][nn][0], acc[i][nn][1]), hi = pack_bf2(acc[i][nn][2], acc[i][nn][3]);
-          *(uint2*)(dst + nn * 16 * SR_OROW + i * 32) = make_uint2(lo, hi);
+        for (int r = 0; r < 4; ++r) {
+          const float a = row16_sum(stS[i][r]), q = row16_sum(stQ[i][r]);
+          const int c = (wave * 3 + i) * 16 + fk * 4 + r;
+          if (fr == 0) {
+            stat_sum[(size_t)c * gridDim.x + blockIdx.x] = a;
+            stat_sq[(size_t)c * gridDim.x + blockIdx.x] = q;
+          }
         }
-      sr_barrier();
     }
     return;
   }
 
   // ========================================================================== data-movement wave
-  const int T = g.Ti, H = g.Hi, W = g.Wi;
-  const unsigned Ptot = (unsigned)g.N * T * H * W;
+  const unsigned Ptot = (unsigned)g.N * g.Ti * H * W;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(Ptot * (SR_CIN * 2u)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)(Ptot * (SR_COUTP * 2u)), 0x00020000);
-  // zero both output stages once: the padding channels 144..159 of every row stay zero
-  for (int i = lane * 16; i < 2 * SR_OST; i += 64 * 16) *(u32x4*)(ost + i) = (u32x4){0u, 0u, 0u, 0u};
   // this lane's pieces of a patch: piece = lane & 7 of patch rows lr, lr + 8, ...
   const int piece = lane & 7, lr = lane >> 3;
   float ps[8], ph[8];
@@ -126,101 +242,72 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
       ph[e] = c < g.Cin ? in_ss[g.Cin + c] : 0.f;
     }
   }
-  int pyx[SR_NIT];                                    // py | px << 8 | live << 16 of the lane's patch rows
+  // per piece (loop invariants): memory offset relative to the patch origin, LDS offset, and which borders it sits on
+  unsigned goff[SR_NIT];
+  int loff[SR_NIT];
+  unsigned mtop = 0, mbot = 0, mleft = 0, mright = 0, mlive = 0;
 #pragma unroll
   for (int i = 0; i < SR_NIT; ++i) {
     const int r = lr + 8 * i, py = r / SR_PW, px = r - py * SR_PW;
-    pyx[i] = py | (px << 8) | ((r < SR_PW * SR_PW) << 16);
+    const bool live = r < SR_PW * SR_PW;
+    goff[i] = (unsigned)((py * W + px) * (SR_CIN * 2) + piece * 16);
+    loff[i] = (live ? py * SR_PITCH + px : SR_PW * SR_PITCH - 1) * SR_ROWB + piece * 16;   // (rows past the patch: an unused pitch column)
+    mlive |= (unsigned)live << i;
+    mtop |= (unsigned)(py == 0) << i;
+    mbot |= (unsigned)(py == SR_PW - 1) << i;
+    mleft |= (unsigned)(px == 0) << i;
+    mright |= (unsigned)(px == SR_PW - 1) << i;
   }
-  struct Tile {
-    int y0, x0;
-    unsigned fpos;                                    // position of the frame's pixel (0, 0)
-  };
-  auto tile_of = [&](int k) __attribute__((always_inline)) {
-    Tile t;
-    const int id = blockIdx.x + k * gridDim.x;
-    const int per = th * tw, f = id / per, rem = id - f * per, ty = rem / tw;
-    t.y0 = ty * SR_T;
-    t.x0 = (rem - ty * tw) * SR_T;
-    t.fpos = (unsigned)f * H * W;
-    if (k >= nt) t.y0 = 1 << 20;                      // (past the last tile: every row fails its bounds test, per lane)
-    return t;
-  };
   u32x4 st[SR_NIT];
   unsigned stv = 0;
-  auto load_patch = [&](const Tile& t) __attribute__((always_inline)) {
-    stv = 0;
+  auto load_patch = [&](int k) __attribute__((always_inline)) {
+    const SrTile t = tile_of(k);
+    // pieces inside the image.  Whole tiles (the common case): a piece is outside iff it lies on a patch border that
+    // coincides with an image border -- four precomputed bit masks; ragged tiles and steps past the last tile: per piece
+    const bool whole = k < nt && t.y0 + SR_T <= H && t.x0 + SR_T <= W;
+    unsigned valid;
+    if (whole) {
+      valid = mlive & ~((t.y0 == 0 ? mtop : 0u) | (t.y0 + SR_T == H ? mbot : 0u) | (t.x0 == 0 ? mleft : 0u) |
+                        (t.x0 + SR_T == W ? mright : 0u));
+    } else {
+      valid = 0;
+      if (k < nt) {
 #pragma unroll
-    for (int i = 0; i < SR_NIT; ++i) {
-      const int py = pyx[i] & 255, px = (pyx[i] >> 8) & 255;
-      const int yy = t.y0 - 1 + py, xx = t.x0 - 1 + px;
-      const bool ok = (pyx[i] >> 16) && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-      stv |= (unsigned)ok << i;
-      const unsigned off = (t.fpos + (unsigned)(yy * W + xx)) * (SR_CIN * 2u) + piece * 16u;
-      st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : 0xFFFFFFF0u, 0, 0));
+        for (int i = 0; i < SR_NIT; ++i) {
+          const int r = lr + 8 * i, py = r / SR_PW, px = r - py * SR_PW;
+          const bool ok = (unsigned)(t.y0 - 1 + py) < (unsigned)H && (unsigned)(t.x0 - 1 + px) < (unsigned)W;
+          valid |= (unsigned)ok << i;
+        }
+        valid &= mlive;
+      }
     }
+    stv = valid;
+    const unsigned base = (t.fpos + (unsigned)((t.y0 - 1) * W + (t.x0 - 1))) * (SR_CIN * 2u);      // (wraps; used by valid pieces only)
+#pragma unroll
+    for (int i = 0; i < SR_NIT; ++i)
+      st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (((valid >> i) & 1) && SLV_SR_ABL != 2) ? base + goff[i] : 0xFFFFFFF0u, 0, 0));
   };
   auto store_patch = [&](int buf) __attribute__((always_inline)) {
-    unsigned char* dst = patch + buf * SR_PATCH + piece * 16;
+    unsigned char* dst = patch + buf * SR_PATCH;
 #pragma unroll
     for (int i = 0; i < SR_NIT; ++i) {
-      const int py = pyx[i] & 255, px = (pyx[i] >> 8) & 255;
       u32x4 v = st[i];
       if constexpr (PRO == 1) {                       // zero padding AFTER the affine: the halo outside the image is zero
         const u32x4 a = affine_relu8(v, ps, ph);
         v = ((stv >> i) & 1) ? a : (u32x4){0u, 0u, 0u, 0u};
       }
-      // (rows past the patch, i == SR_NIT - 1 only, land in the unused pitch columns 10..15 of patch row 9 + ...: keep them inside)
-      const int row = (pyx[i] >> 16) ? py * SR_PITCH + px : SR_PW * SR_PITCH - 1;
-      *(u32x4*)(dst + row * SR_ROWB) = v;
-    }
-  };
-  float accS[9], accQ[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) accS[i] = accQ[i] = 0.f;
-  // output rows: 20 pieces of 16 bytes; 60 lanes cover 3 pixels per instruction
-  const int opiece = lane % 20, olr = lane / 20;
-  auto store_out = [&](const Tile& t, int buf) __attribute__((always_inline)) {
-    const unsigned char* src = ost + buf * SR_OST;
-    if constexpr (EPI == 1) {
-      if (t.y0 + SR_T > H || t.x0 + SR_T > W) {       // ragged tile: pixels outside the image count as zero
-        for (int i = lane; i < SR_T * SR_T * (SR_COUT / 8); i += 64) {
-          const int p = i / (SR_COUT / 8), q = i - p * (SR_COUT / 8);
-          if (t.y0 + (p >> 3) >= H || t.x0 + (p & 7) >= W) *(u32x4*)(ost + buf * SR_OST + p * SR_OROW + q * 16) = (u32x4){0u, 0u, 0u, 0u};
-        }
-      }
-      wave_rows32_stats_acc<9>(src, SR_OROW, lane, accS, accQ);
-      wave_rows32_stats_acc<9>(src + 32 * SR_OROW, SR_OROW, lane, accS, accQ);
-    }
-#pragma unroll 2
-    for (int p0 = 0; p0 < SR_T * SR_T; p0 += 3) {     // (out-of-range offsets drop the store: no branches)
-      const int p = p0 + olr;
-      const int yy = t.y0 + (p >> 3), xx = t.x0 + (p & 7);
-      const bool ok = lane < 60 && p < SR_T * SR_T && yy < H && xx < W;
-      const u32x4 v = *(const u32x4*)(src + (p < SR_T * SR_T ? p : 0) * SR_OROW + opiece * 16);
-      const unsigned off = (t.fpos + (unsigned)(yy * W + xx)) * (SR_COUTP * 2u) + opiece * 16u;
-      __builtin_amdgcn_raw_buffer_store_b128(v, ry, ok ? off : 0xFFFFFFF0u, 0, 0);
+      *(u32x4*)(dst + loff[i]) = v;
     }
   };
   // ---- pipeline head: patch 0 into buffer 0, patch 1 requested
-  load_patch(tile_of(0));
+  load_patch(0);
   store_patch(0);
-  load_patch(tile_of(1));
+  load_patch(1);
   sr_barrier();
   for (int n = 0; n < nt; ++n) {
     store_patch((n + 1) & 1);                         // patch n + 1 (requested a step ago) -> the buffer tile n - 1 used
-    load_patch(tile_of(n + 2));                       // patch n + 2: in flight across the barrier
-    if (n >= 1) store_out(tile_of(n - 1), (n - 1) & 1);      // tile n - 1: statistics + 320-byte rows to memory
+    load_patch(n + 2);                                // patch n + 2: in flight across the barrier
     sr_barrier();
-  }
-  if (nt > 0) store_out(tile_of(nt - 1), (nt - 1) & 1);
-  if constexpr (EPI == 1) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int c = i * 16 + fr;
-      if (fk == 0) stat_sum[(size_t)c * gridDim.x + blockIdx.x] = accS[i];
-      if (fk == (fr >> 2)) stat_sq[(size_t)c * gridDim.x + blockIdx.x] = accQ[i];
-    }
   }
 }
 
