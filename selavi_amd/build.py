@@ -14,8 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libselavi_hip.so")
 STAMP = LIB + ".stamp"
+# -pragma-unroll-threshold: the register-resident conv kernels (csrc/conv_cl16_s[rd].hip) are one straight line of
+# 216-360 MFMAs per tile with compile-time fragment indices; past the default size limit "#pragma unroll" is silently
+# dropped and the resident weight array lands in scratch memory
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-Wno-unused-result", "-Wno-comment"]
+         "-Wno-unused-result", "-Wno-comment", "-mllvm", "-pragma-unroll-threshold=262144"]
 
 
 def _digest():

@@ -222,6 +222,12 @@ int cl16_sr_slots(const ClConv& g);              // statistics partials per chan
 int cl16_sr_try(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, const float* scale_shift,
                 const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr, hipStream_t st);
 
+// csrc/conv_cl16_sd.hip: backward data of the layer-1 spatial conv (160 stored channels -> 64, flipped taps), weights
+// resident in registers, four MFMA waves per workgroup, patches by LDS-DMA
+bool cl16_sd_applies(const ClConv& g);
+int cl16_sd_try(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, const float* scale_shift,
+                const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr, hipStream_t st);
+
 // csrc/wgrad_cl16_s3.hip: weight gradient of the stride-1 (1,3,3) convs with a rolling activation patch
 struct ClWgrad3 {
   int N, T, H, W, Cin_p, Cin, Cout_p;

@@ -402,6 +402,10 @@ static int cl16_launch(const slv::ClConv& g, int mt, const void* x, const void* 
     const int r = cl16_sr_try(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, bnr, (hipStream_t)stream);
     if (r != 0) return r < 0 ? r : 0;
   }
+  {   // backward data of the layer-1 spatial conv: weights resident in registers, LDS-DMA patches (csrc/conv_cl16_sd.hip)
+    const int r = cl16_sd_try(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, bnr, (hipStream_t)stream);
+    if (r != 0) return r < 0 ? r : 0;
+  }
   {   // stride-1 (3,1,1) convs of the narrow layers: weights resident in registers (csrc/conv_cl16_tr.hip)
     const int r = cl16_tr_try(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, bnr, (hipStream_t)stream);
     if (r != 0) return r < 0 ? r : 0;

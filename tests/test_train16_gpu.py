@@ -27,6 +27,10 @@ CASES = [  # N, Cin, T, H, W, Cout, k, stride, pad        the conv families of t
     # across tile / column borders
     (6, 64, 2, 60, 60, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     (3, 144, 3, 120, 120, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    # backward data of the layer-1 spatial conv on the register-resident kernel (csrc/conv_cl16_sd.hip: whole 8 x 8 tiles;
+    # 54 tiles, and 1 024 tiles = two steps per workgroup)
+    (3, 64, 3, 16, 24, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (8, 64, 8, 32, 32, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
 ]
 
 

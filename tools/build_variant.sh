@@ -6,7 +6,7 @@ name=$1; shift
 files=(); while [ "$1" != "--" ]; do files+=("$1"); shift; done; shift
 mkdir -p /tmp/variant_$name
 for f in "${files[@]}"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result "$@" -c selavi_amd/csrc/$f -o /tmp/variant_$name/$f.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -mllvm -pragma-unroll-threshold=262144 "$@" -c selavi_amd/csrc/$f -o /tmp/variant_$name/$f.o &
 done
 wait
 objs=$(ls selavi_amd/build/*.o)
