@@ -17,7 +17,8 @@
 //     4 c + (q ^ (px & 3)) -- found by enumeration to be conflict-free for ds_read_b128 fragments of 2 tile rows x 8
 //     columns at every tap shift.  A DMA writes LDS linearly, so the XOR sits on the SOURCE address; the reader keeps
 //     three lane bases (one per tap column) and every tap row / chunk / fragment is an immediate offset;
-//   * the tile's epilogue (bf16 through a wave-private LDS stage, 64-byte half rows to memory) follows its barrier.
+//   * the epilogue of tile n - 1 (bf16 through a wave-private LDS stage, 64-byte half rows to memory) rides between
+//     the MFMAs of tile n (two accumulator sets).
 // An in-order wave cannot issue past a waiting MFMA, so everything that is not an MFMA is cut into items of <= 3-4
 // instructions and placed one per MFMA slot.
 #include "cl16.hpp"
@@ -57,11 +58,12 @@ struct SdTile {
   int live;
 };
 
-template <int DUMMY>
+// RES 1: y = acc + res (the gradient that arrives over the residual connection; res may be y itself), one rounding
+template <int RES>
 __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned short* __restrict__ x,
                                                              const unsigned short* __restrict__ wl,
-                                                             unsigned short* __restrict__ y, ClConv g, int ntiles, int th,
-                                                             int tw) {
+                                                             unsigned short* y, const unsigned short* res, ClConv g,
+                                                             int ntiles, int th, int tw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -147,12 +149,39 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned sho
     const int p = k * 16 + spx;
     soff[k] = (unsigned)(((p >> 3) * W + (p & 7)) * (SD_COUT * 2) + hf * 64 + spiece * 16);
   }
+  constexpr int SD_ITEMS = 16 + 8 * RES;
   u32x4 carry = {0u, 0u, 0u, 0u};
-  // drain items of the previous tile: 0-7 one accumulator tile each -> bf16 -> stage; 8-15: store k = read, then issue
-  auto drain_item = [&](int it, f32x4 (&pv)[2][4], const SdTile& tl) __attribute__((always_inline)) {   // (in order)
+  // the addend in accumulator layout: pixel nn * 16 + fr, channels (hf * 2 + i) * 16 + 4 fk .. + 3 (8 bytes)
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? res : y), 0, (int)(Ptot * (SD_COUT * 2u)), 0x00020000);
+  unsigned aoff[4];
+#pragma unroll
+  for (int nn = 0; nn < 4; ++nn) {
+    const int p = nn * 16 + fr;
+    aoff[nn] = (unsigned)(((p >> 3) * W + (p & 7)) * (SD_COUT * 2) + hf * 64 + fk * 8);
+  }
+  uint2 radd[8];
+  // items of the previous tile's epilogue, in order: [RES: 0-7 request the addend of accumulator tile it;] then one
+  // accumulator tile each (+ addend) -> bf16 -> stage; then store k = read its pieces, issue it
+  auto drain_item = [&](int it0, f32x4 (&pv)[2][4], const SdTile& tl) __attribute__((always_inline)) {
+    int it = it0;
+    if constexpr (RES == 1) {
+      if (it < 8) {
+        const unsigned tb = (tl.fpos + (unsigned)(tl.y0 * W + tl.x0)) * (SD_COUT * 2u);
+        radd[it] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rr, tl.live ? tb + aoff[it & 3] + (unsigned)((it >> 2) * 32) : 0xFFFFFFF0u, 0, 0));
+        return;
+      }
+      it -= 8;
+    }
     if (it < 8) {
       const int i = it >> 2, nn = it & 3;
-      const unsigned lo = pack_bf2(pv[i][nn][0], pv[i][nn][1]), hi = pack_bf2(pv[i][nn][2], pv[i][nn][3]);
+      float v[4] = {pv[i][nn][0], pv[i][nn][1], pv[i][nn][2], pv[i][nn][3]};
+      if constexpr (RES == 1) {
+        v[0] += bf_lo(radd[it].x);
+        v[1] += bf_hi(radd[it].x);
+        v[2] += bf_lo(radd[it].y);
+        v[3] += bf_hi(radd[it].y);
+      }
+      const unsigned lo = pack_bf2(v[0], v[1]), hi = pack_bf2(v[2], v[3]);
       *(uint2*)(ost + obase + nn * 16 * SD_OROW + i * 32) = make_uint2(lo, hi);
     } else if (it < 16) {
       const int k = (it - 8) >> 1;
@@ -165,10 +194,11 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned sho
     }
   };
   // One tile: 45 MFMA groups (tap, chunk) of 8 MFMAs (2 channel tiles x 4 fragments).  Slot = the place behind one MFMA:
-  // even slots of a group request the fragments of the NEXT group, odd slots of the first four groups carry the DMA of
-  // the next patch.  The tile's epilogue follows its barrier (one accumulator set: the wave has no registers for two).
-  auto tile_step = [&](int n, f32x4 (&acc)[2][4]) __attribute__((always_inline)) {
+  // even slots of a group request the fragments of the NEXT group, odd slots carry one item each -- first the DMA of the
+  // next patch (groups 0-3), then the previous tile's epilogue (two accumulator sets; groups 5-8).
+  auto tile_step = [&](int n, f32x4 (&acc)[2][4], f32x4 (&pv)[2][4], bool drain) __attribute__((always_inline)) {
     const unsigned char* src = pbuf + (n & 1) * SD_PATCH;
+    const SdTile tprev = tile_of(n > 0 ? n - 1 : 0);
     dma_begin(tile_of(n + 1));
     bf16x8 b[2][4];
     auto read_b = [&](int gi, int nn, bf16x8* to) __attribute__((always_inline)) {
@@ -194,16 +224,13 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned sho
           } else {
             const int fs = gi * 4 + (ph >> 1);         // free-slot index within the tile
             if (fs < SD_DMA) dma_item(fs, (n + 1) & 1);
+            else if (fs >= 20 && fs < 20 + 2 * SD_ITEMS && ((fs - 20) & 1) == 0 && drain) drain_item((fs - 20) >> 1, pv, tprev);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the next patch has landed (and the last tile's stores)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the next patch has landed (and this wave's stores)
     __builtin_amdgcn_s_barrier();
-    asm volatile("s_nop 7" ::: "memory");             // (8-pass XDL result -> VALU read: the wait above covers most of it)
-    const SdTile tl = tile_of(n);
-#pragma unroll
-    for (int it = 0; it < 16; ++it) drain_item(it, acc, tl);
   };
   // ---- pipeline head: patch 0 by DMA, wait, barrier
   dma_begin(tile_of(0));
@@ -211,8 +238,22 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned sho
   for (int j = 0; j < SD_DMA; ++j) dma_item(j, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  f32x4 acc[2][4];
-  for (int n = 0; n < nst; ++n) tile_step(n, acc);
+  f32x4 accA[2][4], accB[2][4];
+  for (int n = 0; n < nst; n += 2) {
+    tile_step(n, accA, accB, n > 0);
+    if (n + 1 < nst) tile_step(n + 1, accB, accA, true);
+  }
+  if (nst > 0) {                                      // the last tile's epilogue
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    const SdTile tl = tile_of(nst - 1);
+    if ((nst - 1) & 1) {
+#pragma unroll
+      for (int it = 0; it < SD_ITEMS; ++it) drain_item(it, accB, tl);
+    } else {
+#pragma unroll
+      for (int it = 0; it < SD_ITEMS; ++it) drain_item(it, accA, tl);
+    }
+  }
 }
 
 static bool sd_enabled() {
@@ -239,15 +280,16 @@ bool cl16_sd_applies(const ClConv& g) {
   return true;
 }
 
-// returns 1 when the launch was taken, 0 when it does not apply (prologue / statistics / affine / addend / fused sums:
-// the tile kernel), < 0 on error
+// returns 1 when the launch was taken, 0 when it does not apply (prologue / statistics / affine / fused sums: the tile
+// kernel), < 0 on error
 int cl16_sd_try(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, const float* scale_shift,
                 const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr, hipStream_t st) {
   if (!cl16_sd_applies(g)) return 0;
-  if (in_ss || scale_shift || res || relu || stat_sum || bnr.part) return 0;
+  if (in_ss || scale_shift || relu || stat_sum || bnr.part) return 0;
   static bool attr_set = false;
   if (!attr_set) {
     SLV_HIP(hipFuncSetAttribute((const void*)conv_cl16_sd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SLV_HIP(hipFuncSetAttribute((const void*)conv_cl16_sd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const int th = g.Hi / SD_T, tw = g.Wi / SD_T, ntiles = g.N * g.Ti * th * tw;
@@ -256,8 +298,13 @@ int cl16_sd_try(const ClConv& g, const void* x, const void* wl, void* y, const f
     const char* e = getenv("SELAVI_CL16_SD_BLOCKS");
     return e ? atoi(e) : 256;
   }();
-  hipLaunchKernelGGL((conv_cl16_sd_kernel<0>), dim3(npairs < blocks ? npairs : blocks), dim3(256), SD_LDS, st,
-                     (const unsigned short*)x, (const unsigned short*)wl, (unsigned short*)y, g, ntiles, th, tw);
+  const dim3 grid(npairs < blocks ? npairs : blocks);
+  if (res)
+    hipLaunchKernelGGL((conv_cl16_sd_kernel<1>), grid, dim3(256), SD_LDS, st, (const unsigned short*)x,
+                       (const unsigned short*)wl, (unsigned short*)y, (const unsigned short*)res, g, ntiles, th, tw);
+  else
+    hipLaunchKernelGGL((conv_cl16_sd_kernel<0>), grid, dim3(256), SD_LDS, st, (const unsigned short*)x,
+                       (const unsigned short*)wl, (unsigned short*)y, (const unsigned short*)nullptr, g, ntiles, th, tw);
   const int rc = launch_check("slv_cl16_conv");
   return rc ? rc : 1;
 }
