@@ -83,7 +83,7 @@ def parse():
     ap.add_argument("--no-cfg5", action="store_true", help="skip the 16-bit leg (BASELINE configs[4])")
     ap.add_argument("--cfg5-batch", type=int, default=CFG5["batch"], help="per-GPU batch of the 16-bit leg (cfg5: 128)")
     ap.add_argument("--cfg5-steps", type=int, default=15)
-    ap.add_argument("--cfg5-warmup", type=int, default=3)
+    ap.add_argument("--cfg5-warmup", type=int, default=5)
     return ap.parse_args()
 
 
@@ -240,13 +240,14 @@ FWD_MB_PER_CLIP_T32_BF16 = 1036.2 / 2 + 3.38           # video bytes halve in bf
 PEAK_BF16_MFMA_TF = 2500.0
 
 
-HOT16_KERNEL = "conv_cl16_s3_kernel<9, 1, 1>"
+HOT16_KERNEL = "conv_cl16_sr_kernel<1, 1>"      # csrc/conv_cl16_sr.hip: one persistent workgroup per CU (grid 256)
 
 
 def hot_conv16_roofline(batch, T, dev):
-    """Dominant kernel of the 16-bit step: conv_cl16_s3_kernel<9, PRO, EPI> (csrc/conv_cl16_s3.hip) on the layer-1 spatial conv
-    Conv3d(64->144,(1,3,3)) (train mode: BatchNorm + ReLU prologue on load, statistics epilogue), timed with HIP events
-    on its stream.  Algorithmic bytes = input + output in bf16 (64 + 144 channels x 2 B per position)."""
+    """Dominant kernel of the 16-bit forward: conv_cl16_sr_kernel<PRO, EPI> (csrc/conv_cl16_sr.hip: weights resident in
+    registers, three MFMA waves + a data-movement wave per CU) on the layer-1 spatial conv Conv3d(64->144,(1,3,3)) (train
+    mode: BatchNorm + ReLU prologue on load, statistics epilogue), timed with HIP events on its stream.  Algorithmic
+    bytes = input + output in bf16 (64 + 144 channels x 2 B per position)."""
     from selavi_amd import ops16
 
     class Conv:
@@ -312,7 +313,9 @@ def bf16_leg(a, rank, world, local, dev):
         dt = t.item()
     peak = torch.cuda.max_memory_allocated(dev)
     ms = dt / steps * 1e3
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    raw_steps = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    print("cfg5 leg per-step ms: " + " ".join("%.1f" % v for v in raw_steps), file=sys.stderr)
+    per_step = sorted(raw_steps)
     ms_median, ms_min = per_step[len(per_step) // 2], per_step[0]
     with torch.no_grad():
         for _ in range(2):
@@ -332,7 +335,11 @@ def bf16_leg(a, rank, world, local, dev):
         "metric": "clips/sec (video+audio fwd/bwd + loss + SGD), 16-bit MFMA path", "value": world * B * steps / dt,
         "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": max(a.cfg5_warmup, 1), "ms_per_step": ms,
         # per-step durations between HIP events on the step's stream (rank 0's): the leg's spread
-        "ms_per_step_median": ms_median, "ms_per_step_min": ms_min, "ms_per_step_max": per_step[-1], "dtype": "bf16",
+        "ms_per_step_median": ms_median, "ms_per_step_min": ms_min, "ms_per_step_max": per_step[-1],
+        # (value = the wall clock over all timed steps, as for the headline; one stalled step -- seen once in a dozen runs on
+        #  the pool's boxes: 7.8 s -- drags it down, the median does not)
+        "value_from_median_step": world * B / ms_median * 1e3, "steps_over_2x_median": sum(v > 2 * ms_median for v in per_step),
+        "dtype": "bf16",
         "config": {"workload": "cfg5: R(2+1)D-18 in bf16 (fp32 master weights, fp32 BN statistics) + ResNet-9/heads fp32, "
                                "per-GPU bs=%d, 32x112x112 video, 1x129x100 log-mel, K=309, headcount=10" % B,
                    "global_batch": world * B, "parallelism": "dp%d" % world, "loss_last_step": loss_v,
@@ -341,14 +348,14 @@ def bf16_leg(a, rank, world, local, dev):
                      "frac": hot["bytes"] / hot["ms"] / 1e6 / PEAK_HBM_GBS,
                      # PMC bytes per launch at 16 clips x 16 frames (tools/pmc_traffic.sh), scaled to this launch's positions
                      "traffic": (lambda t: None if t is None else t * (min(B, 64) * T) / (16.0 * 16.0))(_pmc_traffic("hot_conv16_fwd")),
-                     "kernel": "conv_cl16_s3_kernel<9,1,1> (LDS-resident patch) layer1 (1,3,3) 64->144 train forward at bs %d" % min(B, 64),
+                     "kernel": "conv_cl16_sr_kernel<1,1> (register-resident weights, persistent) layer1 (1,3,3) 64->144 train forward at bs %d" % min(B, 64),
                      "ms_per_launch": hot["ms"], "mfma_tflops": hot["flop"] / hot["ms"] / 1e9,
                      "mfma_frac": hot["flop"] / hot["ms"] / 1e9 / PEAK_BF16_MFMA_TF,
                      # the same kernel inside the cfg5 step (full 128 x 32-frame launch; frozen figure, see _rocprof_in_step)
                      "in_step": (lambda r: None if r is None else dict(
-                         r, achieved=B * T * 56 * 56 * (64 + 144) * 2.0 / r["ms"] / 1e6,
-                         frac=B * T * 56 * 56 * (64 + 144) * 2.0 / r["ms"] / 1e6 / PEAK_HBM_GBS))(
-                         _rocprof_in_step(HOT16_KERNEL, (B * T * 56 * 56 + 127) // 128,
+                         r, achieved=B // 2 * T * 56 * 56 * (64 + 144) * 2.0 / r["ms"] / 1e6,      # (a launch = one batch slice of 64 clips)
+                         frac=B // 2 * T * 56 * 56 * (64 + 144) * 2.0 / r["ms"] / 1e6 / PEAK_HBM_GBS))(
+                         _rocprof_in_step(HOT16_KERNEL, 256,
                                           ("r03_step16_cfg5_kernel_summary.txt", "r02_step16_cfg5_kernel_summary.txt"))
                          if B == CFG5["batch"] else None),
                      "note": "bf16: this conv's arithmetic intensity (128 FLOP/B) is below the ridge (312): HBM-bound"},

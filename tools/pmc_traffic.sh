@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the two roofline kernels from PMC counters: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3
 # passes (--kernel-trace only), averaged per dispatch, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950
-# reports 1/2 of wide reads).  Writes gpurun_out/pmc_traffic.json; copy it to profiles/r02_pmc.json.
+# reports 1/2 of wide reads).  Writes gpurun_out/pmc_traffic.json; copy it to profiles/r03_pmc.json.
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -38,7 +38,7 @@ for k, d in list(res.items()):          # aliases bench.py looks up
         out["hot_conv_fwd"] = dict(d, kernel=k)
     if "sk_pass_kernel" in k and k.endswith("grid=262144"):
         out["sk_pass"] = dict(d, kernel=k)
-    if k.startswith("conv_cl16_s3_kernel<9, 1, 1>") or (k.startswith("conv_cl16_kernel<9, 1, 1>") and "hot_conv16_fwd" not in out):
+    if k.startswith("conv_cl16_sr_kernel<1, 1>") or ((k.startswith("conv_cl16_s3_kernel<9, 1, 1>") or k.startswith("conv_cl16_kernel<9, 1, 1>")) and "hot_conv16_fwd" not in out):
         out["hot_conv16_fwd"] = dict(d, kernel=k)          # layer-1 spatial train forward of the 16-bit path
     if k.startswith("cl16_wgrad3_kernel<5, 1>") or (k.startswith("cl16_wgrad_kernel<5, 3, 1>") and "hot_conv16_wgrad" not in out):
         out["hot_conv16_wgrad"] = dict(d, kernel=k)          # layer-1 spatial weight gradient (rolling-patch kernel)
