@@ -40,11 +40,12 @@ def join_side_streams(ctx):
 
 class Raw:
     """A raw conv output with its (pending) BatchNorm."""
-    __slots__ = ("y", "ss", "mi", "plan", "conv", "bn", "src", "wt")
+    __slots__ = ("y", "ss", "mi", "plan", "conv", "bn", "src", "wt", "pending")
 
     def __init__(self, y, ss, mi, plan, conv, bn, src, wt=None):
         self.y, self.ss, self.mi, self.plan, self.conv, self.bn, self.src = y, ss, mi, plan, conv, bn, src
         self.wt = wt                # backward-data weights made together with the forward ones
+        self.pending = None         # (ssum, ssq, count): statistics not finalised yet (finalize_deferred)
 
 
 class Ctx:
@@ -69,9 +70,10 @@ def _as5d(t):
     return t if t.dim() == 5 else t.unsqueeze(2)
 
 
-def conv_bn(ctx, x, conv, bn, need_dx=True):
+def conv_bn(ctx, x, conv, bn, need_dx=True, defer=False):
     """x: materialised tensor or Raw (then relu(bn(x)) is applied on load).  -> Raw
-    need_dx=False: first conv of a trunk (no gradient w.r.t. the network input is ever taken)."""
+    need_dx=False: first conv of a trunk (no gradient w.r.t. the network input is ever taken).
+    defer (SyncBN only): leave the statistics un-finalised -- finalize_deferred packs several layers into one exchange."""
     if isinstance(x, Raw):
         xin, in_ss = x.y, x.ss
     else:
@@ -82,6 +84,11 @@ def conv_bn(ctx, x, conv, bn, need_dx=True):
     wf, wt = ctx.ops.conv_w_transform(plan, conv.weight, need_wt=ctx.training and need_dx)
     y, ssum, ssq = ctx.ops.conv_fwd(plan, xin, conv.weight, in_ss=in_ss, in_relu=in_ss is not None,
                                 want_stats=ctx.training, wf=wf)
+    if ctx.training and defer and ctx.sync is not None:
+        r = Raw(y, None, None, plan, conv, bn, x, wt)
+        r.pending = (ssum, ssq, plan.count)
+        bn.note_batch()
+        return r
     if ctx.training:
         mi, ss = ctx.ops.bn_train_finalize(ssum, ssq, plan.count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                        bn.momentum, bn.eps, sync=ctx.sync)
@@ -89,6 +96,17 @@ def conv_bn(ctx, x, conv, bn, need_dx=True):
     else:
         mi, ss = ctx.ops.bn_eval_params(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
     return Raw(y, ss, mi, plan, conv, bn, x, wt)
+
+
+def finalize_deferred(ctx, raws):
+    """One SyncBN exchange for the deferred statistics of several layers (the main stream's latency-bound exchanges are
+    what data parallelism adds to the step: main.py:117-118)."""
+    raws = [r for r in raws if r is not None and r.pending is not None]
+    if not raws:
+        return
+    items = [(*r.pending, r.bn.weight, r.bn.bias, r.bn.running_mean, r.bn.running_var, r.bn.momentum, r.bn.eps) for r in raws]
+    for r, (mi, ss) in zip(raws, ctx.ops.bn_train_finalize_many(items, ctx.sync)):
+        r.mi, r.ss, r.pending = mi, ss, None
 
 
 def tail(ctx, r, res=None, res_raw=None, relu=True):
@@ -169,10 +187,13 @@ def block_fwd(ctx, u, chain_mods, ds_mods):
     rec.u_in = u
     x = u
     rec.chain = []
-    for conv, bn in chain_mods:
-        x = conv_bn(ctx, x, conv, bn)
+    for k, (conv, bn) in enumerate(chain_mods):
+        # the last BatchNorm of the chain and the downsample BatchNorm are both consumed by the block tail only: their
+        # statistics travel in one exchange
+        x = conv_bn(ctx, x, conv, bn, defer=ds_mods is not None and k == len(chain_mods) - 1)
         rec.chain.append(x)
-    rec.ds = conv_bn(ctx, u, ds_mods[0], ds_mods[1]) if ds_mods is not None else None
+    rec.ds = conv_bn(ctx, u, ds_mods[0], ds_mods[1], defer=True) if ds_mods is not None else None
+    finalize_deferred(ctx, [rec.chain[-1], rec.ds])
     rec.v = tail(ctx, rec.chain[-1], res=None if rec.ds is not None else u, res_raw=rec.ds)
     return rec
 

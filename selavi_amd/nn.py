@@ -437,6 +437,7 @@ class HeadsFunction(torch.autograd.Function):
                 C.slv_heads_bn_stats(ptr(h), ptr(sums), G, B, HID, st)
                 if spec.sync is not None:
                     ops._allreduce(sums, spec.sync[0])
+                    ops.EXCHANGES[0] += 1
                     count *= spec.sync[1]
                 for b in bns:
                     b.note_batch()
@@ -500,6 +501,7 @@ class HeadsFunction(torch.autograd.Function):
             C.slv_heads_bn_bwd_stats(ptr(da), ptr(h), ptr(mi), ga.p, be.p, ptr(m2), msc, ptr(sums), G, B, HID, st)
             if spec.sync is not None:
                 ops._allreduce(sums, spec.sync[0])
+                ops.EXCHANGES[0] += 1
             dh = f32(G, B, HID)
             C.slv_heads_bn_bwd_apply(ptr(da), ptr(h), ptr(mi), ga.p, be.p, ptr(m2), msc, ptr(sums), count, ptr(dh),
                                      ptr(dga), ptr(dbe), G, B, HID, st)

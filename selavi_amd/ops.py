@@ -334,6 +334,7 @@ def bn_train_finalize(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps,
                                 ptr(rvar), float(momentum), float(eps), ptr(mi), ptr(ss), Cc, stream())
         return mi, ss
     sums = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+    EXCHANGES[0] += 1
     comm = _native(sync)
     if comm is not None:        # one library call, one stream: partials -> sums -> RCCL all-reduce -> finalize
         C.slv_bn_sync_finalize(comm.h, ptr(ssum), ptr(ssq), ssum.shape[1], float(count), ptr(gamma), ptr(beta), ptr(rmean),
@@ -345,6 +346,36 @@ def bn_train_finalize(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps,
     C.slv_bn_finalize(ptr(sums), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(momentum),
                       float(eps), ptr(mi), ptr(ss), Cc, stream())
     return mi, ss
+
+
+EXCHANGES = [0]        # SyncBN exchanges issued by this process (tests count them per step)
+
+
+def bn_train_finalize_many(items, sync):
+    """Several BatchNorms whose statistics are complete at the same point of the schedule (the last conv of a residual
+    block and its downsample conv: nothing consumes either before the block tail) finalised behind ONE exchange:
+    items = [(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps), ...] -> [(mean_invstd, scale_shift), ...].
+    The 2C fp64 sums of all items travel in one buffer; kernels and arithmetic are those of bn_train_finalize."""
+    dev = items[0][3].device
+    tot = sum(2 * it[3].numel() for it in items)
+    sums = torch.empty(tot, dtype=torch.float64, device=dev)
+    o, views = 0, []
+    for ssum, ssq, count, gamma, *_ in items:
+        Cc = gamma.numel()
+        v = sums[o:o + 2 * Cc]
+        C.slv_bn_partials_to_sums(ptr(ssum), ptr(ssq), ssum.shape[1], Cc, ptr(v), stream())
+        views.append(v)
+        o += 2 * Cc
+    _allreduce(sums, sync[0])
+    EXCHANGES[0] += 1
+    outs = []
+    for v, (ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps) in zip(views, items):
+        Cc = gamma.numel()
+        mi, ss = _f32(2, Cc, device=dev), _f32(2, Cc, device=dev)
+        C.slv_bn_finalize(ptr(v), float(count * sync[1]), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(momentum),
+                          float(eps), ptr(mi), ptr(ss), Cc, stream())
+        outs.append((mi, ss))
+    return outs
 
 
 def bn_eval_params(gamma, beta, rmean, rvar, eps):
@@ -398,13 +429,29 @@ def bn_bwd_finish(part, part2, ns, count, mi, gamma, ss_mask, mi2, gamma2, sync,
     local_count = count
     if sync is not None:
         count *= sync[1]
+    jobs = [(part, mi, gamma, ss_mask, dgamma, dbeta), (part2, mi2, gamma2, None, dgamma2, dbeta2)]
+    if sync is not None and part2 is not None:
+        # the block's last BatchNorm and its downsample BatchNorm: both sets of sums behind ONE exchange
+        sums = torch.empty(4 * Cc, dtype=torch.float64, device=dev)
+        for k, (pt_, *_r) in enumerate(jobs):
+            C.slv_bn_bwd_sums(ptr(pt_), ns, Cc, ptr(sums[2 * Cc * k:2 * Cc * (k + 1)]), stream())
+        _allreduce(sums, sync[0])
+        EXCHANGES[0] += 1
+        outs = []
+        for k, (pt_, mi_, ga_, ss_, dg_, db_) in enumerate(jobs):
+            b5 = _f32(5, Cc, device=dev)
+            C.slv_bn_bwd_finalize(ptr(sums[2 * Cc * k:2 * Cc * (k + 1)]), count, ptr(ga_), ptr(mi_), ptr(ss_), ptr(b5), ptr(dg_),
+                                  ptr(db_), 0, Cc, stream())
+            outs.append(b5)
+        return outs
     outs = []
-    for (pt_, mi_, ga_, ss_, dg_, db_) in ((part, mi, gamma, ss_mask, dgamma, dbeta),
-                                          (part2, mi2, gamma2, None, dgamma2, dbeta2)):
+    for (pt_, mi_, ga_, ss_, dg_, db_) in jobs:
         if pt_ is None:
             outs.append(None)
             continue
         b5 = _f32(5, Cc, device=dev)
+        if sync is not None:
+            EXCHANGES[0] += 1
         if comm is not None:
             sums = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
             C.slv_bn_bwd_sync_finalize(comm.h, ptr(pt_), ns, local_count, ptr(ga_), ptr(mi_), ptr(ss_), ptr(b5), ptr(dg_),

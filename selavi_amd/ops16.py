@@ -117,6 +117,7 @@ from . import ops as _ops
 # (profiles/r02_notes.md); SELAVI_CL16_FUSE_BNR=1 switches it on.
 FUSE_BNR = os.environ.get("SELAVI_CL16_FUSE_BNR", "0") == "1"
 bn_train_finalize = _ops.bn_train_finalize
+bn_train_finalize_many = _ops.bn_train_finalize_many
 bn_eval_params = _ops.bn_eval_params
 bnrelu_maxpool_fwd = _ops.bnrelu_maxpool_fwd        # the audio trunk stays on the fp32 kernels
 maxpool_bwd = _ops.maxpool_bwd

@@ -116,13 +116,16 @@ def _ddp_worker(rank, world, port, ret, wrap=False, precision="fp32"):
         loss = train.train_step(net, opt, video, audio, sl, sel, hc)
         if wrap:      # several steps (DDP rebuilds its buckets after the first), then hash the whole state
             first = float(loss)
+            from selavi_amd import ops as _o
             for _ in range(2):
+                ex0 = _o.EXCHANGES[0]
                 loss = train.train_step(net, opt, video, audio, sl, sel, hc)
+            exchanges = _o.EXCHANGES[0] - ex0                   # SyncBN exchanges of one step
             import hashlib
             hs = {k: hashlib.sha256(v.detach().cpu().numpy().tobytes()).hexdigest()[:16]
                   for k, v in sorted(m.state_dict().items())}
             from selavi_amd.comm import NativeComm
-            ret[rank] = (first, float(loss), hs, len(NativeComm._cache))      # communicators behind the C ABI (0 on gloo)
+            ret[rank] = (first, float(loss), hs, len(NativeComm._cache), exchanges)      # communicators behind the C ABI (0 on gloo)
             NativeComm.destroy_all()
             return
         sd = m.state_dict()
@@ -190,6 +193,12 @@ def test_two_rank_native_data_parallel_is_bit_identical_to_ddp():
     differs = [k for k in ret[0][2] if ret[0][2][k] != ret_ddp[0][2][k]]
     assert not differs, f"{len(differs)} of {len(ret[0][2])} tensors differ from DDP: {differs[:6]}"
     assert ret[0][0] == ret_ddp[0][0] and ret[0][1] == ret_ddp[0][1]
+    # SyncBN exchanges per step (each one a latency-bound all-reduce on a compute stream): one per BatchNorm forward and
+    # backward -- every one of them sits on a true dependency (the next conv / the backward-data conv needs the global
+    # statistics) -- except the pairs that become available together: the last BatchNorm of a residual block and its
+    # downsample BatchNorm share one exchange in both directions.  R(2+1)D-18 + ResNet-9 + the grouped heads: 88
+    # (100 before the pairs were packed; 49 of them on the audio trunk's own stream and communicator)
+    assert ret[0][4] == ret[1][4] and ret[0][4] <= 88, ret[0][4]
 
 
 def test_two_rank_native_data_parallel_on_the_16bit_path_stays_in_lock_step():
