@@ -59,6 +59,7 @@ class Ctx:
         self.grads = {}             # id(param) -> grad tensor
         self.grad_out = None        # id(param) -> preallocated gradient view (parallel.GradSink), or None
         self.side = None            # HIP stream carrying this pass' weight-gradient launches, if any
+        self.wgrad_side = WGRAD_SIDE_STREAM      # (off for a trunk that itself runs on a side stream: nn.TrunkFunction)
 
     def grad_like(self, p):
         """Where the gradient of parameter p is written: the data-parallel bucket view if there is one."""
@@ -143,7 +144,7 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
     dw_out = ctx.grad_out.get(id(w)) if ctx.grad_out is not None else None     # persistent bucket view (parallel.py)
     if dw_out is not None:
         dw_out = dw_out.view(w.shape[0], -1)
-    if WGRAD_SIDE_STREAM:
+    if ctx.wgrad_side:
         # the backward-data conv is on the critical path: it is enqueued first; the weight gradient starts on
         # the side stream as soon as dXout exists (event recorded before the dgrad launch)
         cur = torch.cuda.current_stream(dxo.device)

@@ -129,13 +129,12 @@ class AVModel(nn.Module):             # model.py:169-252
         if self.overlap_audio and spec.is_cuda:
             main = torch.cuda.current_stream(spec.device)
             side = self._side_stream(spec.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                aud_features = self.audio_network(spec).squeeze()
+            self.audio_network.base.side_stream = side            # the node forks / joins by itself (nn.TrunkFunction)
+            aud_features = self.audio_network(spec).squeeze()
             img_features = self.video_network(img).squeeze()
             main.wait_stream(side)
-            aud_features.record_stream(main)
         else:
+            self.audio_network.base.side_stream = None
             aud_features = self.audio_network(spec).squeeze()
             img_features = self.video_network(img).squeeze()
         if self.return_features:                                  # model.py:226-227

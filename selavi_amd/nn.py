@@ -8,6 +8,8 @@ heads through ``HeadsFunction`` -- all HIP kernels behind the C ABI.
 """
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -221,8 +223,20 @@ def _sync_of(mod):
     return s
 
 
+_FORK_EVENTS = {}      # device index -> event recorded behind the heads' backward (the point a side-stream trunk forks from)
+
+
 class TrunkFunction(torch.autograd.Function):
-    """One autograd node per trunk: forward = engine schedule, backward = hand-written schedule."""
+    """One autograd node per trunk: forward = engine schedule, backward = hand-written schedule.
+
+    ``trunk.side_stream`` (AVModel sets it on the audio trunk): the node's kernels run on that HIP stream, forked from
+    and joined to the caller's stream with events BY THE NODE ITSELF -- from autograd's point of view the node lives on
+    the caller's stream.  (Running ``apply`` under ``torch.cuda.stream(side)`` instead makes autograd hand the incoming
+    gradient across streams on its own, which cannot be captured into a HIP graph: hipStreamEndCapture crashes on ROCm
+    7.0.)  Forward: forks where it is called and is joined by the caller (model.forward, in front of the heads).
+    Backward: forks behind the heads' backward (_FORK_EVENTS) and joins at its own end -- the audio node is the last one
+    of the backward pass (it was issued first), so nothing queues behind that join but the optimizer, while its kernels
+    run beside the video backward already enqueued."""
 
     @staticmethod
     def forward(fctx, trunk, kind, x, *params):
@@ -230,8 +244,17 @@ class TrunkFunction(torch.autograd.Function):
         need_grad = training and any(fctx.needs_input_grad)
         ectx = engine.Ctx(training, sync=_sync_of(trunk) if training else None)
         fwd = engine.video_forward if kind == "video" else engine.audio_forward
-        feat, saved = fwd(ectx, trunk, x)
-        fctx.need = need_grad
+        side = getattr(trunk, "side_stream", None) if x.is_cuda else None
+        if side is not None:
+            main = torch.cuda.current_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                feat, saved = fwd(ectx, trunk, x)
+            x.record_stream(side)
+            feat.record_stream(main)
+        else:
+            feat, saved = fwd(ectx, trunk, x)
+        fctx.need, fctx.side = need_grad, side
         if need_grad:
             fctx.saved_rec, fctx.trunk, fctx.kind, fctx.sync = saved, trunk, kind, ectx.sync
         return feat
@@ -246,7 +269,27 @@ class TrunkFunction(torch.autograd.Function):
         if sink is not None:
             ectx.grad_out = sink.views((fctx.kind,), params)
         bwd = engine.video_backward if fctx.kind == "video" else engine.audio_backward
-        bwd(ectx, fctx.saved_rec, dfeat)
+        side = fctx.side
+        if side is not None:
+            # (no second-level fork: a weight-gradient stream forked from this side stream crashes hipStreamEndCapture on
+            #  ROCm 7.0 -- tests/diag/graph_capture_stages.py; the audio trunk's 1.5 ms of small kernels are off the
+            #  critical path either way)
+            ectx.wgrad_side = False
+            main = torch.cuda.current_stream(dfeat.device)
+            ev = _FORK_EVENTS.pop(dfeat.device.index, None)
+            if ev is not None and os.environ.get("SELAVI_FORK_EVENT", "1") == "1":
+                side.wait_event(ev)                            # behind the heads' backward, not behind the video backward
+            else:
+                side.wait_stream(main)
+            dfeat = dfeat.contiguous()
+            with torch.cuda.stream(side):
+                bwd(ectx, fctx.saved_rec, dfeat)
+            dfeat.record_stream(side)
+            for gt in ectx.grads.values():
+                gt.record_stream(main)
+            main.wait_stream(side)
+        else:
+            bwd(ectx, fctx.saved_rec, dfeat)
         fctx.saved_rec = None
         if sink is not None:
             sink.deliver((fctx.kind,), params)                 # .grad = bucket views, all-reduce launched
@@ -537,6 +580,8 @@ class HeadsFunction(torch.autograd.Function):
             C.slv_heads_sum_groups(ptr(dxg), ptr(dX), hcg, B * dxg.shape[2], st)
             dfv, dfa = dX[0], dX[1]
         hp = head_params(heads)
+        if not spec.single:                   # where a side-stream trunk's backward forks from (TrunkFunction)
+            _FORK_EVENTS[dev.index] = torch.cuda.current_stream(dev).record_event()
         if spec.grad_sink is not None:        # the grouped gradient tensors are views of one bucket: one all-reduce
             for p in hp:
                 p.grad = grads[id(p)]

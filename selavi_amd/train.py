@@ -86,11 +86,7 @@ class GraphedStep:
         import torch
         self.model, self.video, self.audio, self.selflabels, self.selected = model, video, audio, selflabels, selected
         self._bns = [m for m in model.modules() if hasattr(m, "note_batch")]
-        # the audio trunk stays on the capturing stream: capturing its backward on the side stream (autograd's own
-        # cross-stream hand-over of the incoming gradient) segfaults in hipStreamEndCapture on ROCm 7.0
-        # (tests/diag/graph_capture_stages.py); the weight-gradient side streams capture fine
-        core = model.module if hasattr(model, "module") else model
-        core.overlap_audio = False
+        # (the audio trunk keeps its own stream under capture: its node forks and joins with events, nn.TrunkFunction)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                  # plans, tuning, momentum buffers, side streams: all before capture

@@ -42,6 +42,8 @@ with torch.cuda.stream(side):
 torch.cuda.current_stream().wait_stream(side)
 torch.cuda.synchronize()
 print("warm-up done", flush=True)
+from selavi_amd import nn as snn       # noqa: E402
+snn.dropout_device_state(dev, create=True)
 g = torch.cuda.CUDAGraph()
 opt.zero_grad(set_to_none=True)
 with torch.cuda.graph(g):

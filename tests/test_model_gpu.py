@@ -522,9 +522,11 @@ def test_training_step_with_batch_sliced_convs(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_graphed_step_replays_bit_identically_to_eager():
-    """train.GraphedStep: the whole step (forward, loss, backward with the weight-gradient side streams, SGD) captured
-    into one HIP graph; two replays leave exactly the weights two eager steps leave."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graphed_step_replays_bit_identically_to_eager(precision):
+    """train.GraphedStep: the whole step (forward, loss, backward with the weight-gradient side streams AND the audio
+    trunk on its own stream -- its autograd node forks and joins with events --, SGD) captured into one HIP graph; two
+    replays leave exactly the weights two eager steps leave, on the fp32 path and with the video trunk on the 16-bit path."""
     from selavi_amd import model as smodel, optim, train
 
     def make():
@@ -532,7 +534,8 @@ def test_graphed_step_replays_bit_identically_to_eager():
         portable_init_(m, seed=31)
         step_ref.set_dropout_p(m, 0.0)
         m = m.cuda().train()
-        m.overlap_audio = False                    # same stream assignment as the captured step
+        m.set_precision(precision)
+        assert m.overlap_audio
         return m, optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
 
     video = portable_fill_(torch.empty(4, 3, 4, 32, 32), 5).cuda()
