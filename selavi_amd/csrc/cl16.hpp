@@ -46,6 +46,13 @@ __device__ __forceinline__ u32x4 affine_relu8(u32x4 v, const float* s, const flo
   return o;
 }
 
+// The two halves of a transposed fragment (ds_read_b64_tr_b16 results) as one MFMA operand: a plain concatenation of the
+// two register pairs.  (Assembling the eight shorts one by one makes hipcc emit a v_bfi on each half right behind its
+// read: a full LDS latency in front of the next MFMA.)
+__device__ __forceinline__ bf16x8 tr_pair(s16x4 lo, s16x4 hi) {
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // Geometry of one launch (int32 x CLC_WORDS, mirrored by selavi_amd/ops16.py).  The block enumerates a LATTICE of
 // positions; the B operand (activation rows) is read at  lattice * bm + bo + tap offset, the output is written at
 // lattice * om + oo:
@@ -120,8 +127,7 @@ __device__ __forceinline__ void wave_tile_stats(const unsigned char* rows, int o
   for (int i = 0; i < MT; ++i) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32 + 16 * orow));
-    const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    const bf16x8 yv = __builtin_bit_cast(bf16x8, tmp);
+    const bf16x8 yv = tr_pair(lo, hi);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yv, z, 0, 0, 0);
     const f32x4 q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yv, yv, z, 0, 0, 0);
@@ -147,8 +153,7 @@ __device__ __forceinline__ void wave_rows32_stats_acc(const unsigned char* rows,
   for (int i = 0; i < MT; ++i) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32 + 16 * orow));
-    const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    yv[i] = __builtin_bit_cast(bf16x8, tmp);
+    yv[i] = tr_pair(lo, hi);
   }
   f32x4 sm[MT], q[MT];
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -181,8 +186,7 @@ __device__ __forceinline__ void wave_rows32_stats_acc_asm(const unsigned char* r
   for (int i = 0; i < MT; ++i) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + i * 32 + 16 * orow));
-    const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    yv[i] = __builtin_bit_cast(bf16x8, tmp);
+    yv[i] = tr_pair(lo, hi);
   }
   f32x4 sm[MT], q[MT];
 #pragma unroll
@@ -237,6 +241,14 @@ bool wgrad3_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, int
                  int pt, int ph, int pw, int To, int Ho, int Wo, int* wm, ClWgrad3* out);
 size_t wgrad3_ws_bytes(const ClWgrad3& g, int wm);
 void wgrad3_launch(const ClWgrad3& g, int wm, const void* dy, const void* x, const float* in_ss, float* part, hipStream_t st);
+
+// csrc/wgrad_cl16_acc.hip: weight gradient of the layer-1 spatial conv (64 -> 144), the whole dW resident in the
+// accumulators of a persistent workgroup; partials [blocks][144][9 * 64]
+bool wgrad_acc_applies(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, int Cout, int kt, int kh, int kw, int st,
+                       int sh, int sw, int pt, int ph, int pw, int To, int Ho, int Wo);
+int wgrad_acc_blocks();
+size_t wgrad_acc_ws_bytes();
+int wgrad_acc_launch(int N, int T, int H, int W, const void* dy, const void* x, const float* in_ss, float* part, hipStream_t st);
 
 // csrc/wgrad_cl16_t.hip: weight gradient of the stride-1 (3,1,1) convs, one pass over the activations for the three taps
 struct ClWgradT {

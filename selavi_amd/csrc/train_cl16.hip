@@ -199,16 +199,14 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad_kernel(const unsigned short
     for (int j = 0; j < WN; ++j) {
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(B + fb + j * 32));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(B + fb + j * 32 + 16 * SB));
-      const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      bfr[j] = __builtin_bit_cast(bf16x8, tmp);
+      bfr[j] = tr_pair(lo, hi);
     }
     bf16x8 afr[WM];                                    // all fragment reads of the K-step before its first MFMA
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(A + fa + i * 32));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(A + fa + i * 32 + 16 * SA));
-      const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      afr[i] = __builtin_bit_cast(bf16x8, tmp);
+      afr[i] = tr_pair(lo, hi);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -511,7 +509,10 @@ int32_t slv_cl16_wgrad_words(void) { return slv::CLW_WORDS; }
 size_t slv_cl16_wgrad_ws_bytes(const int32_t* clw, int wm, int wn) {
   slv::ClWgrad g;
   memcpy(&g, clw, sizeof(g));
-  const size_t general = (size_t)g.kslices * g.mtiles * wm * 32 * g.ntiles * wn * 32 * sizeof(float);
+  size_t general = (size_t)g.kslices * g.mtiles * wm * 32 * g.ntiles * wn * 32 * sizeof(float);
+  if (slv::wgrad_acc_applies(g.N, g.Ti, g.Hi, g.Wi, g.Cin_p, g.Cin, g.Cout_p, 144, g.kt, g.kh, g.kw, g.st, g.sh, g.sw, g.pt, g.ph,
+                             g.pw, g.To, g.Ho, g.Wo) && slv::wgrad_acc_ws_bytes() > general)
+    general = slv::wgrad_acc_ws_bytes();
   slv::ClWgrad3 g3;
   int wm3;
   if (slv::wgrad3_plan(g.N, g.Ti, g.Hi, g.Wi, g.Cin_p, g.Cin, g.Cout_p, g.kt, g.kh, g.kw, g.st, g.sh, g.sw, g.pt, g.ph, g.pw,
@@ -551,6 +552,16 @@ int slv_cl16_wgrad(const int32_t* clw, int wm, int wn, const void* dy_bf16, cons
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
   const int taps = g.kt * g.kh * g.kw;
+  if (!patch_kw && wgrad_acc_applies(g.N, g.Ti, g.Hi, g.Wi, g.Cin_p, g.Cin, g.Cout_p, Cout, g.kt, g.kh, g.kw, g.st, g.sh, g.sw,
+                                     g.pt, g.ph, g.pw, g.To, g.Ho, g.Wo)) {   // layer-1 spatial: dW resident in accumulators
+    const int rc = wgrad_acc_launch(g.N, g.Ti, g.Hi, g.Wi, dy_bf16, x_bf16, in_scale_shift, part, st);
+    if (rc) return rc;
+    const size_t ldpa = (size_t)g.Ncols;
+    hipLaunchKernelGGL(cl16_wgrad_reduce_kernel, dim3((g.Ncols + 255) / 256, Cout), dim3(256), 0, st, part, dw, Cout, g.Cin,
+                       taps, g.Cin_p, wgrad_acc_blocks(), (size_t)Cout * ldpa, ldpa, 0, (unsigned)g.Ncols);
+    SLV_LAUNCH_CHECK();
+    return 0;
+  }
   {                                                                // stride-1 (1,3,3): the rolling-patch kernel
     ClWgrad3 g3;
     int wm3;

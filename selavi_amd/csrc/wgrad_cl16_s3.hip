@@ -188,8 +188,7 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad3_kernel(const unsigned shor
         for (int c = 0; c < 2; ++c) {
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(blo + c * 32));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bhi + c * 32));
-          const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          b[e][c] = __builtin_bit_cast(bf16x8, tmp);
+          b[e][c] = tr_pair(lo, hi);
         }
       }
       // The hand-issued reads are invisible to the compiler's counters, but every MFMA also takes a patch fragment, and

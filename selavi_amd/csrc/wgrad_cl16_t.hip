@@ -177,8 +177,7 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad_t_kernel(const unsigned sho
         for (int c = 0; c < NC; ++c) {
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bt + c * 32));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bt + c * 32 + 16 * SPB));
-          const short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          const bf16x8 b = __builtin_bit_cast(bf16x8, tmp);
+          const bf16x8 b = tr_pair(lo, hi);
 #pragma unroll
           for (int i = 0; i < WM; ++i) acc[i][e][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][e][c], 0, 0, 0);
         }

@@ -173,6 +173,10 @@ PATCH_WGRAD_CASES = [  # N, Cin, T, H, W, Cout: stride-1 (1,3,3) layers -> the r
     (1, 64, 2, 4, 3, 96),         # W = 3: falls back to the general kernel
     (2, 128, 4, 24, 24, 144),     # 4 608 positions: two K slices, rows cross frame and clip borders inside a slice
     (1, 32, 1, 9, 33, 40),        # one image, W > 32 (a K step inside one image row), 32 channels = half a group
+    # layer-1 spatial with >= 2 048 tiles of 8 x 8: the accumulator-resident kernel (csrc/wgrad_cl16_acc.hip), 8 or 9 tiles
+    # per workgroup (ragged), tiles of every border kind, frames and clips crossed inside a workgroup's sequence
+    (4, 64, 11, 56, 56, 144),
+    (2, 64, 9, 64, 120, 144),     # 8 x 15 tiles per frame
 ]
 
 
