@@ -377,6 +377,14 @@ int slv_cl16_bn_bwd_reduce(const void* g_bf16, const void* x_bf16, const float* 
 int slv_cl16_bn_bwd_apply(const void* g_bf16, const void* x_bf16, const float* bwd5, int relu, void* out_bf16, int64_t P,
                           int C, int Cp, slv_stream_t stream);
 int slv_cl16_avgpool_bwd(const float* dout, void* dv_bf16, int64_t N, int64_t S, int C, int Cp, slv_stream_t stream);
+/* the audio trunk's stem on the 16-bit path (torchvision ResNet conv1-bn1-relu-maxpool: /root/reference/model.py:114-132
+ * builds it, main.py:296-299 runs its backward; fp32 counterparts: slv_bnrelu_maxpool_fwd / slv_maxpool_bwd):
+ * out = MaxPool2d(3, 2, 1)(relu(x * scale + shift)) on bf16 [N][H][W][Cp], idx [N][Ho][Wo][Cp] = winning tap 0..8 (first
+ * maximum, as torch); backward: the gather form over the <= 4 windows of an input pixel, fp32 sum, one rounding */
+int slv_cl16_bnrelu_maxpool_fwd(const void* x_bf16, const float* scale_shift, void* out_bf16, uint8_t* idx, int64_t N, int C,
+                                int Cp, int H, int W, slv_stream_t stream);
+int slv_cl16_maxpool_bwd(const void* dout_bf16, const uint8_t* idx, void* dy_bf16, int64_t N, int Cp, int H, int W,
+                         slv_stream_t stream);
 /* bf16 [N][S][Cp] -> fp32 N,C,S: the inverse of slv_to_cl16 (inspection, tests) */
 int slv_from_cl16(const void* x_bf16, float* y, int64_t N, int C, int Cp, int64_t S, slv_stream_t stream);
 

@@ -261,6 +261,96 @@ __global__ __launch_bounds__(256) void cl16_wgrad_reduce_kernel(const float* __r
   dw[out] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
+// ------------------------------------------------------------------------------------------ audio stem pooling
+// relu(bn(x)) -> MaxPool2d(3, stride 2, padding 1) on [N][H][W][Cp] bf16 (the audio trunk's stem: torchvision ResNet
+// conv1-bn1-relu-maxpool, /root/reference/model.py:114-132), one thread per (output pixel, 8 channels).  The pooled value
+// is the bf16-rounded activation (what a conv prologue would have fed the MFMAs); idx = the winning tap 0..8, first
+// maximum wins like torch.
+__global__ __launch_bounds__(256) void cl16_bnrelu_maxpool_fwd_kernel(const unsigned short* __restrict__ x,
+                                                                     const float* __restrict__ ss,
+                                                                     unsigned short* __restrict__ out,
+                                                                     unsigned char* __restrict__ idx, int C, int Cp, int H,
+                                                                     int W, int Ho, int Wo, unsigned total) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const unsigned pc = Cp >> 3, piece = i % pc, o = i / pc;
+  const int wo = (int)(o % (unsigned)Wo), ho = (int)((o / (unsigned)Wo) % (unsigned)Ho);
+  const unsigned n = o / (unsigned)(Wo * Ho);
+  const int c0 = piece * 8;
+  float s[8], h[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool ok = c0 + j < C;
+    s[j] = ok ? ss[c0 + j] : 0.f;
+    h[j] = ok ? ss[C + c0 + j] : 0.f;
+  }
+  unsigned best[4] = {0u, 0u, 0u, 0u};
+  unsigned char bi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool any = false;
+  for (int dh = 0; dh < 3; ++dh) {
+    const int hh = ho * 2 - 1 + dh;
+    if (hh < 0 || hh >= H) continue;
+    for (int dw = 0; dw < 3; ++dw) {
+      const int ww = wo * 2 - 1 + dw;
+      if (ww < 0 || ww >= W) continue;
+      const u32x4 v = affine_relu8(*(const u32x4*)(x + ((size_t)(n * H + hh) * W + ww) * Cp + c0), s, h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned cur = (v[j >> 1] >> (16 * (j & 1))) & 0xFFFFu, old = (best[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        if (!any || cur > old) {                 // activated values are >= +0: their bf16 patterns order like unsigned ints
+          best[j >> 1] = (best[j >> 1] & ~(0xFFFFu << (16 * (j & 1)))) | (cur << (16 * (j & 1)));
+          bi[j] = (unsigned char)(dh * 3 + dw);
+        }
+      }
+      any = true;
+    }
+  }
+  *(u32x4*)(out + (size_t)o * Cp + c0) = (u32x4){best[0], best[1], best[2], best[3]};
+  unsigned lo = 0, hi = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    lo |= (unsigned)bi[j] << (8 * j);
+    hi |= (unsigned)bi[4 + j] << (8 * j);
+  }
+  *(uint2*)(idx + (size_t)o * Cp + c0) = make_uint2(lo, hi);
+}
+
+// gather form (deterministic): dy[n][h][w][c] = sum over the <= 4 windows that contain (h, w) and chose it, fp32, one rounding
+__global__ __launch_bounds__(256) void cl16_maxpool_bwd_kernel(const unsigned short* __restrict__ dout,
+                                                              const unsigned char* __restrict__ idx,
+                                                              unsigned short* __restrict__ dy, int Cp, int H, int W, int Ho,
+                                                              int Wo, unsigned total) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const unsigned pc = Cp >> 3, piece = i % pc, q = i / pc;
+  const int w = (int)(q % (unsigned)W), h = (int)((q / (unsigned)W) % (unsigned)H);
+  const unsigned n = q / (unsigned)(W * H);
+  const int c0 = piece * 8;
+  float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int ho = (h + 1) / 2 - 1; ho <= (h + 1) / 2; ++ho) {
+    if (ho < 0 || ho >= Ho) continue;
+    const int dh = h - (ho * 2 - 1);
+    if (dh < 0 || dh > 2) continue;
+    for (int wo = (w + 1) / 2 - 1; wo <= (w + 1) / 2; ++wo) {
+      if (wo < 0 || wo >= Wo) continue;
+      const int dw = w - (wo * 2 - 1);
+      if (dw < 0 || dw > 2) continue;
+      const size_t o = ((size_t)(n * Ho + ho) * Wo + wo) * Cp + c0;
+      const u32x4 d = *(const u32x4*)(dout + o);
+      const uint2 ix = *(const uint2*)(idx + o);
+      const unsigned tap = (unsigned)(dh * 3 + dw);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned t = ((j < 4 ? ix.x : ix.y) >> (8 * (j & 3))) & 0xFFu;
+        const float dv = (j & 1) ? bf_hi(d[j >> 1]) : bf_lo(d[j >> 1]);
+        if (t == tap) g[j] += dv;
+      }
+    }
+  }
+  *(u32x4*)(dy + (size_t)q * Cp + c0) = (u32x4){pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3]), pack_bf2(g[4], g[5]), pack_bf2(g[6], g[7])};
+}
+
+
 // ------------------------------------------------------------------------------------------ BatchNorm, channels last
 // Elementwise kernels on [P][Cp] bf16: one thread per 16-byte piece (8 channels).  The grid stride (gridDim.x * 256) is a
 // multiple of Cp/8 (cl16_ew_blocks), so a thread keeps ITS 8 channels for every position it visits and loads their
@@ -689,6 +779,34 @@ int slv_cl16_avgpool_bwd(const float* dout, void* dv_bf16, int64_t N, int64_t S,
   const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(cl16_avgpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout,
                      (unsigned short*)dv_bf16, (unsigned)S, C, Cp, (unsigned)total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_cl16_bnrelu_maxpool_fwd(const void* x_bf16, const float* scale_shift, void* out_bf16, uint8_t* idx, int64_t N, int C,
+                                int Cp, int H, int W, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(x_bf16 && scale_shift && out_bf16 && idx && N > 0 && C > 0 && Cp >= C && (Cp & 7) == 0 && H > 0 && W > 0,
+                "bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long total = N * Ho * Wo * (Cp / 8);
+  SLV_CHECK_ARG(total < 0xFFFFFF00LL && N * H * W * (long long)Cp < 0xFFFFFF00LL, "tensor too large");
+  hipLaunchKernelGGL(cl16_bnrelu_maxpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x_bf16, scale_shift, (unsigned short*)out_bf16, idx, C, Cp, H, W, Ho, Wo,
+                     (unsigned)total);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_cl16_maxpool_bwd(const void* dout_bf16, const uint8_t* idx, void* dy_bf16, int64_t N, int Cp, int H, int W,
+                         slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(dout_bf16 && idx && dy_bf16 && N > 0 && Cp > 0 && (Cp & 7) == 0 && H > 0 && W > 0, "bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long total = N * H * W * (Cp / 8);
+  SLV_CHECK_ARG(total < 0xFFFFFF00LL, "tensor too large");
+  hipLaunchKernelGGL(cl16_maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)dout_bf16, idx, (unsigned short*)dy_bf16, Cp, H, W, Ho, Wo, (unsigned)total);
   SLV_LAUNCH_CHECK();
   return 0;
 }

@@ -178,7 +178,15 @@ __global__ __launch_bounds__(256, 1) void cl16_wgrad_acc_kernel(const unsigned s
   // requests the X fragment of the next tap, slot 1 the dY fragment `tap` of the next K step; the other 7 x 18 = 126
   // slots carry the data movement of tile k + 2 (fs = free-slot index): 4 X requests, 6 DMA instructions, late in the
   // tile the 20 staging items.
-  auto tile_step = [&](int bc, int bn, int bf, const WaTile& tf) __attribute__((always_inline)) {
+#ifdef SLV_WA_TRACE   // s_memtime at 5 points of tiles 8..23, every wave of blocks 0..15 -> the head of `part` (timing only!)
+#define WA_T(slot) if (tr_on && k >= 8 && k < 24) trace[(k - 8) * 5 + (slot)] = __builtin_amdgcn_s_memtime()
+  const bool tr_on = lane == 0 && blockIdx.x < 16;
+  unsigned long long* trace = (unsigned long long*)part + (size_t)((blockIdx.x * 4 + wave) * 16) * 5;
+#else
+#define WA_T(slot)
+#endif
+  auto tile_step = [&](int k, int bc, int bn, int bf, const WaTile& tf) __attribute__((always_inline)) {
+    WA_T(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -186,6 +194,7 @@ __global__ __launch_bounds__(256, 1) void cl16_wgrad_acc_kernel(const unsigned s
 #pragma unroll
         for (int cot = 0; cot < 9; ++cot) {
           const int m = t * 9 + cot, gt = ks * 9 + t;
+          if (ks == 1 && m == 0) WA_T(1);
           if (SLV_WA_ABL == 1) {
             if (m < WA_NA) accA[m][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, dyf[ks][cot])[0] ^ __builtin_bit_cast(u32x4, xf[gt & 1])[0]);
             else accV[m - WA_NA][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, dyf[ks][cot])[0] ^ __builtin_bit_cast(u32x4, xf[gt & 1])[0]);
@@ -209,8 +218,11 @@ __global__ __launch_bounds__(256, 1) void cl16_wgrad_acc_kernel(const unsigned s
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+    WA_T(2);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    WA_T(3);
     __builtin_amdgcn_s_barrier();
+    WA_T(4);
   };
 
   // ---- pipeline head: tiles 0 and 1 staged, then the first fragments
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void cl16_wgrad_acc_kernel(const unsigned s
   int bc = 0, bn = 1, bf = 2;
   for (int k = 0; k < nst; ++k) {
     const WaTile tf = next_tile();
-    tile_step(bc, bn, bf, tf);
+    tile_step(k, bc, bn, bf, tf);
     const int b0 = bc;
     bc = bn;
     bn = bf;
@@ -246,6 +258,9 @@ __global__ __launch_bounds__(256, 1) void cl16_wgrad_acc_kernel(const unsigned s
   // ---- this workgroup's partial: part[wg][co][tap * 64 + ci]; C/D layout: column (ci) = lane & 15, rows (co) 4 fk + r
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
   float* pw = part + (size_t)blockIdx.x * (WA_COUT * 9 * WA_CIN) + wave * 16 + fr;
+#ifdef SLV_WA_TRACE
+  if (accV[0][0] == 123.456f)
+#endif
 #pragma unroll
   for (int m = 0; m < 81; ++m) {
     const int t = m / 9, cot = m % 9;

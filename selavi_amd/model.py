@@ -92,14 +92,18 @@ class AVModel(nn.Module):             # model.py:169-252
         for h in self._heads():
             h.sync = sync
 
-    def set_precision(self, precision):
-        """"fp32" (default; every parity claim) or "bf16": the video trunk -- 99 % of the step's FLOPs -- trains on the
-        16-bit MFMA path (what --use_fp16 / apex O1 does to the convs in the reference, main.py:151-153): bf16
-        channels-last activations and activation gradients, fp32 accumulation, fp32 master weights, BatchNorm
-        statistics and parameters in fp32, no loss scaling (bf16 has fp32's exponent range).  The audio trunk
-        (0.6 % of the FLOPs, on its own stream) and the heads stay on the fp32 kernels."""
+    def set_precision(self, precision, audio=None):
+        """"fp32" (default; every parity claim) or "bf16": both trunks train on the 16-bit MFMA path (what --use_fp16 /
+        apex O1 does to the convs in the reference, main.py:151-153): bf16 channels-last activations and activation
+        gradients, fp32 accumulation, fp32 master weights, BatchNorm statistics and parameters in fp32, no loss scaling
+        (bf16 has fp32's exponent range).  ``audio``: precision of the audio trunk when it should differ from the video
+        trunk's (SELAVI_AUDIO_PRECISION overrides the default).  The heads (0.2 % of the FLOPs) stay on the fp32 kernels."""
         assert precision in ("fp32", "bf16")
+        if audio is None:
+            audio = os.environ.get("SELAVI_AUDIO_PRECISION", precision)
+        assert audio in ("fp32", "bf16")
         self.video_network.base.precision = precision
+        self.audio_network.base.precision = audio
 
     def set_grad_sink(self, sink):
         """parallel.DataParallel: parameter gradients are written into the sink's flat buffers and all-reduced per

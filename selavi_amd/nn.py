@@ -242,7 +242,7 @@ class TrunkFunction(torch.autograd.Function):
     def forward(fctx, trunk, kind, x, *params):
         training = trunk.training
         need_grad = training and any(fctx.needs_input_grad)
-        ectx = engine.Ctx(training, sync=_sync_of(trunk) if training else None)
+        ectx = engine.Ctx(training, sync=_sync_of(trunk) if training else None, ops=_backend(trunk))
         fwd = engine.video_forward if kind == "video" else engine.audio_forward
         side = getattr(trunk, "side_stream", None) if x.is_cuda else None
         if side is not None:
@@ -256,14 +256,14 @@ class TrunkFunction(torch.autograd.Function):
             feat, saved = fwd(ectx, trunk, x)
         fctx.need, fctx.side = need_grad, side
         if need_grad:
-            fctx.saved_rec, fctx.trunk, fctx.kind, fctx.sync = saved, trunk, kind, ectx.sync
+            fctx.saved_rec, fctx.trunk, fctx.kind, fctx.sync, fctx.ops = saved, trunk, kind, ectx.sync, ectx.ops
         return feat
 
     @staticmethod
     def backward(fctx, dfeat):
         if not fctx.need:
             raise RuntimeError("selavi_amd: backward through a trunk that ran in eval / no_grad mode")
-        ectx = engine.Ctx(True, sync=fctx.sync)
+        ectx = engine.Ctx(True, sync=fctx.sync, ops=fctx.ops)
         params = _trunk_params(fctx.trunk)
         sink = getattr(fctx.trunk, "grad_sink", None)          # parallel.GradSink: gradients go to its flat buffer
         if sink is not None:

@@ -119,8 +119,27 @@ FUSE_BNR = os.environ.get("SELAVI_CL16_FUSE_BNR", "0") == "1"
 bn_train_finalize = _ops.bn_train_finalize
 bn_train_finalize_many = _ops.bn_train_finalize_many
 bn_eval_params = _ops.bn_eval_params
-bnrelu_maxpool_fwd = _ops.bnrelu_maxpool_fwd        # the audio trunk stays on the fp32 kernels
-maxpool_bwd = _ops.maxpool_bwd
+
+
+def bnrelu_maxpool_fwd(x, ss):
+    """MaxPool2d(3, 2, 1)(relu(bn(x))) of the audio stem on bf16 [N,1,H,W,Cp]: (out, idx)."""
+    N, T, H, W, Cp = x.shape
+    assert T == 1 and x.dtype == torch.bfloat16 and x.is_contiguous()
+    Cc = ss.shape[1]
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = _bf16(N, 1, Ho, Wo, Cp, device=x.device)
+    idx = torch.empty(N, 1, Ho, Wo, Cp, dtype=torch.uint8, device=x.device)
+    C.slv_cl16_bnrelu_maxpool_fwd(ptr(x), ptr(ss), ptr(out), ptr(idx), N, Cc, Cp, H, W, stream())
+    return out, idx
+
+
+def maxpool_bwd(dout, idx, in_shape):
+    N, T, H, W, Cp = in_shape
+    assert T == 1 and dout.dtype == torch.bfloat16 and dout.is_contiguous()
+    dy = _bf16(*in_shape, device=dout.device)
+    C.slv_cl16_maxpool_bwd(ptr(dout), ptr(idx), ptr(dy), N, Cp, H, W, stream())
+    return dy
+
 
 CL_BUF_LIMIT = int(os.environ.get("SELAVI_CL16_BUF_LIMIT", str(0xFFFFFFF0)))
 _CLC_WORDS = None

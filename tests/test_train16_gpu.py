@@ -455,8 +455,8 @@ def test_bf16_training_step_against_fp32_step():
 
 
 def _oracle_step_on_rounded(B, T, S, hc, K, round_activations):
-    """oracle/step_ref (torch CPU, fp32 arithmetic) on the operands the 16-bit path sees: video conv weights and the clip
-    rounded to bf16; with ``round_activations`` every video conv output is additionally stored as bf16 (forward value and
+    """oracle/step_ref (torch CPU, fp32 arithmetic) on the operands the 16-bit path sees: the conv weights of both trunks,
+    the clip and the spectrogram rounded to bf16; with ``round_activations`` every conv output is additionally stored as bf16 (forward value and
     the gradient that flows back through it), which is what the channels-last bf16 tensors of the HIP path do."""
     from oracle import model_ref, step_ref
     from oracle.model_ref import portable_fill_, portable_init_
@@ -465,23 +465,23 @@ def _oracle_step_on_rounded(B, T, S, hc, K, round_activations):
     step_ref.set_dropout_p(m, 0.0)
     m.train()
     with torch.no_grad():
-        for p in m.video_network.parameters():
-            if p.dim() == 5:
+        for p in list(m.video_network.parameters()) + list(m.audio_network.parameters()):
+            if p.dim() >= 4:
                 p.copy_(p.to(torch.bfloat16).float())
     hooks = []
     if round_activations:
-        for mod in m.video_network.modules():
-            if isinstance(mod, torch.nn.Conv3d):
+        for mod in list(m.video_network.modules()) + list(m.audio_network.modules()):
+            if isinstance(mod, (torch.nn.Conv3d, torch.nn.Conv2d)):
                 hooks.append(mod.register_forward_hook(lambda _m, _i, out: out.to(torch.bfloat16).float()))
     video = portable_fill_(torch.empty(B, 3, T, S, S), 5).to(torch.bfloat16).float()
-    audio = portable_fill_(torch.empty(B, 1, 40, 36), 6)
+    audio = portable_fill_(torch.empty(B, 1, 40, 36), 6).to(torch.bfloat16).float()
     sl = torch.from_numpy((np.arange(64 * hc).reshape(64, hc) * 7919 % K).astype(np.int64))
     sel = torch.tensor([3, 17, 42, 63, 5, 9, 33, 60])[:B]
     opt = step_ref.make_optimizer(m, lr=0.0)
     loss, _, _ = step_ref.train_step(m, opt, video, audio, sl, sel, hc)
     for h in hooks:
         h.remove()
-    grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if n.startswith("video_network")}
+    grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if n.startswith(("video_network", "audio_network"))}
     return float(loss), grads
 
 
@@ -535,6 +535,66 @@ def test_bf16_step_against_the_cpu_oracle_on_rounded_operands():
     tight = [(n, f, h) for n, f, h, _ in rows if f > 0.98 and h < 0.9]
     assert not tight, tight[:5]
     assert np.median(hip) >= np.median(floor) ** 2 - 0.05
+
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 65, 50), (2, 64, 9, 7), (2, 45, 8, 8)])
+def test_audio_stem_pooling_matches_torch(shape):
+    """MaxPool2d(3, 2, 1)(relu(bn(x))) of the audio stem on bf16 channels-last tensors, and its backward (first maximum
+    wins, the gather over the <= 4 windows of a pixel), against torch on the same bf16-rounded activations."""
+    from selavi_amd import ops16
+    N, Cc, H, W = shape
+    g = torch.Generator().manual_seed(11 + H)
+    x = _bf(torch.randn(N, Cc, 1, H, W, generator=g))
+    x[0, :, 0, :4, :4] = 0.25                                  # ties inside and across windows
+    ss = torch.stack([torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3]).contiguous()
+    act = _bf(torch.addcmul(ss[1].view(1, -1, 1, 1, 1), x, ss[0].view(1, -1, 1, 1, 1)).clamp_min(0))
+    a = act[:, :, 0].clone().requires_grad_(True)
+    want = F.max_pool2d(a, 3, 2, 1)
+    out, idx = ops16.bnrelu_maxpool_fwd(_cl(x), ss.cuda())
+    got = _ncthw(out, Cc)[:, :, 0]
+    # the kernel's fma rounds once where addcmul + clamp + rounding above round twice: a value may sit one bf16 step away
+    assert float((got - want.detach()).abs().max()) <= 2 ** -7 * float(want.detach().abs().max())
+    exact = (got == want.detach())
+    assert float(exact.float().mean()) > 0.99
+    dout = _bf(torch.randn(want.shape, generator=g))
+    (dwant,) = torch.autograd.grad(want, a, dout)
+    dy = ops16.maxpool_bwd(_cl(dout.unsqueeze(2)), idx, (N, 1, H, W, ops16.pad32(Cc)))
+    dgot = _ncthw(dy, Cc)[:, :, 0]
+    # compare where the forward agreed bit for bit on the whole neighbourhood (elsewhere the argmax may differ by a tie)
+    ok = F.max_pool2d((~exact).float(), 3, 2, 1) == 0
+    okin = 1 - F.interpolate((~ok).float(), size=(H, W), mode="nearest")
+    sel = F.max_pool2d(1 - okin, 5, 1, 2) == 0
+    assert float(sel.float().mean()) > 0.8
+    assert float(((dgot - _bf(dwant)).abs() * sel).max()) <= 2 ** -7 * float(dwant.abs().max())
+    assert (dy[..., Cc:] == 0).all() and (out[..., Cc:] == 0).all()
+
+
+def test_audio_trunk_on_the_16bit_path_against_fp32():
+    """ResNet-9 on spectrograms with set_precision("bf16") (2-D convs = T = 1 on the cl16 kernels, stem through the W-patch
+    layout, pooling kernels above): features and parameter gradients against the fp32 HIP trunk from the same weights."""
+    from oracle.model_ref import portable_fill_, portable_init_
+    from selavi_amd import model as smodel
+    res = {}
+    for prec in ("fp32", "bf16"):
+        m = smodel.load_model(use_mlp=True, num_classes=7, norm_feat=False, headcount=2)
+        portable_init_(m, seed=31)
+        m = m.cuda().train()
+        m.set_precision("fp32", audio=prec)
+        spec = portable_fill_(torch.empty(8, 1, 129, 100), 6).cuda()
+        feat = m.audio_network(spec)
+        assert feat.dtype == torch.float32 and feat.shape == (8, 512)
+        w = portable_fill_(torch.empty(8, 512), 9).cuda()
+        (feat * w).sum().backward()
+        res[prec] = (feat.detach().double().cpu(), {n: p.grad.detach().double().cpu().flatten()
+                                                      for n, p in m.audio_network.named_parameters()})
+    f32, f16 = res["fp32"][0], res["bf16"][0]
+    assert float((f16 - f32).norm() / f32.norm()) < 2e-2
+    cosines = {n: float((res["bf16"][1][n] @ g) / (res["bf16"][1][n].norm() * g.norm() + 1e-30)) for n, g in res["fp32"][1].items()}
+    low = sorted(cosines.items(), key=lambda kv: kv[1])[:5]
+    print("audio trunk bf16 vs fp32: feature rel err %.2e, gradient cos min %s" % (float((f16 - f32).norm() / f32.norm()), low))
+    # (bf16 storage of every activation and gradient under train-mode BatchNorm: measured min 0.969 / median 0.983)
+    assert min(cosines.values()) > 0.9 and np.median(list(cosines.values())) > 0.97, low
 
 
 def test_bf16_and_fp32_loss_curves_agree_over_sixty_steps():
