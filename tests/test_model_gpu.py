@@ -631,3 +631,39 @@ def test_dropout_masks_are_philox_bit_exact_and_loss_total():
         assert not torch.equal(o1, o2)
         outs.append(o1)
     assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,IN,OUT,shared", [(16, 512, 512, 1), (5, 512, 309, 1), (40, 512, 309, 0), (128, 512, 512, 1),
+                                             (70, 64, 20, 0)])
+def test_grouped_head_linears_on_the_matrix_cores(B, IN, OUT, shared):
+    """slv_heads_linear_fwd / _bwd_w / _bwd_x (the MFMA kernels: IN % 16 == 0) against fp64 matmuls with the same dropout
+    masks: ragged batch tiles, K = 309 outputs (not a multiple of 4 or 16), X shared per modality or one per head."""
+    from selavi_amd import ops
+    from selavi_amd._lib import C, ptr, stream
+    hc, G = 3, 6
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + OUT)
+    X = torch.randn(2 if shared else G, B, IN, generator=g)
+    Ws = [torch.randn(OUT, IN, generator=g) * IN ** -0.5 for _ in range(G)]
+    bs = [torch.randn(OUT, generator=g) for _ in range(G)]
+    mask = (torch.rand(G, B, IN, generator=g) > 0.3).float()
+    msc = 1.0 / 0.7
+    dout = torch.randn(G, B, OUT, generator=g)
+    Xd, Wd, bd, md, dd = X.to(dev), [w.to(dev) for w in Ws], [b.to(dev) for b in bs], mask.to(dev), dout.to(dev)
+    Wt, bt = ops.PtrArray(Wd), ops.PtrArray(bd)
+    for use_mask in (True, False):
+        Xm = torch.stack([X[gi // hc if shared else gi].double() * (mask[gi].double() * msc if use_mask else 1.0) for gi in range(G)])
+        want = torch.stack([Xm[gi] @ Ws[gi].double().t() + bs[gi].double() for gi in range(G)])
+        out = torch.empty(G, B, OUT, device=dev)
+        C.slv_heads_linear_fwd(ptr(Xd), shared, hc, ptr(md) if use_mask else 0, msc, Wt.p, bt.p, ptr(out), G, B, IN, OUT, stream())
+        assert float((out.cpu().double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        dW, db = torch.empty(G, OUT, IN, device=dev), torch.empty(G, OUT, device=dev)
+        C.slv_heads_linear_bwd_w(ptr(dd), ptr(Xd), shared, hc, ptr(md) if use_mask else 0, msc, ptr(dW), ptr(db), G, B, IN, OUT, stream())
+        wantW = torch.stack([dout[gi].double().t() @ Xm[gi] for gi in range(G)])
+        assert float((dW.cpu().double() - wantW).abs().max()) <= 2e-5 * float(wantW.abs().max())
+        assert float((db.cpu().double() - dout.double().sum(1)).abs().max()) <= 2e-5 * float(dout.double().sum(1).abs().max())
+        dx = torch.empty(G, B, IN, device=dev)
+        C.slv_heads_linear_bwd_x(ptr(dd), Wt.p, ptr(md) if use_mask else 0, msc, ptr(dx), G, B, IN, OUT, stream())
+        wantx = torch.stack([(dout[gi].double() @ Ws[gi].double()) * (mask[gi].double() * msc if use_mask else 1.0) for gi in range(G)])
+        assert float((dx.cpu().double() - wantx).abs().max()) <= 2e-5 * float(wantx.abs().max())
