@@ -297,13 +297,19 @@ def conv_wt_transform(plan, w):
     return conv_w_transform(plan, w, need_wf=False)[1]
 
 
-def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True, wf=None, out=None):
+def stem_patch(plan, x):
+    """The W-patch image of the fp32 clip / spectrogram a stem conv reads (made once per step: the forward and the weight
+    gradient both take it through ``patch=``)."""
+    return _patch(plan, x) if plan.stem else None
+
+
+def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True, wf=None, out=None, patch=None):
     """y = conv(relu(x*s+h)) on the MFMA kernel; returns (y, stat_sum, stat_sq) with [Cout][nblk] partials."""
     assert (in_ss is not None) == bool(in_relu), "the load prologue is BatchNorm + ReLU"
     if wf is None:
         wf, _ = conv_w_transform(plan, w, need_wt=False)
     if plan.stem:
-        x = _patch(plan, x)
+        x = patch if patch is not None else _patch(plan, x)
     if plan.chunks is not None:
         y = _bf16(*plan.out_shape, device=x.device)
         parts = [conv_fwd(sub, x[b0:b1], w, in_ss, in_relu, want_stats, wf, out=y[b0:b1]) for b0, b1, sub in plan.chunks]
@@ -349,13 +355,13 @@ def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out
     return dx if bnr is None else (dx, part)
 
 
-def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, in_relu=False, out=None):
+def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, in_relu=False, out=None, patch=None):
     """dw (fp32, [Cout][Cin*taps] = the reference layout flattened) from bf16 dy and act(x_in)."""
     assert bwd5 is None and (in_ss is not None) == bool(in_relu)
     n_w = plan.Cin_w * plan.w_shape_taps
     dw = out if out is not None else torch.empty(plan.Cout, n_w, dtype=torch.float32, device=dy.device)
     if plan.stem:
-        x_in = _patch(plan, x_in)
+        x_in = patch if patch is not None else _patch(plan, x_in)
     if plan.chunks is not None:
         n = len(plan.chunks)
         slices = torch.empty(n, plan.Cout, n_w, dtype=torch.float32, device=dy.device)
