@@ -368,6 +368,16 @@ size_t slv_cl16_wgrad_ws_bytes(const int32_t* clw, int wm, int wn);
 int slv_cl16_wgrad(const int32_t* clw, int wm, int wn, const void* dy_bf16, const void* x_bf16,
                    const float* in_scale_shift, float* dw, int Cout, int patch_kw, void* ws, size_t ws_bytes,
                    slv_stream_t stream);
+/* Weight gradient of a stride-1 (3,1,1) conv that ALSO returns the BatchNorm-backward sums of the layer the conv reads
+ * (x = that layer's raw output, in_scale_shift / in_mean_invstd its BatchNorm; main.py:296-299): dw as slv_cl16_wgrad with
+ * the BN + ReLU prologue, bn_part[C][2] = { sum g', sum g' xhat } with g' = the masked gradient w.r.t. relu(bn(x)) -- the
+ * input of slv_bn_bwd_sums_finalize, without the slv_cl16_bn_bwd_reduce pass over the gradient and x.  w: the conv's fp32
+ * master weights [Cout][Cin][3] (rounded to bf16 inside, as the backward-data conv uses them).
+ * slv_cl16_wgrad_bnr_ws_bytes returns 0 for a geometry this path does not take. */
+size_t slv_cl16_wgrad_bnr_ws_bytes(const int32_t* clw);
+int slv_cl16_wgrad_bnr(const int32_t* clw, const void* dy_bf16, const void* x_bf16, const float* in_scale_shift,
+                       const float* in_mean_invstd, const float* w, float* dw, float* bn_part, int Cout, void* ws,
+                       size_t ws_bytes, slv_stream_t stream);
 int slv_cl16_bn_act(const void* x_bf16, const float* scale_shift, const void* res_bf16, const float* res_scale_shift,
                     int relu, void* out_bf16, int64_t P, int C, int Cp, slv_stream_t stream);
 int32_t slv_cl16_bn_bwd_nsplit(int64_t P, int Cp);

@@ -260,5 +260,16 @@ bool wgrad_t_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, in
                   int pt, int ph, int pw, int To, int Ho, int Wo, int* wm, int* nc, ClWgradT* out);
 size_t wgrad_t_ws_bytes(const ClWgradT& g, int wm);
 void wgrad_t_launch(const ClWgradT& g, int wm, int nc, const void* dy, const void* x, const float* in_ss, float* part, hipStream_t st);
+void wgrad_t_launch_dual(const ClWgradT& g, int wm, int nc, const void* dy, const void* x, const float* in_ss, float* part,
+                         size_t kind_stride, hipStream_t st);
+
+
+// csrc/wgrad_cl16_t2.hip: the same weight gradient formed as s G2 + h G1 (G2, G1: the gradient against the masked raw
+// activation and against the mask), which also yields the BatchNorm-backward sums of the layer the conv reads
+bool wgrad_t2_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, int kt, int kh, int kw, int st, int sh, int sw,
+                   int pt, int ph, int pw, int To, int Ho, int Wo, int* wm, int* nc, ClWgradT* out);
+size_t wgrad_t2_ws_bytes(const ClWgradT& g, int wm);
+int wgrad_t2_launch(const ClWgradT& g, int wm, int nc, const void* dy, const void* x, const float* in_ss, const float* mi,
+                    const float* w, float* dw, float* bn_part, int Cout, float* ws, hipStream_t st);
 
 }  // namespace slv

@@ -696,6 +696,35 @@ int slv_cl16_wgrad(const int32_t* clw, int wm, int wn, const void* dy_bf16, cons
   return 0;
 }
 
+size_t slv_cl16_wgrad_bnr_ws_bytes(const int32_t* clw) {
+  slv::ClWgrad g;
+  memcpy(&g, clw, sizeof(g));
+  slv::ClWgradT gt;
+  int wmt, nct;
+  if (!slv::wgrad_t2_plan(g.N, g.Ti, g.Hi, g.Wi, g.Cin_p, g.Cin, g.Cout_p, g.kt, g.kh, g.kw, g.st, g.sh, g.sw, g.pt, g.ph, g.pw,
+                          g.To, g.Ho, g.Wo, &wmt, &nct, &gt))
+    return 0;
+  return slv::wgrad_t2_ws_bytes(gt, wmt);
+}
+
+int slv_cl16_wgrad_bnr(const int32_t* clw, const void* dy_bf16, const void* x_bf16, const float* in_scale_shift,
+                       const float* in_mean_invstd, const float* w, float* dw, float* bn_part, int Cout, void* ws,
+                       size_t ws_bytes, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(clw && dy_bf16 && x_bf16 && in_scale_shift && in_mean_invstd && w && dw && bn_part && ws, "null pointer");
+  ClWgrad g;
+  memcpy(&g, clw, sizeof(g));
+  ClWgradT gt;
+  int wmt, nct;
+  SLV_CHECK_ARG(wgrad_t2_plan(g.N, g.Ti, g.Hi, g.Wi, g.Cin_p, g.Cin, g.Cout_p, g.kt, g.kh, g.kw, g.st, g.sh, g.sw, g.pt, g.ph,
+                              g.pw, g.To, g.Ho, g.Wo, &wmt, &nct, &gt), "not a stride-1 (3,1,1) conv this kernel takes");
+  SLV_CHECK_ARG(Cout > 0 && Cout <= g.Cout_p && ws_bytes >= wgrad_t2_ws_bytes(gt, wmt), "Cout / workspace");
+  SLV_CHECK_ARG((long long)g.N * g.Ti * g.Hi * g.Wi * g.Cin_p * 2 < 0xFFFFFFF0LL &&
+                    (long long)g.N * g.To * g.Ho * g.Wo * g.Cout_p * 2 < 0xFFFFFFF0LL, "tensor beyond the 32-bit buffer range");
+  return wgrad_t2_launch(gt, wmt, nct, dy_bf16, x_bf16, in_scale_shift, in_mean_invstd, w, dw, bn_part, Cout, (float*)ws,
+                         (hipStream_t)stream);
+}
+
 int slv_cl16_bn_act(const void* x_bf16, const float* scale_shift, const void* res_bf16, const float* res_scale_shift,
                     int relu, void* out_bf16, int64_t P, int C, int Cp, slv_stream_t stream) {
   using namespace slv;

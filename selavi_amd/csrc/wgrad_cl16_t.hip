@@ -29,7 +29,9 @@ template <int WM, int NC, int PRO>
 __global__ __launch_bounds__(256, 2) void cl16_wgrad_t_kernel(const unsigned short* __restrict__ dy,
                                                               const unsigned short* __restrict__ x,
                                                               const float* __restrict__ in_ss, float* __restrict__ part,
-                                                              ClWgradT g, FastDiv dT1, FastDiv dPB) {
+                                                              ClWgradT g, FastDiv dT1, FastDiv dPB, size_t kind_stride) {
+  // PRO 2 (csrc/wgrad_cl16_t2.hip): consecutive units are the two KINDS of one (tile, slice) -- the activation operand is
+  // the masked raw value m x (kind 0) or the mask m itself (kind 1), m = [x s + h > 0]; partials of kind k at k * kind_stride
   constexpr int BM = 32 * WM, APC = BM / 8 + 2, SA = APC * 16, AIT = (32 * APC + 255) / 256;
   constexpr int ABYTES = 32 * SA;             // pieces are linear (pc * 16) and a wave's piece outside the tile is skipped: no rounding to 4 KiB
   constexpr int NG = 32 * NC, NGP = NG / 8, SPB = NG * 2 + 32, TILEB = 32 * SPB, SIT = (32 * NGP + 255) / 256;
@@ -37,12 +39,15 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad_t_kernel(const unsigned sho
   // two LDS objects: the DMA's target is read with hand-issued ds_read_b64_tr_b16 only (wgrad_cl16_s3.hip)
   __shared__ __attribute__((aligned(16))) unsigned char lds_a[NAB * ABYTES];
   __shared__ __attribute__((aligned(16))) unsigned char ring[NRING * TILEB + (PRO ? 2 * NG * 4 : 0)];
+  static_assert(PRO >= 0 && PRO <= 2, "prologue kinds");
   float* const pro = (float*)(ring + NRING * TILEB);               // PRO 1: [2][NG] scale, shift of this group's channels
   typedef __attribute__((address_space(3))) void* lds_void;
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const unsigned total = gridDim.x, q8 = total >> 3, r8 = total & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
   unsigned unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  const int kind = PRO == 2 ? (int)(unit & 1u) : 0;
+  if constexpr (PRO == 2) unit >>= 1;
   const int grp = unit % g.groups; unit /= g.groups;
   const int mt = unit % g.mtiles;
   const unsigned slice = unit / g.mtiles;
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad_t_kernel(const unsigned sho
   const unsigned Prows = (unsigned)g.N * g.T * g.HW;
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)(Prows * (unsigned)g.Cout_p * 2u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(Prows * (unsigned)g.Cin_p * 2u), 0x00020000);
-  if constexpr (PRO == 1) {
+  if constexpr (PRO != 0) {
     for (int i = tid; i < 2 * NG; i += 256) {
       const int c = c0 + (i % NG), which = i / NG;
       pro[i] = c < g.Cin ? in_ss[which * g.Cin + c] : 0.f;
@@ -130,6 +135,18 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad_t_kernel(const unsigned sho
           const u32x4 t = affine_relu8(v, sc, sh);
           v = ((S.okm >> i) & 1) ? t : (u32x4){0u, 0u, 0u, 0u};
         }
+        if constexpr (PRO == 2) {
+          const float* sp = pro + pc * 8;
+          const bool live = (S.okm >> i) & 1;
+          const u32x4 base = kind ? (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u} : v;      // bf16 1.0 / x
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            // the mask as every kernel of this path evaluates it: one fused multiply-add in fp32, > 0
+            const bool lo = live && bn_affine(bf_lo(v[d]), sp[2 * d], sp[NG + 2 * d]) > 0.f;
+            const bool hi = live && bn_affine(bf_hi(v[d]), sp[2 * d + 1], sp[NG + 2 * d + 1]) > 0.f;
+            v[d] = base[d] & ((lo ? 0x0000FFFFu : 0u) | (hi ? 0xFFFF0000u : 0u));
+          }
+        }
         *(u32x4*)(dst + j * SPB + pc * 16) = v;
       }
     }
@@ -189,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad_t_kernel(const unsigned sho
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SIT + AIT - 1) : "memory");
   };
   if (nsteps > 0) {
-    if constexpr (PRO == 1) __syncthreads();                         // the prologue table
+    if constexpr (PRO != 0) __syncthreads();                         // the prologue table
     stage_load(s_lo - 1, sg[0]);
     dma_a(s_lo, 0);
     dma_a(s_lo + 1, 1);
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void cl16_wgrad_t_kernel(const unsigned sho
   }
   // ---- partial tile: part[slice][mtiles * BM][3 * Cin_p]; C/D: col = lane & 15, rows (lane >> 4) * 4 + r
   const size_t ldp = (size_t)3 * g.Cin_p;
-  float* pt = part + ((size_t)slice * g.mtiles * BM + m0 + wm * WM * 16) * ldp;
+  float* pt = part + (size_t)kind * kind_stride + ((size_t)slice * g.mtiles * BM + m0 + wm * WM * 16) * ldp;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int ch = c0 + wn * NC * 16 + c * 16;
@@ -283,10 +300,28 @@ static void wgrad_t_launch_one(const ClWgradT& g, const void* dy, const void* x,
   const unsigned blocks = (unsigned)(g.kslices * g.mtiles * g.groups);
   if (in_ss)
     hipLaunchKernelGGL((cl16_wgrad_t_kernel<WM, NC, 1>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dy,
-                       (const unsigned short*)x, in_ss, part, g, dT1, dPB);
+                       (const unsigned short*)x, in_ss, part, g, dT1, dPB, (size_t)0);
   else
     hipLaunchKernelGGL((cl16_wgrad_t_kernel<WM, NC, 0>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dy,
-                       (const unsigned short*)x, in_ss, part, g, dT1, dPB);
+                       (const unsigned short*)x, in_ss, part, g, dT1, dPB, (size_t)0);
+}
+
+// PRO 2: both kinds of every (tile, slice), partials [2][slices][rows][3 Cin_p] (csrc/wgrad_cl16_t2.hip)
+template <int WM, int NC>
+static void wgrad_t_launch_dual_one(const ClWgradT& g, const void* dy, const void* x, const float* in_ss, float* part,
+                                    size_t kind_stride, hipStream_t st) {
+  const FastDiv dT1 = make_fastdiv(g.T + 1), dPB = make_fastdiv(g.PB);
+  const unsigned blocks = (unsigned)(2 * g.kslices * g.mtiles * g.groups);
+  hipLaunchKernelGGL((cl16_wgrad_t_kernel<WM, NC, 2>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)dy,
+                     (const unsigned short*)x, in_ss, part, g, dT1, dPB, kind_stride);
+}
+
+void wgrad_t_launch_dual(const ClWgradT& g, int wm, int nc, const void* dy, const void* x, const float* in_ss, float* part,
+                         size_t kind_stride, hipStream_t st) {
+  if (wm == 2 && nc == 5) wgrad_t_launch_dual_one<2, 5>(g, dy, x, in_ss, part, kind_stride, st);
+  else if (wm == 2) wgrad_t_launch_dual_one<2, 2>(g, dy, x, in_ss, part, kind_stride, st);
+  else if (wm == 4) wgrad_t_launch_dual_one<4, 2>(g, dy, x, in_ss, part, kind_stride, st);
+  else wgrad_t_launch_dual_one<5, 2>(g, dy, x, in_ss, part, kind_stride, st);
 }
 
 void wgrad_t_launch(const ClWgradT& g, int wm, int nc, const void* dy, const void* x, const float* in_ss, float* part, hipStream_t st) {

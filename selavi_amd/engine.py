@@ -161,6 +161,14 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
             return ctx.ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None, out=dw_out, patch=r.patch)
         return ctx.ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None, out=dw_out)
 
+    if fuse_bn and in_ss is not None and getattr(ctx.ops, "wgrad_bnr_ok", None) is not None and ctx.ops.wgrad_bnr_ok(r.plan):
+        # stride-1 temporal conv on the 16-bit path: its weight gradient also yields the source BatchNorm's backward sums
+        # (csrc/wgrad_cl16_t2.hip) -- on this stream, the sums are on the critical path; no reduce pass over g and x
+        dw, part = ctx.ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=True, out=dw_out, bnr=(src.mi, w))
+        ctx.grads[id(w)] = dw.view_as(w)
+        wt = r.wt if r.wt is not None else ctx.ops.conv_wt_transform(r.plan, w)
+        dx = ctx.ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out) if need_dx else None
+        return dx, part
     if ctx.wgrad_side:
         # the backward-data conv is on the critical path: it is enqueued first; the weight gradient starts on
         # the side stream as soon as dXout exists (event recorded before the dgrad launch)

@@ -256,6 +256,8 @@ class Plan16:
                                  kt, kh, kw, self.taps * self.Cin_p, mtiles, ntiles, ksl, kper], dtype=np.int32)
         assert len(self.g_wgrad) == C.slv_cl16_wgrad_words()
         self.ws_wgrad = C.slv_cl16_wgrad_ws_bytes(self.g_wgrad.ctypes.data, self.wm, self.wn)
+        # stride-1 (3,1,1) layers: the weight gradient that also yields the BatchNorm-backward sums of the layer it reads
+        self.ws_wgrad_bnr = 0 if stem else C.slv_cl16_wgrad_bnr_ws_bytes(self.g_wgrad.ctypes.data)
 
 
 def plan_for(xin, conv):
@@ -355,11 +357,40 @@ def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out
     return dx if bnr is None else (dx, part)
 
 
-def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, in_relu=False, out=None, patch=None):
-    """dw (fp32, [Cout][Cin*taps] = the reference layout flattened) from bf16 dy and act(x_in)."""
+# BatchNorm-backward sums from the temporal convs' weight gradient (conv_wgrad(bnr=...), csrc/wgrad_cl16_t2.hip): exact and
+# tested, OFF by default -- the column-order kernel is bound by its per-step load -> store -> barrier chain, not by HBM, so
+# forming the two products costs the layer-1 launches 1.24 -> 4.15 ms (3.70 ms as one 8-wave workgroup) against the
+# 1.4 ms reduce pass it replaces: cfg5 step 126 -> 137 ms (profiles/r03_notes.md).  SELAVI_CL16_WGRAD_BNR=1 switches it on.
+WGRAD_BNR = os.environ.get("SELAVI_CL16_WGRAD_BNR", "0") == "1"
+
+
+def wgrad_bnr_available(plan):
+    """Does conv_wgrad(..., bnr=...) take this layer (stride-1 (3,1,1), one batch slice)?"""
+    return plan.chunks is None and getattr(plan, "ws_wgrad_bnr", 0) > 0
+
+
+def wgrad_bnr_ok(plan):
+    """... and is it the engine's choice (SELAVI_CL16_WGRAD_BNR)?"""
+    return WGRAD_BNR and wgrad_bnr_available(plan)
+
+
+def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, in_relu=False, out=None, patch=None,
+               bnr=None):
+    """dw (fp32, [Cout][Cin*taps] = the reference layout flattened) from bf16 dy and act(x_in).
+    bnr = (mean_invstd of the BatchNorm behind in_ss, this conv's fp32 weights): the kernel forms the weight gradient from
+    the gradients against the masked raw activation and against the mask, which also gives that BatchNorm's backward
+    sums -> returns (dw, part [Cin][1][2]) for bn_bwd(part=...), no reduce pass over the gradient (csrc/wgrad_cl16_t2.hip)."""
     assert bwd5 is None and (in_ss is not None) == bool(in_relu)
     n_w = plan.Cin_w * plan.w_shape_taps
     dw = out if out is not None else torch.empty(plan.Cout, n_w, dtype=torch.float32, device=dy.device)
+    if bnr is not None:
+        assert wgrad_bnr_available(plan) and in_ss is not None
+        mi, w = bnr
+        part = torch.empty(plan.Cin, 1, 2, dtype=torch.float32, device=dy.device)
+        ws = _ops.workspace(plan.ws_wgrad_bnr, dy.device)
+        C.slv_cl16_wgrad_bnr(plan.g_wgrad.ctypes.data, ptr(dy), ptr(x_in), ptr(in_ss), ptr(mi), ptr(w.contiguous()), ptr(dw),
+                             ptr(part), plan.Cout, ptr(ws), plan.ws_wgrad_bnr, stream())
+        return dw, part
     if plan.stem:
         x_in = patch if patch is not None else _patch(plan, x_in)
     if plan.chunks is not None:

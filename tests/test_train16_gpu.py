@@ -142,6 +142,63 @@ def test_weight_gradient_matches_autograd(case):
     assert torch.equal(dw2, dw)                                      # fixed-order split-K: bit-reproducible
 
 
+
+@pytest.mark.parametrize("case", [(2, 144, 5, 10, 10, 64), (2, 144, 16, 4, 6, 64), (2, 45, 3, 9, 9, 64), (1, 64, 8, 8, 8, 230),
+                                  (1, 288, 4, 7, 7, 128), (3, 144, 3, 120, 120, 64)])
+def test_temporal_weight_gradient_yields_the_source_batchnorm_sums(case):
+    """conv_wgrad(bnr=...) on the stride-1 (3,1,1) convs (csrc/wgrad_cl16_t2.hip): dW = s G2 + h G1 from the gradients
+    against the masked raw activation (G2) and against the mask (G1), and the BatchNorm-backward sums of the layer the
+    conv reads as contractions of the same two tensors with the weights -- against fp64: the weight gradient of
+    relu(bn(y)), and sum g m / sum g m xhat of the exact backward-data gradient g."""
+    from selavi_amd import ops16
+    N, Cin, T, H, W, Cout = case
+    k, st, pd = (3, 1, 1), (1, 1, 1), (1, 0, 0)
+    gen = torch.Generator().manual_seed(Cin + 3 * Cout + T)
+    y = _bf(torch.randn(N, Cin, T, H, W, generator=gen))
+    ss = torch.stack([torch.rand(Cin, generator=gen) + 0.5, torch.randn(Cin, generator=gen) * 0.3]).contiguous()
+    mi = torch.stack([torch.randn(Cin, generator=gen) * 0.2, torch.rand(Cin, generator=gen) + 0.5]).contiguous()
+    w = torch.randn(Cout, Cin, *k, generator=gen) * (Cin * 3) ** -0.5
+    yc = _cl(y)
+    plan = ops16.plan_for(yc, _Conv(Cin, Cout, k, st, pd))
+    assert ops16.wgrad_bnr_available(plan)
+    dy = _bf(torch.randn(N, Cout, *plan.out_dims, generator=gen))
+    dyc = _cl(dy)
+    sv, hv = ss[0].view(1, -1, 1, 1, 1).double(), ss[1].view(1, -1, 1, 1, 1).double()
+    t = y.double() * sv + hv
+    mask = (t > 0).double()
+    a = (t * mask).requires_grad_(True)
+    out = F.conv3d(a, _bf(w).double(), stride=st, padding=pd)
+    (g,) = torch.autograd.grad(out, a, dy.double())                                    # exact backward data
+    wv = torch.zeros(Cout, Cin, *k, dtype=torch.float64, requires_grad=True)
+    (dw_want,) = torch.autograd.grad(F.conv3d(a.detach(), wv, stride=st, padding=pd), wv, dy.double())
+    gm = g * mask
+    xhat = (y.double() - mi[0].view(1, -1, 1, 1, 1).double()) * mi[1].view(1, -1, 1, 1, 1).double()
+    s1_want, s2_want = gm.sum((0, 2, 3, 4)), (gm * xhat).sum((0, 2, 3, 4))
+    l1 = gm.abs().sum((0, 2, 3, 4)) + 1e-30
+    l2 = (gm * y.double()).abs().sum((0, 2, 3, 4)) * mi[1].double() + mi[0].double().abs() * mi[1].double() * l1
+    ssd, mid, wd = ss.cuda(), mi.cuda(), w.cuda()
+    dw, part = ops16.conv_wgrad(plan, dyc, yc, in_ss=ssd, in_relu=True, bnr=(mid, wd))
+    got = dw.view(Cout, Cin, *k).double().cpu()
+    assert float((got - dw_want).abs().max()) <= 2e-5 * float(dw_want.abs().max())     # exact operands: fp32 summation only
+    p = part.double().cpu()
+    assert p.shape == (Cin, 1, 2)
+    assert float(((p[:, 0, 0] - s1_want).abs() / l1).max()) <= 2e-5, float(((p[:, 0, 0] - s1_want).abs() / l1).max())
+    assert float(((p[:, 0, 1] - s2_want).abs() / l2).max()) <= 2e-5, float(((p[:, 0, 1] - s2_want).abs() / l2).max())
+    # and against the path it replaces: the prologue weight gradient, and the reduce pass over the stored (bf16) gradient
+    dw_old = ops16.conv_wgrad(plan, dyc, yc, in_ss=ssd, in_relu=True)
+    assert float((dw_old.view_as(got).double().cpu() - dw_want).abs().max()) <= 2e-3 * float(dw_want.abs().max())
+    _, wt = ops16.conv_w_transform(plan, wd)
+    gc = ops16.conv_dgrad(plan, dyc, wt)
+    from selavi_amd._lib import C, ptr, stream
+    ns = C.slv_cl16_bn_bwd_nsplit(gc.numel() // gc.shape[-1], gc.shape[-1])
+    po = torch.empty(Cin, ns, 2, device="cuda")
+    C.slv_cl16_bn_bwd_reduce(ptr(gc), ptr(yc), ptr(mid), ptr(ssd), 0, 0, 0, 0, ptr(po), 0, gc.numel() // gc.shape[-1],
+                             Cin, gc.shape[-1], ns, stream())
+    po = po.double().sum(1).cpu()
+    assert float(((po[:, 0] - s1_want).abs() / l1).max()) <= 2e-3 and float(((po[:, 1] - s2_want).abs() / l2).max()) <= 2e-3
+    dw2, part2 = ops16.conv_wgrad(plan, dyc, yc, in_ss=ssd, in_relu=True, bnr=(mid, wd))
+    assert torch.equal(dw2, dw) and torch.equal(part2, part)                           # fixed-order sums: bit-reproducible
+
 @pytest.mark.parametrize("case", [(2, 144, 4, 14, 14, 64), (2, 64, 3, 28, 28, 144), (1, 256, 2, 7, 7, 460)])
 def test_patch_conv_kernels_are_bit_reproducible(case):
     """The same launch repeated gives the same bits: forward + statistics, backward data and weight gradient of the
