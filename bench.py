@@ -236,7 +236,7 @@ def sk_round_estimate(m, dev, world, step_clips_per_s, sk):
 
 CFG5 = dict(batch=128, T=32, S=112, F=129, Tp=100, K=309, hc=10)
 FWD_GFLOP_PER_CLIP_T32 = 162.08 + 0.506 + 0.0168      # SURVEY 8d, T = 32
-FWD_MB_PER_CLIP_T32_BF16 = 1036.2 / 2 + 3.38           # video bytes halve in bf16; the audio trunk stays fp32
+FWD_MB_PER_CLIP_T32_BF16 = 1036.2 / 2 + 3.38           # video bytes halve in bf16 (the audio trunk's 3.4 MB/clip are kept at the fp32 figure)
 PEAK_BF16_MFMA_TF = 2500.0
 
 
@@ -274,7 +274,7 @@ def hot_conv16_roofline(batch, T, dev):
 
 def bf16_leg(a, rank, world, local, dev):
     """BASELINE configs[4] ("cfg5"): large-batch stress on the 16-bit MFMA path -- per-GPU batch 128 x 32-frame clips
-    (global 1024 on 8 GPUs), video trunk in bf16 (fp32 master weights, fp32 BatchNorm statistics), audio + heads fp32."""
+    (global 1024 on 8 GPUs), both trunks in bf16 (fp32 master weights, fp32 BatchNorm statistics), heads fp32 (MFMA)."""
     import torch.distributed as dist
     from selavi_amd import model as smodel, optim, train
     B, T, hc, K = a.cfg5_batch, CFG5["T"], CFG5["hc"], CFG5["K"]
@@ -340,7 +340,7 @@ def bf16_leg(a, rank, world, local, dev):
         #  the pool's boxes: 7.8 s -- drags it down, the median does not)
         "value_from_median_step": world * B / ms_median * 1e3, "steps_over_2x_median": sum(v > 2 * ms_median for v in per_step),
         "dtype": "bf16",
-        "config": {"workload": "cfg5: R(2+1)D-18 in bf16 (fp32 master weights, fp32 BN statistics) + ResNet-9/heads fp32, "
+        "config": {"workload": "cfg5: R(2+1)D-18 + ResNet-9 in bf16 (fp32 master weights, fp32 BN statistics), heads fp32, "
                                "per-GPU bs=%d, 32x112x112 video, 1x129x100 log-mel, K=309, headcount=10" % B,
                    "global_batch": world * B, "parallelism": "dp%d" % world, "loss_last_step": loss_v,
                    "peak_hbm_gb": round(peak / 2 ** 30, 2)},

@@ -40,8 +40,8 @@ for k, d in list(res.items()):          # aliases bench.py looks up
         out["sk_pass"] = dict(d, kernel=k)
     if k.startswith("conv_cl16_sr_kernel<1, 1>") or ((k.startswith("conv_cl16_s3_kernel<9, 1, 1>") or k.startswith("conv_cl16_kernel<9, 1, 1>")) and "hot_conv16_fwd" not in out):
         out["hot_conv16_fwd"] = dict(d, kernel=k)          # layer-1 spatial train forward of the 16-bit path
-    if k.startswith("cl16_wgrad3_kernel<5, 1>") or (k.startswith("cl16_wgrad_kernel<5, 3, 1>") and "hot_conv16_wgrad" not in out):
-        out["hot_conv16_wgrad"] = dict(d, kernel=k)          # layer-1 spatial weight gradient (rolling-patch kernel)
+    if k.startswith("cl16_wgrad_acc_kernel<1>") or ((k.startswith("cl16_wgrad3_kernel<5, 1>") or k.startswith("cl16_wgrad_kernel<5, 3, 1>")) and "hot_conv16_wgrad" not in out):
+        out["hot_conv16_wgrad"] = dict(d, kernel=k)          # layer-1 spatial weight gradient (accumulator-resident kernel)
 json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 import shutil
 for tag in ("conv", "sk", "c16"):
