@@ -272,4 +272,11 @@ size_t wgrad_t2_ws_bytes(const ClWgradT& g, int wm);
 int wgrad_t2_launch(const ClWgradT& g, int wm, int nc, const void* dy, const void* x, const float* in_ss, const float* mi,
                     const float* w, float* dw, float* bn_part, int Cout, float* ws, hipStream_t st);
 
+// csrc/wgrad_cl16_tacc.hip: both products of the layer-1 temporal conv (144 -> 64) in the accumulators of one persistent
+// workgroup per CU; partials [2 kinds][blocks][64][3 * 160]
+bool wgrad_tacc_applies(const ClWgradT& g);
+int wgrad_tacc_blocks();
+int wgrad_tacc_launch(const ClWgradT& g, const void* dy, const void* x, const float* in_ss, float* part, size_t kind_stride,
+                      hipStream_t st);
+
 }  // namespace slv

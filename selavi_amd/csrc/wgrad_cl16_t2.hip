@@ -92,6 +92,12 @@ bool wgrad_t2_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, i
                    int pt, int ph, int pw, int To, int Ho, int Wo, int* wm, int* nc, ClWgradT* out) {
   if (!t2_enabled()) return false;
   if (!wgrad_t_plan(N, T, H, W, Cin_p, Cin, Cout_p, kt, kh, kw, st, sh, sw, pt, ph, pw, To, Ho, Wo, wm, nc, out)) return false;
+  // SELAVI_CL16_WGT2=all: also the layers only the two-workgroup column kernel takes (slower than the reduce pass it saves)
+  static const bool all = []() {
+    const char* e = getenv("SELAVI_CL16_WGT2");
+    return e && e[0] == 'a';
+  }();
+  if (!all && !wgrad_tacc_applies(*out)) return false;
   ClWgradT& g = *out;                       // one round of resident workgroups with two per unit: half the K slices
   const long long steps = (long long)N * g.PB * (T + 1);
   long long ksl = (g.kslices + 1) / 2;
@@ -101,22 +107,31 @@ bool wgrad_t2_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, i
   return true;
 }
 
-// workspace: [2 kinds][slices][rows][3 Cin_p] partials, then [2][Cout_p rows][3 Cin_p] sums
+// workspace: [2 kinds][slices][rows][3 Cin_p] partials, then [2][Cout_p rows][3 Cin_p] sums (slices: the K slices of the
+// column-order kernel, or the workgroups of the accumulator-resident kernel of the layer-1 shape: csrc/wgrad_cl16_tacc.hip)
 size_t wgrad_t2_ws_bytes(const ClWgradT& g, int wm) {
   const size_t rows = (size_t)g.mtiles * wm * 32;
-  return (2 * (size_t)g.kslices * rows + 2 * rows) * 3 * g.Cin_p * sizeof(float);
+  const size_t slices = wgrad_tacc_applies(g) ? (size_t)wgrad_tacc_blocks() : (size_t)g.kslices;
+  return (2 * slices * rows + 2 * rows) * 3 * g.Cin_p * sizeof(float);
 }
 
 int wgrad_t2_launch(const ClWgradT& g, int wm, int nc, const void* dy, const void* x, const float* in_ss, const float* mi,
                     const float* w, float* dw, float* bn_part, int Cout, float* ws, hipStream_t st) {
   const size_t rows = (size_t)g.mtiles * wm * 32, ncols = (size_t)3 * g.Cin_p;
-  const size_t slice_stride = rows * ncols, kind_stride = (size_t)g.kslices * slice_stride;
+  const bool tacc = wgrad_tacc_applies(g);
+  const int slices = tacc ? wgrad_tacc_blocks() : g.kslices;
+  const size_t slice_stride = rows * ncols, kind_stride = (size_t)slices * slice_stride;
   float* gsum = ws + 2 * kind_stride;
-  wgrad_t_launch_dual(g, wm, nc, dy, x, in_ss, ws, kind_stride, st);
-  int rc = launch_check("slv_cl16_wgrad_bnr");
+  int rc;
+  if (tacc) {
+    rc = wgrad_tacc_launch(g, dy, x, in_ss, ws, kind_stride, st);
+  } else {
+    wgrad_t_launch_dual(g, wm, nc, dy, x, in_ss, ws, kind_stride, st);
+    rc = launch_check("slv_cl16_wgrad_bnr");
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(cl16_wgrad_t2_sum_kernel, dim3((unsigned)((ncols + 255) / 256), Cout, 2), dim3(256), 0, st, ws, gsum, Cout,
-                     (unsigned)ncols, g.kslices, slice_stride, kind_stride);
+                     (unsigned)ncols, slices, slice_stride, kind_stride);
   rc = launch_check("slv_cl16_wgrad_bnr");
   if (rc) return rc;
   hipLaunchKernelGGL(cl16_wgrad_t2_finish_kernel, dim3(g.Cin), dim3(256), 0, st, gsum, w, in_ss, mi, dw, bn_part, Cout, g.Cin,

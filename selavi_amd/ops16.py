@@ -357,11 +357,12 @@ def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out
     return dx if bnr is None else (dx, part)
 
 
-# BatchNorm-backward sums from the temporal convs' weight gradient (conv_wgrad(bnr=...), csrc/wgrad_cl16_t2.hip): exact and
-# tested, OFF by default -- the column-order kernel is bound by its per-step load -> store -> barrier chain, not by HBM, so
-# forming the two products costs the layer-1 launches 1.24 -> 4.15 ms (3.70 ms as one 8-wave workgroup) against the
-# 1.4 ms reduce pass it replaces: cfg5 step 126 -> 137 ms (profiles/r03_notes.md).  SELAVI_CL16_WGRAD_BNR=1 switches it on.
-WGRAD_BNR = os.environ.get("SELAVI_CL16_WGRAD_BNR", "0") == "1"
+# BatchNorm-backward sums from the temporal convs' weight gradient (conv_wgrad(bnr=...), csrc/wgrad_cl16_t2.hip): ON for the
+# layers the accumulator-resident two-product kernel takes (csrc/wgrad_cl16_tacc.hip: the layer-1 shape 144 -> 64 with
+# >= 1 024 pixel columns; cfg5 step 124.8 -> 123.4 ms).  On the column-order kernel the two products cost more than the
+# reduce pass they replace (1.24 -> 4.15 ms per layer-1 launch): SELAVI_CL16_WGT2=all admits those layers too (tests).
+# SELAVI_CL16_WGRAD_BNR=0 switches the path off.
+WGRAD_BNR = os.environ.get("SELAVI_CL16_WGRAD_BNR", "1") == "1"
 
 
 def wgrad_bnr_available(plan):

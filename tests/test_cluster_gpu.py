@@ -92,7 +92,7 @@ def test_cluster_round_matches_oracle_reenactment(hc, K):
 def _ddp_worker(rank, world, port, ret, wrap=False, precision="fp32"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=300))
     try:
         from selavi_amd import model as smodel, optim, train
         torch.cuda.set_device(0)
@@ -268,7 +268,7 @@ def _cluster_worker(rank, world, port, hc, K, ret, match=True):
     import torch.distributed as dist
     if world > 1:
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=300))
     try:
         from selavi_amd import model as smodel, sk_utils
         from selavi_amd.data import SyntheticAVDataset

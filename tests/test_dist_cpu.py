@@ -23,7 +23,7 @@ class Args:
 
 def _worker(rank, world, port, N, K, scale, seed, gauss, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=300))
     try:
         from selavi_amd import sk_utils
         from tests._sk_double import NumpySkBackend
@@ -122,7 +122,7 @@ class _Node(torch.autograd.Function):
 
 def _sink_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=300))
     try:
         from selavi_amd.parallel import GradSink
         sink = GradSink()

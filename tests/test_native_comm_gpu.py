@@ -43,7 +43,7 @@ def _collectives_worker(rank, world, port, ret):
     import ctypes
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=300))
     try:
         torch.cuda.set_device(0)
         from selavi_amd import ops

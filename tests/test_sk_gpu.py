@@ -114,7 +114,7 @@ def test_roundtrip_properties_full_size():
 def _sharded_worker(rank, world, port, name, golden_dir, ret, want_native=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=300))
     try:
         from selavi_amd import sk_utils
         torch.cuda.set_device(0)

@@ -144,7 +144,11 @@ def test_weight_gradient_matches_autograd(case):
 
 
 @pytest.mark.parametrize("case", [(2, 144, 5, 10, 10, 64), (2, 144, 16, 4, 6, 64), (2, 45, 3, 9, 9, 64), (1, 64, 8, 8, 8, 230),
-                                  (1, 288, 4, 7, 7, 128), (3, 144, 3, 120, 120, 64)])
+                                  (1, 288, 4, 7, 7, 128), (3, 144, 3, 120, 120, 64),
+                                  # >= 1 024 columns of the layer-1 shape: both products in the accumulators of persistent
+                                  # workgroups (csrc/wgrad_cl16_tacc.hip): ragged last column (9 000 pixels), 4 or 5 columns
+                                  # per workgroup, 7 steps per column with the virtual frame
+                                  (4, 144, 6, 90, 100, 64)])
 def test_temporal_weight_gradient_yields_the_source_batchnorm_sums(case):
     """conv_wgrad(bnr=...) on the stride-1 (3,1,1) convs (csrc/wgrad_cl16_t2.hip): dW = s G2 + h G1 from the gradients
     against the masked raw activation (G2) and against the mask (G1), and the BatchNorm-backward sums of the layer the
