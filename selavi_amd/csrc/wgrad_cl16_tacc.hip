@@ -97,6 +97,10 @@ __global__ __launch_bounds__(256, 1) void cl16_wgrad_tacc_kernel(const unsigned 
     ps[i] = (tid < 240 && c < Cin) ? in_ss[c] : 0.f;
     ph[i] = (tid < 240 && c < Cin) ? in_ss[Cin + c] : 0.f;
   }
+  // (a use in front of the loop: otherwise the compiler's own s_waitcnt vmcnt(0) for these ONE-TIME loads lands in front of
+  //  their first use INSIDE the loop body, every iteration -- and drains the five steps of requests the pipeline keeps in flight)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(ps[i]), "v"(ph[i]));
   u32x4 xr[3][3];                                       // [register set][piece]: written by in-flight loads, hands off!
   unsigned xok = 0;                                     // bit set * 3 + i: that piece is inside the tensor
   auto x_load = [&](int S, int i, const TaStep& s) __attribute__((always_inline)) {      // S, i: compile time after inlining
@@ -113,11 +117,12 @@ __global__ __launch_bounds__(256, 1) void cl16_wgrad_tacc_kernel(const unsigned 
     if (d < 4) {
       const bool live = (xok >> (S * 3 + i)) & 1u;
       const unsigned v = xr[S][i][d];
-      const bool lo = SLV_TA_ABL == 1 ? live : live && bn_affine(bf_lo(v), ps[2 * d], ph[2 * d]) > 0.f;
-      const bool hi = SLV_TA_ABL == 1 ? live : live && bn_affine(bf_hi(v), ps[2 * d + 1], ph[2 * d + 1]) > 0.f;
+      // (no short-circuit "live && ...": hipcc turns it into a divergent branch per half; a dead piece's one is zeroed)
+      const bool lo = SLV_TA_ABL == 1 ? true : bn_affine(bf_lo(v), ps[2 * d], ph[2 * d]) > 0.f;
+      const bool hi = SLV_TA_ABL == 1 ? true : bn_affine(bf_hi(v), ps[2 * d + 1], ph[2 * d + 1]) > 0.f;
       const unsigned keep = (lo ? 0x0000FFFFu : 0u) | (hi ? 0xFFFF0000u : 0u);
-      xmy[d] = v & keep;
-      xm1[d] = 0x3F803F80u & keep;
+      xmy[d] = v & keep;                                 // (a request outside the tensor returned zeros)
+      xm1[d] = (live ? 0x3F803F80u : 0u) & keep;
     } else {
       const int px = spx + 12 * i;
       if (tid < 240 && px < 32) {
