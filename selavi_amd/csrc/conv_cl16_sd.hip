@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned sho
     const int p = k * 16 + spx;
     soff[k] = (unsigned)(((p >> 3) * W + (p & 7)) * (SD_COUT * 2) + hf * 64 + spiece * 16);
   }
-  constexpr int SD_ITEMS = 16 + 8 * RES;
+  constexpr int SD_ITEMS = 16;
   u32x4 carry = {0u, 0u, 0u, 0u};
   // the addend in accumulator layout: pixel nn * 16 + fr, channels (hf * 2 + i) * 16 + 4 fk .. + 3 (8 bytes)
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? res : y), 0, (int)(Ptot * (SD_COUT * 2u)), 0x00020000);
@@ -160,18 +160,19 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned sho
     aoff[nn] = (unsigned)(((p >> 3) * W + (p & 7)) * (SD_COUT * 2) + hf * 64 + fk * 8);
   }
   uint2 radd[8];
-  // items of the previous tile's epilogue, in order: [RES: 0-7 request the addend of accumulator tile it;] then one
-  // accumulator tile each (+ addend) -> bf16 -> stage; then store k = read its pieces, issue it
+  // RES: the addend of accumulator tile `it` (8 requests per tile), as INLINE ASM: the compiler must not count them -- its
+  // own s_waitcnt for a visible load (vmcnt(7..0): it does not see the patch DMAs) drained the 16 DMAs of the same tile a
+  // quarter into the tile instead of at its end (sd<1> 2.39 ms against sd<0> 2.05 ms in the cfg5 step).  They are issued
+  // in FRONT of the DMAs; a hand-counted s_waitcnt vmcnt(16) (this wave's DMA instructions) precedes the first use.
+  auto res_load = [&](int it, const SdTile& tl) __attribute__((always_inline)) {
+    const unsigned tb = (tl.fpos + (unsigned)(tl.y0 * W + tl.x0)) * (SD_COUT * 2u);
+    const unsigned voff = tl.live ? tb + aoff[it & 3] + (unsigned)((it >> 2) * 32) : 0xFFFFFFF0u;
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(radd[it]) : "v"(voff), "s"(rr) : "memory");
+  };
+  // items of the previous tile's epilogue, in order: one accumulator tile each (+ addend) -> bf16 -> stage; then store k =
+  // read its pieces, issue it
   auto drain_item = [&](int it0, f32x4 (&pv)[2][4], const SdTile& tl) __attribute__((always_inline)) {
     int it = it0;
-    if constexpr (RES == 1) {
-      if (it < 8) {
-        const unsigned tb = (tl.fpos + (unsigned)(tl.y0 * W + tl.x0)) * (SD_COUT * 2u);
-        radd[it] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rr, tl.live ? tb + aoff[it & 3] + (unsigned)((it >> 2) * 32) : 0xFFFFFFF0u, 0, 0));
-        return;
-      }
-      it -= 8;
-    }
     if (it < 8) {
       const int i = it >> 2, nn = it & 3;
       float v[4] = {pv[i][nn][0], pv[i][nn][1], pv[i][nn][2], pv[i][nn][3]};
@@ -223,8 +224,17 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned sho
             if (gi + 1 < 45) read_b(gi + 1, ph >> 1, b[(gi + 1) & 1]);
           } else {
             const int fs = gi * 4 + (ph >> 1);         // free-slot index within the tile
-            if (fs < SD_DMA) dma_item(fs, (n + 1) & 1);
-            else if (fs >= 20 && fs < 20 + 2 * SD_ITEMS && ((fs - 20) & 1) == 0 && drain) drain_item((fs - 20) >> 1, pv, tprev);
+            if constexpr (RES == 1) {
+              if (fs < 8) {
+                if (drain) res_load(fs, tprev);
+              } else if (fs < 8 + SD_DMA) dma_item(fs - 8, (n + 1) & 1);
+              else if (fs == 26) {
+                if (drain) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+              } else if (fs >= 28 && fs < 28 + 2 * SD_ITEMS && ((fs - 28) & 1) == 0 && drain) drain_item((fs - 28) >> 1, pv, tprev);
+            } else {
+              if (fs < SD_DMA) dma_item(fs, (n + 1) & 1);
+              else if (fs >= 20 && fs < 20 + 2 * SD_ITEMS && ((fs - 20) & 1) == 0 && drain) drain_item((fs - 20) >> 1, pv, tprev);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -246,6 +256,12 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned sho
   if (nst > 0) {                                      // the last tile's epilogue
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     const SdTile tl = tile_of(nst - 1);
+    if constexpr (RES == 1) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) res_load(it, tl);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);          // (the asm orders memory operations only: pin the register uses behind it)
+    }
     if ((nst - 1) & 1) {
 #pragma unroll
       for (int it = 0; it < SD_ITEMS; ++it) drain_item(it, accB, tl);

@@ -116,7 +116,13 @@ __global__ __launch_bounds__(256, 1) void cl16_wgrad_acc_kernel(const unsigned s
     const bool ok = (((xflags >> (8 * i)) & 63u) & t.tm) == 0u;
     xok = (xok & ~(1u << i)) | ((unsigned)ok << i);
     if (SLV_WA_ABL == 3 || SLV_WA_ABL == 4) xr[i] = (u32x4){t.xbase, 1u, 2u, 3u};
-    else xr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? t.xbase + xoff[i] : 0xFFFFFFF0u, 0, 0));
+    else {
+      // inline asm: the compiler must not count these requests -- its own s_waitcnt for them (vmcnt(3..0), it does not see the
+      // DMAs issued behind them) would drain the dY DMAs of the same tile at 60 % of the tile instead of at its end; the
+      // hand-counted wait sits in front of the first staging item
+      const unsigned voff = ok ? t.xbase + xoff[i] : 0xFFFFFFF0u;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(xr[i]) : "v"(voff), "s"(rx) : "memory");
+    }
   };
   u32x4 xo;
   // staging items of piece i: d = 0..3 one dword (two channels) each, d = 4 the store
@@ -214,7 +220,11 @@ __global__ __launch_bounds__(256, 1) void cl16_wgrad_acc_kernel(const unsigned s
             const int fs = ks * 63 + t * 7 + (cot - 2);
             if (fs < 4) x_load(fs, tf);
             else if (fs < 10) y_dma(fs - 4, bf, tf);
-            else if (fs >= 80 && fs < 120 && ((fs - 80) & 1) == 0) x_item((fs - 80) / 10, ((fs - 80) >> 1) % 5, bf);
+            else if (fs == 78) {                       // the four X requests have arrived; this wave's DMAs behind them may fly
+              if (SLV_WA_ABL == 2 || SLV_WA_ABL == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              else if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else if (fs >= 80 && fs < 120 && ((fs - 80) & 1) == 0) x_item((fs - 80) / 10, ((fs - 80) >> 1) % 5, bf);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -234,6 +244,8 @@ __global__ __launch_bounds__(256, 1) void cl16_wgrad_acc_kernel(const unsigned s
       for (int i = 0; i < 4; ++i) x_load(i, t);
 #pragma unroll
       for (int j = 0; j < 6; ++j) y_dma(j, b, t);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);          // (the asm orders memory operations only: pin the register uses behind it)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, 1) void cl16_wgrad_tacc_kernel(const unsigned 
 #pragma unroll
     for (int j = 0; j < 2; ++j) y_dma(j, 1, s1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);            // (the asm orders memory operations only: pin the register uses behind it)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
