@@ -361,6 +361,16 @@ int slv_cl16_conv(const int32_t* clconv, int mt, const void* x_bf16, const void*
                   float* stat_sum, float* stat_sq, const void* bnr_x_bf16 /* nullable: no fused reduction */,
                   const float* bnr_scale_shift /* [2][Cout] */, const float* bnr_mean_invstd /* [2][Cout] */,
                   float* bnr_part /* [Cout][bnr_nslots][2] */, int bnr_slot0, int bnr_nslots, slv_stream_t stream);
+/* Backward data of a stride-1 (3,1,1) conv with the BatchNorm-backward APPLY of the layer it feeds folded into its epilogue
+ * (main.py:296-299): out = A1 * mask * g + A2 + A3 * x with g = this conv's gradient as it would have been stored (bf16),
+ * x = src_x (raw output of the layer that produced this conv's input, same positions), mask = [x s + h > 0],
+ * bwd5 = {s, h, A1, A2, A3}[Cout] as slv_cl16_bn_bwd_apply takes them -- bit for bit what that pass makes of the stored g,
+ * without the pass (possible when the coefficients are known beforehand: slv_cl16_wgrad_bnr).  clconv: a backward-data
+ * launch description; slv_cl16_conv_dgrad_bn_apply_ok says whether this path takes it (the register-resident column
+ * kernel of the 64 -> 144 layer, csrc/conv_cl16_tr.hip). */
+int32_t slv_cl16_conv_dgrad_bn_apply_ok(const int32_t* clconv);
+int slv_cl16_conv_dgrad_bn_apply(const int32_t* clconv, const void* dy_bf16, const void* w_layout_bf16, void* out_bf16,
+                                 const void* src_x_bf16, const float* bwd5, slv_stream_t stream);
 int slv_cl16_w_transform(const float* w, void* wf_bf16, void* wt_bf16, int Cout, int Cin, int taps, int Cin_p,
                          int Cout_p, int mrows_fwd, int mrows_dgrad, int patch_kw, slv_stream_t stream);
 int32_t slv_cl16_wgrad_words(void);

@@ -218,6 +218,8 @@ int cl16_tr_columns(const ClConv& g);            // statistics partials per chan
 bool cl16_tr_forward(const ClConv& g);
 int cl16_tr_try(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, const float* scale_shift,
                 const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr, hipStream_t st);
+bool cl16_tr_dgrad_apply_ok(const ClConv& g);    // backward data 64 -> 144 with the BatchNorm-backward apply in its epilogue
+int cl16_tr_dgrad_apply(const ClConv& g, const void* x, const void* wl, void* y, const void* ax, const float* ab5, hipStream_t st);
 
 // csrc/conv_cl16_sr.hip: the layer-1 spatial conv 64 -> 144 (1,3,3), weights resident in registers, three MFMA waves + one
 // data-movement wave per workgroup, persistent over 8 x 8-pixel tiles

@@ -477,6 +477,24 @@ int slv_conv_cl16_fwd(const int32_t* geom, int mt, const void* x_bf16, const voi
 int32_t slv_cl16_conv_words(void) { return slv::CLC_WORDS; }
 int32_t slv_cl16_conv_nblk(const int32_t* clconv);
 
+int32_t slv_cl16_conv_dgrad_bn_apply_ok(const int32_t* clconv) {
+  if (!clconv) return 0;
+  slv::ClConv g;
+  memcpy(&g, clconv, sizeof(g));
+  return slv::cl16_tr_dgrad_apply_ok(g) ? 1 : 0;
+}
+
+int slv_cl16_conv_dgrad_bn_apply(const int32_t* clconv, const void* dy_bf16, const void* w_layout_bf16, void* out_bf16,
+                                 const void* src_x_bf16, const float* bwd5, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(clconv && dy_bf16 && w_layout_bf16 && out_bf16 && src_x_bf16 && bwd5, "null pointer");
+  ClConv g;
+  memcpy(&g, clconv, sizeof(g));
+  SLV_CHECK_ARG(cl16_tr_dgrad_apply_ok(g), "not a launch this path takes (slv_cl16_conv_dgrad_bn_apply_ok)");
+  const int rc = cl16_tr_dgrad_apply(g, dy_bf16, w_layout_bf16, out_bf16, src_x_bf16, bwd5, (hipStream_t)stream);
+  return rc == 1 ? 0 : (rc ? rc : -1);
+}
+
 int slv_cl16_conv(const int32_t* clconv, int mt, const void* x_bf16, const void* w_layout_bf16, void* y_bf16,
                   const float* in_scale_shift, const float* scale_shift, const void* res_bf16, int relu,
                   float* stat_sum, float* stat_sq, const void* bnr_x_bf16, const float* bnr_scale_shift,

@@ -61,14 +61,20 @@ __device__ __forceinline__ void tr_mfma_settle() {
 
 // MT: 16-row tiles of output channels (all of them: Mrows == 16 MT); KC: 32-channel chunks of the input (Cin_p / 32).
 // PRO 1: rows are read as relu(x * s + h).  EPI 0: y = acc -> bf16.  EPI 1: + per-channel sum / sum of squares of the
-// rounded outputs, one partial per column: stat_sum / stat_sq [Cout][ncol].
+// rounded outputs, one partial per column: stat_sum / stat_sq [Cout][ncol].  EPI 3 (backward data whose BatchNorm-backward
+// coefficients are known BEFORE it runs -- they come out of the weight gradient, csrc/wgrad_cl16_t2.hip): the stored
+// value is A1 * mask * g + A2 + A3 * x with g = the rounded gradient, x = ax (raw output of the layer this conv read, same
+// positions), mask = [x s + h > 0], ab5 = {s, h, A1, A2, A3}[Cout] -- what slv_cl16_bn_bwd_apply would make of the stored g
+// in a pass of its own (read g, read x, write), bit for bit.
 template <int MT, int KC, int PRO, int EPI>
 __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned short* __restrict__ x,
                                                             const unsigned short* __restrict__ wl,
                                                             unsigned short* __restrict__ y,
                                                             const float* __restrict__ in_ss,
                                                             float* __restrict__ stat_sum, float* __restrict__ stat_sq,
-                                                            ClConv g, int ncol, int pbn) {
+                                                            ClConv g, int ncol, int pbn,
+                                                            const unsigned short* __restrict__ ax,
+                                                            const float* __restrict__ ab5) {
   constexpr int PPR = KC * 4;                         // 16-byte pieces per input row
   constexpr int RPI = 64 / PPR;                       // input rows one load instruction covers
   constexpr int NIT = (TR_PX + RPI - 1) / RPI;
@@ -123,6 +129,20 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
   const int oppr = g.Cout_p >> 3, orpi = 64 / oppr;
   const int opiece = lane % oppr, olr = lane / oppr;
   const bool oact = lane < orpi * oppr;
+  float e_s[8], e_h[8], e_a1[8], e_a2[8], e_a3[8];
+  if constexpr (EPI == 3) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = opiece * 8 + e;
+      const bool ok = oact && c < g.Cout;
+      e_s[e] = ok ? ab5[c] : 0.f;
+      e_h[e] = ok ? ab5[g.Cout + c] : 0.f;
+      e_a1[e] = ok ? ab5[2 * g.Cout + c] : 0.f;
+      e_a2[e] = ok ? ab5[3 * g.Cout + c] : 0.f;
+      e_a3[e] = ok ? ab5[4 * g.Cout + c] : 0.f;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rax = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 3 ? ax : x), 0, (int)(Ptot * out_row), 0x00020000);
 
   // zero the output stage once: the channel pieces beyond the accumulator tiles (Cout_p > 16 MT) stay zero
   for (int i = lane * 16; i < TR_PX * orow; i += 64 * 16) *(u32x4*)(ost + i) = (u32x4){0u, 0u, 0u, 0u};
@@ -268,7 +288,23 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
       for (int r0 = 0; r0 < TR_PX; r0 += orpi) {      // (out-of-range offsets drop the store: no branches)
         const int r = r0 + olr;
         const bool ok = oact && r < TR_PX && cc.px0 + r < HW;
-        const u32x4 v = *(const u32x4*)(ost + (r < TR_PX ? r : 0) * orow + opiece * 16);
+        u32x4 v = *(const u32x4*)(ost + (r < TR_PX ? r : 0) * orow + opiece * 16);
+        if constexpr (EPI == 3) {
+          const u32x4 xv = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rax, ok ? obase + (unsigned)r * out_row : 0xFFFFFFF0u, 0, 0));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float o2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int k = 2 * i + e;
+              const float xx = e ? bf_hi(xv[i]) : bf_lo(xv[i]);
+              float gg = e ? bf_hi(v[i]) : bf_lo(v[i]);
+              if (!(bn_affine(xx, e_s[k], e_h[k]) > 0.f)) gg = 0.f;
+              o2[e] = e_a1[k] * gg + e_a2[k] + e_a3[k] * xx;     // (the expression of cl16_bn_bwd_apply_kernel)
+            }
+            v[i] = pack_bf2(o2[0], o2[1]);
+          }
+        }
         __builtin_amdgcn_raw_buffer_store_b128(v, ry, ok ? obase + (unsigned)r * out_row : 0xFFFFFFF0u, 0, 0);
       }
     }
@@ -339,7 +375,7 @@ bool cl16_tr_forward(const ClConv& g) { return (g.tap[0] & 15) - 8 + g.bot < 0; 
 
 template <int MT, int KC, int PRO, int EPI>
 static int tr_launch_one(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, float* stat_sum,
-                         float* stat_sq, hipStream_t st) {
+                         float* stat_sq, hipStream_t st, const void* ax = nullptr, const float* ab5 = nullptr) {
   const size_t lds = 3 * (size_t)KC * TR_PX * 64 + (size_t)TR_PX * (g.Cout_p * 2 + 16) + 1024;
   static bool attr_set = false;
   if (!attr_set) {
@@ -356,8 +392,23 @@ static int tr_launch_one(const ClConv& g, const void* x, const void* wl, void* y
   const int waves = waves_env > 0 ? waves_env : (MT * KC * 3 <= 24 ? 2048 : 1024);
   const int grid = ncol < waves ? ncol : waves;
   hipLaunchKernelGGL((conv_cl16_tr_kernel<MT, KC, PRO, EPI>), dim3(grid), dim3(64), lds, st, (const unsigned short*)x,
-                     (const unsigned short*)wl, (unsigned short*)y, in_ss, stat_sum, stat_sq, g, ncol, pbn);
+                     (const unsigned short*)wl, (unsigned short*)y, in_ss, stat_sum, stat_sq, g, ncol, pbn,
+                     (const unsigned short*)ax, ab5);
   return 0;
+}
+
+// backward data of the layer-1 temporal conv (64 -> 144 stored channels) with the BatchNorm-backward apply of the layer in
+// front folded into its epilogue (EPI 3)
+bool cl16_tr_dgrad_apply_ok(const ClConv& g) {
+  return cl16_tr_applies(g) && !cl16_tr_forward(g) && g.Mrows / 16 == 9 && g.Cin_p / 32 == 2;
+}
+
+int cl16_tr_dgrad_apply(const ClConv& g, const void* x, const void* wl, void* y, const void* ax, const float* ab5, hipStream_t st) {
+  if (!cl16_tr_dgrad_apply_ok(g)) return 0;
+  int rc = tr_launch_one<9, 2, 0, 3>(g, x, wl, y, nullptr, nullptr, nullptr, st, ax, ab5);
+  if (rc) return rc;
+  rc = launch_check("slv_cl16_conv_dgrad_bn_apply");
+  return rc ? rc : 1;
 }
 
 // returns 1 when the launch was taken, 0 when it does not apply (epilogues this kernel does not have: affine, residual,

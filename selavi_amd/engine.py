@@ -128,12 +128,14 @@ def tail(ctx, r, res=None, res_raw=None, relu=True):
     return ctx.ops.bn_act(r.y, r.ss, res=res, relu=relu)
 
 
-def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, keep_g=False, fuse_bn=False):
+def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, keep_g=False, fuse_bn=False, applied=False):
     """Backward through conv `r.conv` given the gradient `g` w.r.t. the ACTIVATED output of r's BN
     (or the masked tail gradient when a_relu is False) and its folded BN-backward coefficients.
     Writes the weight gradient; returns the gradient w.r.t. the conv input (activated, if the
     source is itself Raw) or None.  fuse_bn (source is Raw, consumed through its own ReLU): the dgrad
-    epilogue also forms the source BN's backward partial sums -> returns (dx, part) for bn_bwd_own."""
+    epilogue also forms the source BN's backward partial sums -> returns (dx, part) for bn_bwd_own.
+    applied: g already IS the gradient w.r.t. r's raw output (the backward-data conv that produced it applied r's BatchNorm
+    backward in its epilogue).  When this conv can do the same for ITS source it returns (dx, ("applied", b5 of the source))."""
     src = r.src
     if isinstance(src, Raw):
         xin, in_ss = src.y, src.ss
@@ -142,7 +144,7 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
     # materialise dXout once (in place over g, which is dead afterwards unless it doubles as the
     # residual addend) and feed plain tensors to both GEMMs (1.8x faster than folding the BN backward
     # into the wgrad/dgrad operand loaders, which is what round 1 started with)
-    dxo = ctx.ops.bn_bwd_apply(g, r.y, b5, a_relu, out=torch.empty_like(g) if (keep_g or addend is g) else None)
+    dxo = g if applied else ctx.ops.bn_bwd_apply(g, r.y, b5, a_relu, out=torch.empty_like(g) if (keep_g or addend is g) else None)
 
     def dgrad():
         wt = r.wt if r.wt is not None else ctx.ops.conv_wt_transform(r.plan, r.conv.weight)
@@ -167,6 +169,12 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
         dw, part = ctx.ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=True, out=dw_out, bnr=(src.mi, w))
         ctx.grads[id(w)] = dw.view_as(w)
         wt = r.wt if r.wt is not None else ctx.ops.conv_wt_transform(r.plan, w)
+        if need_dx and addend is None and getattr(ctx.ops, "dgrad_apply_ok", None) is not None and ctx.ops.dgrad_apply_ok(r.plan):
+            # the source BatchNorm's backward coefficients exist before its gradient does: the backward-data conv applies
+            # them in its epilogue and stores the gradient w.r.t. the source's RAW output (no bn_bwd_apply pass)
+            b5_src = bn_bwd_own(ctx, src, None, part)
+            dx = ctx.ops.conv_dgrad(r.plan, dxo, wt, out=out, bn_apply=(src.y, b5_src))
+            return dx, ("applied", b5_src)
         dx = ctx.ops.conv_dgrad(r.plan, dxo, wt, addend=addend, out=out) if need_dx else None
         return dx, part
     if ctx.wgrad_side:
@@ -242,19 +250,23 @@ def block_bwd(ctx, rec, dv, need_du=True):
     ctx.grads[id(last.bn.bias)] = db
     g, a_relu = dz, False
     n = len(rec.chain)
+    applied = False                  # g is already the gradient w.r.t. the conv's raw output (fused into the producer)
     for i in range(n - 1, -1, -1):
         r = rec.chain[i]
         if i > 0:
             g, part = backprop_raw(ctx, r, g, b5, a_relu, keep_g=(i == n - 1),  # dz is reused by the shortcut
-                                   fuse_bn=True)
-            b5 = bn_bwd_own(ctx, rec.chain[i - 1], g, part)
+                                   fuse_bn=True, applied=applied)
+            if isinstance(part, tuple):
+                b5, applied = part[1], True
+            else:
+                b5, applied = bn_bwd_own(ctx, rec.chain[i - 1], g, part), False
             a_relu = True
         else:
             if ds is not None:
-                du = backprop_raw(ctx, r, g, b5, a_relu, need_dx=need_du, keep_g=(n == 1))
+                du = backprop_raw(ctx, r, g, b5, a_relu, need_dx=need_du, keep_g=(n == 1), applied=applied)
                 du = backprop_raw(ctx, ds, dz, b5ds, False, need_dx=need_du, addend=du, out=du)
             else:
-                du = backprop_raw(ctx, r, g, b5, a_relu, need_dx=need_du, addend=dz)
+                du = backprop_raw(ctx, r, g, b5, a_relu, need_dx=need_du, addend=dz, applied=applied)
             return du
 
 

@@ -244,6 +244,8 @@ class Plan16:
                                                 (Ti, Hi, Wi), self.Cin, self.Cin_p, (st, sh, sw), (ct, ch, cw),
                                                 self.mrows_d, tp))
         self.dgrad_nblk = [C.slv_cl16_conv_nblk(g_.ctypes.data) for g_ in self.g_dgrad]     # position tiles per class
+        # backward data with the source layer's BatchNorm-backward apply in its epilogue (conv_dgrad(bn_apply=...))
+        self.dgrad_apply_ok = len(self.g_dgrad) == 1 and bool(C.slv_cl16_conv_dgrad_bn_apply_ok(self.g_dgrad[0].ctypes.data))
         self.bnr_slots = sum(self.dgrad_nblk)
         # ---- weight gradient: M = Cout_p, N = taps * Cin_p, K = output positions
         self.wm, self.wn = _pick_w(self.Cout_p), _pick_w(self.taps * self.Cin_p)
@@ -328,12 +330,33 @@ def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True, wf=None, ou
     return y, ssum, ssq
 
 
-def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out=None, bnr=None):
+# the BatchNorm-backward apply in the epilogue of the backward-data conv that produces the gradient (conv_dgrad(bn_apply=...),
+# csrc/conv_cl16_tr.hip EPI 3): bit-exact and tested, OFF by default -- the one-wave column kernel runs the epilogue's ~550
+# VALU instructions and its x loads behind its MFMAs, not beside them: 3.83 ms per launch against 1.10 + 2.62 ms of the two
+# passes it replaces (cfg5 step unchanged).  SELAVI_CL16_DGRAD_APPLY=1 switches it on.
+DGRAD_APPLY = os.environ.get("SELAVI_CL16_DGRAD_APPLY", "0") == "1"
+
+
+def dgrad_apply_ok(plan):
+    """Does conv_dgrad(..., bn_apply=...) take this layer (and is it switched on)?"""
+    return DGRAD_APPLY and plan.chunks is None and getattr(plan, "dgrad_apply_ok", False)
+
+
+def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out=None, bnr=None, bn_apply=None):
     """dx = conv_transpose(dy) (+ addend): the forward kernel on the transposed weights, one launch per parity class.
     bnr = (x, scale_shift, mean_invstd) of the layer that produced this conv's input: the epilogue also emits that
-    BatchNorm's backward partial sums and (dx, part) is returned -- pass ``part`` to bn_bwd."""
+    BatchNorm's backward partial sums and (dx, part) is returned -- pass ``part`` to bn_bwd.
+    bn_apply = (x, bwd5) of that layer when its BatchNorm-backward coefficients are known already (conv_wgrad(bnr=...)): the
+    epilogue stores bn_bwd_apply(dx, x, bwd5, relu=True) -- the gradient w.r.t. that layer's RAW output -- bit for bit what
+    the separate pass makes of the stored dx."""
     assert bwd5 is None and not plan.stem
     dx = out if out is not None else _bf16(*plan.in_shape, device=dy.device)
+    if bn_apply is not None:
+        assert plan.chunks is None and plan.dgrad_apply_ok and addend is None and bnr is None
+        sx, b5 = bn_apply
+        assert sx.shape == dx.shape and b5.shape == (5, plan.Cin)
+        C.slv_cl16_conv_dgrad_bn_apply(plan.g_dgrad[0].ctypes.data, ptr(dy), ptr(wt), ptr(dx), ptr(sx), ptr(b5), stream())
+        return dx
     if plan.chunks is not None:
         parts = []
         for b0, b1, sub in plan.chunks:

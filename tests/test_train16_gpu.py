@@ -203,6 +203,30 @@ def test_temporal_weight_gradient_yields_the_source_batchnorm_sums(case):
     dw2, part2 = ops16.conv_wgrad(plan, dyc, yc, in_ss=ssd, in_relu=True, bnr=(mid, wd))
     assert torch.equal(dw2, dw) and torch.equal(part2, part)                           # fixed-order sums: bit-reproducible
 
+
+@pytest.mark.parametrize("case", [(2, 144, 5, 10, 10, 64), (2, 144, 16, 4, 6, 64), (3, 144, 3, 120, 120, 64)])
+def test_backward_data_with_the_batchnorm_apply_in_its_epilogue(case):
+    """conv_dgrad(bn_apply=(x, bwd5)) of the layer-1 temporal conv (csrc/conv_cl16_tr.hip, EPI 3): bit for bit what
+    bn_bwd_apply makes of the separately stored backward-data output."""
+    from selavi_amd import ops16
+    N, Cin, T, H, W, Cout = case
+    k, st, pd = (3, 1, 1), (1, 1, 1), (1, 0, 0)
+    gen = torch.Generator().manual_seed(7 * Cin + Cout + T)
+    xs = _cl(_bf(torch.randn(N, Cin, T, H, W, generator=gen)))              # raw output of the layer in front
+    plan = ops16.plan_for(xs, _Conv(Cin, Cout, k, st, pd))
+    assert plan.dgrad_apply_ok
+    w = (torch.randn(Cout, Cin, *k, generator=gen) * (Cin * 3) ** -0.5).cuda()
+    _, wt = ops16.conv_w_transform(plan, w)
+    dy = _cl(_bf(torch.randn(N, Cout, *plan.out_dims, generator=gen)))
+    b5 = torch.stack([torch.rand(Cin, generator=gen) + 0.5, torch.randn(Cin, generator=gen) * 0.3,
+                      torch.rand(Cin, generator=gen) + 0.2, torch.randn(Cin, generator=gen) * 0.05,
+                      torch.randn(Cin, generator=gen) * 0.1]).contiguous().cuda()
+    g = ops16.conv_dgrad(plan, dy, wt)
+    want = ops16.bn_bwd_apply(g.clone(), xs, b5, True)
+    got = ops16.conv_dgrad(plan, dy, wt, bn_apply=(xs, b5))
+    assert torch.equal(got, want)
+    assert (got[..., Cin:] == 0).all()
+
 @pytest.mark.parametrize("case", [(2, 144, 4, 14, 14, 64), (2, 64, 3, 28, 28, 144), (1, 256, 2, 7, 7, 460)])
 def test_patch_conv_kernels_are_bit_reproducible(case):
     """The same launch repeated gives the same bits: forward + statistics, backward data and weight gradient of the
