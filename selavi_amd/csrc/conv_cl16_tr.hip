@@ -227,6 +227,20 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
   auto step = [&](u32x4* cur, unsigned& vcur, u32x4* nxt, unsigned& vnxt) __attribute__((always_inline)) {
     load_frame(pf, nxt, vnxt);                        // two frames in flight behind this step's MFMAs
     advance(pf);
+    // EPI 3: the x pieces this step's epilogue needs (160 stored channels: 3 rows per instruction, 11 instructions) are
+    // requested HERE, in front of the step's MFMAs (requested inside the store loop they cost one memory round trip each:
+    // 3.83 ms per launch)
+    constexpr int E3_NOIT = (TR_PX + 2) / 3;
+    u32x4 yv[EPI == 3 ? E3_NOIT : 1];
+    if constexpr (EPI == 3) {
+      const unsigned ob3 = (cc.pos0 + (unsigned)cc.t * HW) * out_row + opiece * 16u;
+#pragma unroll
+      for (int q = 0; q < E3_NOIT; ++q) {
+        const int r = 3 * q + olr;
+        const bool ok = oact && r < TR_PX && cc.px0 + r < HW;
+        yv[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rax, ok ? ob3 + (unsigned)r * out_row : 0xFFFFFFF0u, 0, 0));
+      }
+    }
     const int sprev = slot == 0 ? 2 : slot - 1, snext = slot == 2 ? 0 : slot + 1;
     f32x4 acc[MT][2];
     int pi = 0;                                       // next staged piece to get its BatchNorm + ReLU
@@ -285,12 +299,13 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
     }
     {
       const unsigned obase = (cc.pos0 + (unsigned)cc.t * HW) * out_row + opiece * 16u;
-      for (int r0 = 0; r0 < TR_PX; r0 += orpi) {      // (out-of-range offsets drop the store: no branches)
-        const int r = r0 + olr;
-        const bool ok = oact && r < TR_PX && cc.px0 + r < HW;
-        u32x4 v = *(const u32x4*)(ost + (r < TR_PX ? r : 0) * orow + opiece * 16);
-        if constexpr (EPI == 3) {
-          const u32x4 xv = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rax, ok ? obase + (unsigned)r * out_row : 0xFFFFFFF0u, 0, 0));
+      if constexpr (EPI == 3) {
+#pragma unroll
+        for (int q = 0; q < E3_NOIT; ++q) {
+          const int r = 3 * q + olr;
+          const bool ok = oact && r < TR_PX && cc.px0 + r < HW;
+          u32x4 v = *(const u32x4*)(ost + (r < TR_PX ? r : 0) * orow + opiece * 16);
+          const u32x4 xv = yv[q];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float o2[2];
@@ -304,8 +319,15 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
             }
             v[i] = pack_bf2(o2[0], o2[1]);
           }
+          __builtin_amdgcn_raw_buffer_store_b128(v, ry, ok ? obase + (unsigned)r * out_row : 0xFFFFFFF0u, 0, 0);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(v, ry, ok ? obase + (unsigned)r * out_row : 0xFFFFFFF0u, 0, 0);
+      } else {
+        for (int r0 = 0; r0 < TR_PX; r0 += orpi) {    // (out-of-range offsets drop the store: no branches)
+          const int r = r0 + olr;
+          const bool ok = oact && r < TR_PX && cc.px0 + r < HW;
+          const u32x4 v = *(const u32x4*)(ost + (r < TR_PX ? r : 0) * orow + opiece * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, ry, ok ? obase + (unsigned)r * out_row : 0xFFFFFFF0u, 0, 0);
+        }
       }
     }
     if constexpr (EPI == 1) {

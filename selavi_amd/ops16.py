@@ -323,18 +323,22 @@ def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True, wf=None, ou
     y = out if out is not None else _bf16(*plan.out_shape, device=x.device)
     ssum = ssq = None
     if want_stats:
-        ssum = torch.empty(plan.Cout, plan.nblk, dtype=torch.float32, device=x.device)
-        ssq = torch.empty_like(ssum)
+        if os.environ.get("SELAVI_DIAG_ZERO_STATS") == "1":          # diagnostic: are there partial slots no block writes?
+            ssum = torch.zeros(plan.Cout, plan.nblk, dtype=torch.float32, device=x.device)
+            ssq = torch.zeros_like(ssum)
+        else:
+            ssum = torch.empty(plan.Cout, plan.nblk, dtype=torch.float32, device=x.device)
+            ssq = torch.empty_like(ssum)
     C.slv_cl16_conv(plan.g_fwd.ctypes.data, plan.mt_f, ptr(x), ptr(wf), ptr(y), ptr(in_ss), 0, 0, 0, ptr(ssum), ptr(ssq),
                     0, 0, 0, 0, 0, 0, stream())
     return y, ssum, ssq
 
 
 # the BatchNorm-backward apply in the epilogue of the backward-data conv that produces the gradient (conv_dgrad(bn_apply=...),
-# csrc/conv_cl16_tr.hip EPI 3): bit-exact and tested, OFF by default -- the one-wave column kernel runs the epilogue's ~550
-# VALU instructions and its x loads behind its MFMAs, not beside them: 3.83 ms per launch against 1.10 + 2.62 ms of the two
-# passes it replaces (cfg5 step unchanged).  SELAVI_CL16_DGRAD_APPLY=1 switches it on.
-DGRAD_APPLY = os.environ.get("SELAVI_CL16_DGRAD_APPLY", "0") == "1"
+# csrc/conv_cl16_tr.hip EPI 3): bit-exact against the separate pass; the x pieces are requested in front of the step's MFMAs
+# (requested inside the store loop: one memory round trip each, 3.83 ms per launch = no gain).  cfg5 step 122.3 -> 114.6 ms.
+# SELAVI_CL16_DGRAD_APPLY=0 switches it off.
+DGRAD_APPLY = os.environ.get("SELAVI_CL16_DGRAD_APPLY", "1") == "1"
 
 
 def dgrad_apply_ok(plan):
