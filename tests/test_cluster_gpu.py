@@ -117,7 +117,8 @@ def _ddp_worker(rank, world, port, ret, wrap=False, precision="fp32"):
         if wrap:      # several steps (DDP rebuilds its buckets after the first), then hash the whole state
             first = float(loss)
             from selavi_amd import ops as _o
-            for _ in range(2):
+            ex0 = _o.EXCHANGES[0]
+            for _ in range(int(os.environ.get("SELAVI_DIAG_EXTRA_STEPS", "2"))):      # (diagnostic: 0 = hash after ONE step)
                 ex0 = _o.EXCHANGES[0]
                 loss = train.train_step(net, opt, video, audio, sl, sel, hc)
             exchanges = _o.EXCHANGES[0] - ex0                   # SyncBN exchanges of one step
