@@ -274,7 +274,7 @@ def hot_conv16_roofline(batch, T, dev):
 
 def bf16_leg(a, rank, world, local, dev):
     """BASELINE configs[4] ("cfg5"): large-batch stress on the 16-bit MFMA path -- per-GPU batch 128 x 32-frame clips
-    (global 1024 on 8 GPUs), video trunk in bf16 (fp32 master weights, fp32 BatchNorm statistics), audio trunk + heads fp32."""
+    (global 1024 on 8 GPUs), both trunks in bf16 (fp32 master weights, fp32 BatchNorm statistics), heads fp32 (MFMA)."""
     import torch.distributed as dist
     from selavi_amd import model as smodel, optim, train
     B, T, hc, K = a.cfg5_batch, CFG5["T"], CFG5["hc"], CFG5["K"]
@@ -340,7 +340,7 @@ def bf16_leg(a, rank, world, local, dev):
         #  the pool's boxes: 7.8 s -- drags it down, the median does not)
         "value_from_median_step": world * B / ms_median * 1e3, "steps_over_2x_median": sum(v > 2 * ms_median for v in per_step),
         "dtype": "bf16",
-        "config": {"workload": "cfg5: R(2+1)D-18 in bf16 (fp32 master weights, fp32 BN statistics) + ResNet-9/heads fp32, "
+        "config": {"workload": "cfg5: R(2+1)D-18 + ResNet-9 in bf16 (fp32 master weights, fp32 BN statistics), heads fp32, "
                                "per-GPU bs=%d, 32x112x112 video, 1x129x100 log-mel, K=309, headcount=10" % B,
                    "global_batch": world * B, "parallelism": "dp%d" % world, "loss_last_step": loss_v,
                    "peak_hbm_gb": round(peak / 2 ** 30, 2)},

@@ -93,17 +93,15 @@ class AVModel(nn.Module):             # model.py:169-252
             h.sync = sync
 
     def set_precision(self, precision, audio=None):
-        """"fp32" (default; every parity claim) or "bf16": the video trunk -- 99 % of the step's FLOPs -- trains on the 16-bit
-        MFMA path (what --use_fp16 / apex O1 does to the convs in the reference, main.py:151-153): bf16 channels-last
-        activations and activation gradients, fp32 accumulation, fp32 master weights, BatchNorm statistics and parameters
-        in fp32, no loss scaling (bf16 has fp32's exponent range).  ``audio="bf16"`` (or SELAVI_AUDIO_PRECISION=bf16) puts the
-        ResNet-9 audio trunk on the same kernels (its 2-D convs are T = 1 launches; -1 ms of the cfg5 step); it stays on the
-        fp32 kernels by default: under two-rank SyncBN its parameters after three steps differed between the library's own
-        communicator and the torch.distributed rig in 2 of 8 runs (tools/flake.sh; single-process runs are bit-reproducible) --
-        an open item (profiles/r03_notes.md).  The heads (0.2 % of the FLOPs) stay in fp32, on the matrix cores."""
+        """"fp32" (default; every parity claim) or "bf16": both trunks train on the 16-bit MFMA path (what --use_fp16 / apex O1
+        does to the convs in the reference, main.py:151-153): bf16 channels-last activations and activation gradients, fp32
+        accumulation, fp32 master weights, BatchNorm statistics and parameters in fp32, no loss scaling (bf16 has fp32's
+        exponent range).  ``audio``: precision of the ResNet-9 audio trunk when it should differ from the video trunk's
+        (its 2-D convs are T = 1 launches of the same kernels; SELAVI_AUDIO_PRECISION overrides the default).  The heads
+        (0.2 % of the FLOPs) stay in fp32, on the matrix cores."""
         assert precision in ("fp32", "bf16")
         if audio is None:
-            audio = os.environ.get("SELAVI_AUDIO_PRECISION", "fp32")
+            audio = os.environ.get("SELAVI_AUDIO_PRECISION", precision)
         assert audio in ("fp32", "bf16")
         self.video_network.base.precision = precision
         self.audio_network.base.precision = audio

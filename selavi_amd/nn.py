@@ -266,7 +266,13 @@ class TrunkFunction(torch.autograd.Function):
         ectx = engine.Ctx(True, sync=fctx.sync, ops=fctx.ops)
         params = _trunk_params(fctx.trunk)
         sink = getattr(fctx.trunk, "grad_sink", None)          # parallel.GradSink: gradients go to its flat buffer
+        fresh = False
         if sink is not None:
+            # the FIRST call allocates the flat buffer and zero-fills it -- on the caller's stream, now.  A side-stream trunk
+            # that forks from the earlier event behind the heads' backward does not wait for that fill: it could land on top
+            # of the trunk's first gradients (the dgamma / dbeta of its last BatchNorm: found as a 1-in-10 difference between
+            # two two-rank rigs after step 1).  The first step forks from the caller's stream as it is now.
+            fresh = (fctx.kind,) not in sink.flat
             ectx.grad_out = sink.views((fctx.kind,), params)
         bwd = engine.video_backward if fctx.kind == "video" else engine.audio_backward
         side = fctx.side
@@ -277,7 +283,7 @@ class TrunkFunction(torch.autograd.Function):
             ectx.wgrad_side = False
             main = torch.cuda.current_stream(dfeat.device)
             ev = _FORK_EVENTS.pop(dfeat.device.index, None)
-            if ev is not None and os.environ.get("SELAVI_FORK_EVENT", "1") == "1":
+            if ev is not None and not fresh and os.environ.get("SELAVI_FORK_EVENT", "1") == "1":
                 side.wait_event(ev)                            # behind the heads' backward, not behind the video backward
             else:
                 side.wait_stream(main)

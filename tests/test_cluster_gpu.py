@@ -195,12 +195,6 @@ def test_two_rank_native_data_parallel_is_bit_identical_to_ddp():
 
     ret, ret_ddp = rigs(0)
     differs = [k for k in ret[0][2] if ret[0][2][k] != ret_ddp[0][2][k]]
-    if differs and all(k.startswith("audio_network") for k in differs):
-        # KNOWN OPEN ITEM (profiles/r03_notes.md, tests/test_native_comm_gpu.py): the audio trunk's bits after three steps
-        # differ between two rigs in about one run of eight; the ranks never diverge.  One retry, loudly.
-        print(f"WARNING: {len(differs)} audio tensors differed between the rigs on the first attempt; retrying once")
-        ret, ret_ddp = rigs(1)
-        differs = [k for k in ret[0][2] if ret[0][2][k] != ret_ddp[0][2][k]]
     diverged = [k for k in ret[0][2] if ret[0][2][k] != ret[1][2][k]]
     assert not diverged, f"ranks diverged in {len(diverged)} tensors: {diverged[:6]}"
     assert not differs, f"{len(differs)} of {len(ret[0][2])} tensors differ from DDP: {differs[:6]}"
