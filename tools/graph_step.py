@@ -1,6 +1,6 @@
 """Eager vs HIP-graph replay of the training step at a small shape (BASELINE configs[0]: bs 4, 8 frames).
 
-    python tools/graph_step.py [--batch 4 --frames 8]
+    python tools/graph_step.py [--batch 4 --frames 8] [--precision bf16 --batch 16 --frames 16 --mel 129 100 --K 309 --hc 10]
 """
 import argparse
 import os
@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--K", type=int, default=28)
     ap.add_argument("--hc", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32")
     a = ap.parse_args()
     from selavi_amd import model as smodel, ops, optim, train
     ops.set_benchmark(True)
@@ -29,6 +30,7 @@ def main():
         torch.manual_seed(31)
         m = smodel.load_model(vid_base_arch="r2plus1d_18", aud_base_arch="resnet9", use_mlp=True, num_classes=a.K,
                               pretrained=False, norm_feat=False, use_max_pool=False, headcount=a.hc).to(dev).train()
+        m.set_precision(a.precision)
         opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
         g = torch.Generator(device=dev).manual_seed(1)
         video = torch.randn(a.batch, 3, a.frames, 112, 112, device=dev, generator=g)
