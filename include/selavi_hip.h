@@ -46,6 +46,8 @@ const char* slv_comm_library(void);               /* what was loaded ("" before 
 int slv_comm_unique_id(void* id_out_128 /* host, 128 bytes */);
 int slv_comm_init(slv_comm_t* comm_out /* host */, const void* unique_id_128 /* host */, int rank, int world);
 int slv_comm_destroy(slv_comm_t comm);
+int slv_comm_abort(slv_comm_t comm);               /* ncclCommAbort: tear down a communicator whose collective hangs (watchdog) */
+int slv_comm_async_error(slv_comm_t comm);         /* ncclCommGetAsyncError: 0 = healthy / in progress, < 0 = failed            */
 int32_t slv_comm_rank(slv_comm_t comm);
 int32_t slv_comm_world(slv_comm_t comm);
 int slv_comm_allreduce_f64(slv_comm_t comm, double* buf, int64_t n, slv_stream_t stream);              /* sum */

@@ -31,27 +31,46 @@ def _digest():
     return h.hexdigest()
 
 
+def _obj_digest(src, headers):
+    """An object is rebuilt when its source, any header of csrc/ or include/, or the flags change."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in [src] + headers:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=True):
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.h")) +
+                     glob.glob(os.path.join(HERE, "..", "include", "*.h")))
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     procs = []
     for s in srcs:
         o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
         objs.append(o)
+        od = _obj_digest(s, headers)
+        if not force and os.path.exists(o) and os.path.exists(o + ".stamp") and open(o + ".stamp").read() == od:
+            continue
         cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for s, p in procs:
+        procs.append((s, o, od, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = None
+    for s, o, od, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(out.decode())
-            raise RuntimeError(f"hipcc failed on {s}")
+            failed = failed or s
+        else:
+            open(o + ".stamp", "w").write(od)
+    if failed:
+        raise RuntimeError(f"hipcc failed on {failed}")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

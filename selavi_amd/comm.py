@@ -27,6 +27,7 @@ from ._lib import C, ptr, stream
 
 class NativeComm:
     _cache = {}
+    _disabled = None        # reason string once the preflight has switched the native path off for this process
 
     def __init__(self, handle, rank, world, group):
         self.h, self.rank, self.world, self.group = handle, rank, world, group
@@ -44,7 +45,7 @@ class NativeComm:
         if not (dist.is_available() and dist.is_initialized()):
             return None
         mode = cls.mode()
-        if mode == "0" or (mode != "force" and dist.get_backend(group) != "nccl"):
+        if mode == "0" or cls._disabled or (mode != "force" and dist.get_backend(group) != "nccl"):
             return None
         key = (0 if (group is None or group is dist.group.WORLD) else id(group), tag)   # WORLD and None are the same group
         got = cls._cache.get(key)
@@ -77,6 +78,80 @@ class NativeComm:
         for comm in cls._cache.values():
             C.slv_comm_destroy(comm.h)
         cls._cache.clear()
+
+    @classmethod
+    def preflight(cls, group=None, timeout_s=None, rounds=3):
+        """Watchdog around the FIRST collectives of every communicator created so far: the step drives
+        them CONCURRENTLY -- "bn" from the main stream, "bn_audio" from the audio trunk's stream, "grad" (100 MB buckets)
+        from the buckets' stream -- which RCCL documents as safe only while all of them can be co-resident.  This issues
+        exactly that pattern (`rounds` times: a 2C-double sum on bn and on bn_audio, a 100 MB fp32 mean on grad, each on a
+        stream of its own), polls the streams' events against a deadline (SELAVI_COMM_TIMEOUT_S, default 120 s) and lets
+        the ranks agree on the outcome over torch.distributed (MIN).  If ANY rank timed out or saw an error, every rank
+        aborts its native communicators (ncclCommAbort), prints a LOUD warning and disables the native path for the
+        process: callers re-create their exchanges on torch.distributed (SELAVI_NATIVE_COMM=0 behaviour).
+        Returns True if the native path stays on (or was not in use)."""
+        import sys
+        import time
+        import torch.distributed as dist
+        comms = {k: v for k, v in cls._cache.items() if v.world > 1}
+        if not comms:
+            return True
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("SELAVI_COMM_TIMEOUT_S", "120"))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        main = torch.cuda.current_stream(dev)
+        ok, why, events, keep = 1, "", [], []
+        try:
+            for (gid, tag), comm in comms.items():
+                st = torch.cuda.Stream(device=dev)
+                st.wait_stream(main)
+                n = 25_000_000 if tag == "grad" else 2 * 512
+                buf = torch.ones(n, dtype=torch.float32 if tag == "grad" else torch.float64, device=dev)
+                keep.append((buf, st))
+                with torch.cuda.stream(st):
+                    for _ in range(rounds):
+                        if tag == "grad":
+                            comm.allreduce_avg_f32_(buf)
+                        else:
+                            comm.allreduce_(buf)
+                            buf.mul_(1.0 / comm.world)
+                    events.append((tag, comm, buf, st.record_event()))
+            deadline = time.time() + timeout_s
+            for tag, comm, buf, ev in events:
+                while not ev.query():
+                    if time.time() > deadline:
+                        ok, why = 0, f"communicator {tag!r}: collective still running after {timeout_s:.0f} s"
+                        break
+                    C.slv_comm_async_error(comm.h)          # raises on an asynchronous RCCL error
+                    time.sleep(0.002)
+                if not ok:
+                    break
+                if abs(float(buf[0]) - 1.0) > 1e-6:          # ones stay ones under sum / world and under mean
+                    ok, why = 0, f"communicator {tag!r}: wrong result {float(buf[0])!r}"
+                    break
+        except Exception as e:                                # SelaviHipError from a failing collective
+            ok, why = 0, repr(e)
+        if os.environ.get("SELAVI_COMM_PREFLIGHT_INJECT") == f"rank{dist.get_rank()}":     # test hook: this rank "fails"
+            ok, why = 0, "injected failure (SELAVI_COMM_PREFLIGHT_INJECT)"
+        flag = torch.tensor([ok], dtype=torch.int32)
+        if dist.get_backend(group) == "nccl":
+            flag = flag.to(dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 1:
+            return True
+        sys.stderr.write("\n" + "!" * 100 + "\nselavi_amd.comm: the native RCCL communicators FAILED their preflight on rank %d (%s);\n"
+                         "falling back to torch.distributed for SyncBN / Sinkhorn-Knopp / gradient buckets on EVERY rank "
+                         "(SELAVI_NATIVE_COMM=0 behaviour).\n" % (dist.get_rank(), why or "another rank reported the failure")
+                         + "!" * 100 + "\n")
+        sys.stderr.flush()
+        for comm in cls._cache.values():
+            try:
+                C.slv_comm_abort(comm.h)
+            except Exception:
+                pass
+        cls._cache.clear()
+        cls._disabled = why or "preflight failed on another rank"
+        return False
 
     def allreduce_(self, t):
         """In-place sum on the current stream (fp64 / fp32 / int64 tensors)."""

@@ -26,6 +26,8 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                       // optional (watchdog path)
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr; // optional
   char path[512] = {0};
 };
 static RcclApi g_api;
@@ -64,6 +66,8 @@ static int load_api(const char* path_hint) {
   SLV_SYM(Broadcast, "ncclBroadcast");
   SLV_SYM(GetErrorString, "ncclGetErrorString");
 #undef SLV_SYM
+  *(void**)(&g_api.CommAbort) = dlsym(h, "ncclCommAbort");
+  *(void**)(&g_api.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");
   g_api.handle = h;
   return 0;
 }
@@ -133,6 +137,27 @@ int slv_comm_destroy(slv_comm_t comm) {
   ncclResult_t r = g_api.CommDestroy(c->nccl);
   delete c;
   if (r != ncclSuccess) return fail(-6, "slv_comm_destroy: ncclCommDestroy failed: %s", g_api.GetErrorString(r));
+  return 0;
+}
+
+int slv_comm_abort(slv_comm_t comm) {
+  using namespace slv;
+  if (!comm) return 0;
+  Comm* c = (Comm*)comm;
+  ncclResult_t r = g_api.CommAbort ? g_api.CommAbort(c->nccl) : g_api.CommDestroy(c->nccl);
+  delete c;
+  if (r != ncclSuccess) return fail(-6, "slv_comm_abort: %s", g_api.GetErrorString(r));
+  return 0;
+}
+
+int slv_comm_async_error(slv_comm_t comm) {
+  using namespace slv;
+  SLV_CHECK_ARG(comm, "null communicator");
+  Comm* c = (Comm*)comm;
+  if (!g_api.CommGetAsyncError) return 0;
+  ncclResult_t st = ncclSuccess;
+  SLV_NCCL(g_api.CommGetAsyncError(c->nccl, &st));
+  if (st != ncclSuccess && st != ncclInProgress) return fail(-6, "slv_comm_async_error: %s", g_api.GetErrorString(st));
   return 0;
 }
 

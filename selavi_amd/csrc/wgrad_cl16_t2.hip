@@ -79,12 +79,9 @@ __global__ __launch_bounds__(256) void cl16_wgrad_t2_finish_kernel(const float* 
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-static bool t2_enabled() {
-  static const bool on = []() {
-    const char* e = getenv("SELAVI_CL16_WGT2");
-    return !(e && e[0] == '0');
-  }();
-  return on;
+static bool t2_enabled() {            // (read per plan, not cached: tests switch it per case)
+  const char* e = getenv("SELAVI_CL16_WGT2");
+  return !(e && e[0] == '0');
 }
 
 // the shapes wgrad_t_plan takes, one workgroup of 8 waves per CU
@@ -93,10 +90,8 @@ bool wgrad_t2_plan(int N, int T, int H, int W, int Cin_p, int Cin, int Cout_p, i
   if (!t2_enabled()) return false;
   if (!wgrad_t_plan(N, T, H, W, Cin_p, Cin, Cout_p, kt, kh, kw, st, sh, sw, pt, ph, pw, To, Ho, Wo, wm, nc, out)) return false;
   // SELAVI_CL16_WGT2=all: also the layers only the two-workgroup column kernel takes (slower than the reduce pass it saves)
-  static const bool all = []() {
-    const char* e = getenv("SELAVI_CL16_WGT2");
-    return e && e[0] == 'a';
-  }();
+  const char* ea = getenv("SELAVI_CL16_WGT2");
+  const bool all = ea && ea[0] == 'a';
   if (!all && !wgrad_tacc_applies(*out)) return false;
   ClWgradT& g = *out;                       // one round of resident workgroups with two per unit: half the K slices
   const long long steps = (long long)N * g.PB * (T + 1);

@@ -131,15 +131,26 @@ class AVModel(nn.Module):             # model.py:169-252
         # HIP stream next to the video trunk, forward and -- autograd replays a node on the stream of its
         # forward -- backward.  It is issued first: autograd then runs the video backward before the
         # audio backward, which leaves the tail of the video gradients' all-reduce something to hide behind.
+        atrunk = self.audio_network.base
+        atrunk.__dict__.pop("_fork_event", None)                  # a fork point belongs to ONE graph (nn._take_fork_event)
+        overlapped = False
         if self.overlap_audio and spec.is_cuda:
             main = torch.cuda.current_stream(spec.device)
-            side = self._side_stream(spec.device)
-            self.audio_network.base.side_stream = side            # the node forks / joins by itself (nn.TrunkFunction)
-            aud_features = self.audio_network(spec).squeeze()
-            img_features = self.video_network(img).squeeze()
-            main.wait_stream(side)
+            # the attribute lives for THIS call only: a later direct ``model.audio_network(spec)`` (feature extraction,
+            # tools) must run on the caller's stream, where nobody would join a side stream for it
+            atrunk.side_stream = self._side_stream(spec.device)
+            atrunk._join_event = None
+            try:
+                aud_features = self.audio_network(spec).squeeze()
+                img_features = self.video_network(img).squeeze()
+            finally:
+                atrunk.side_stream = None
+                ev, atrunk._join_event = atrunk._join_event, None
+                if ev is not None:
+                    main.wait_event(ev)                           # the join of the node's forward fork
+                    overlapped = True
         else:
-            self.audio_network.base.side_stream = None
+            atrunk.side_stream = None
             aud_features = self.audio_network(spec).squeeze()
             img_features = self.video_network(img).squeeze()
         if self.return_features:                                  # model.py:226-227
@@ -151,7 +162,8 @@ class AVModel(nn.Module):             # model.py:169-252
         heads = self._heads()
         spec_ = snn.HeadSpec(heads, self.hc, False, self.use_mlp, self.training,
                              snn._sync_of(self.video_network.base) if self.training else None,
-                             masks=self._dropout_masks, grad_sink=getattr(self, "_grad_sink", None))
+                             masks=self._dropout_masks, grad_sink=getattr(self, "_grad_sink", None),
+                             fork_for=atrunk if overlapped else None)
         logits = snn.HeadsFunction.apply(spec_, img_features.contiguous(), aud_features.contiguous(),
                                          *snn.head_params(heads))
         if self.norm_feat:

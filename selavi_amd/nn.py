@@ -223,7 +223,18 @@ def _sync_of(mod):
     return s
 
 
-_FORK_EVENTS = {}      # device index -> event recorded behind the heads' backward (the point a side-stream trunk forks from)
+def _take_fork_event(trunk, dfeat):
+    """The event a side-stream trunk's backward may fork from: recorded by THIS graph's heads' backward (HeadsFunction stores
+    it on the trunk object the model named in its HeadSpec; model.forward clears it), and valid only if the incoming
+    gradient IS the heads' dX buffer -- a contiguous view of it, nothing enqueued on the caller's stream after the event
+    (a copy made contiguous, an accumulation from a second consumer of the features) produced it."""
+    rec = trunk.__dict__.pop("_fork_event", None)
+    if rec is None:
+        return None
+    ev, dptr = rec
+    if not dfeat.is_contiguous() or dfeat.data_ptr() != dptr:
+        return None
+    return ev
 
 
 class TrunkFunction(torch.autograd.Function):
@@ -234,7 +245,7 @@ class TrunkFunction(torch.autograd.Function):
     the caller's stream.  (Running ``apply`` under ``torch.cuda.stream(side)`` instead makes autograd hand the incoming
     gradient across streams on its own, which cannot be captured into a HIP graph: hipStreamEndCapture crashes on ROCm
     7.0.)  Forward: forks where it is called and is joined by the caller (model.forward, in front of the heads).
-    Backward: forks behind the heads' backward (_FORK_EVENTS) and joins at its own end -- the audio node is the last one
+    Backward: forks behind the heads' backward (_take_fork_event) and joins at its own end -- the audio node is the last one
     of the backward pass (it was issued first), so nothing queues behind that join but the optimizer, while its kernels
     run beside the video backward already enqueued."""
 
@@ -252,6 +263,9 @@ class TrunkFunction(torch.autograd.Function):
                 feat, saved = fwd(ectx, trunk, x)
             x.record_stream(side)
             feat.record_stream(main)
+            # the join the consumer of ``feat`` owes: model.forward waits for it in front of the heads (a caller that sets
+            # ``side_stream`` itself must do the same; model.forward resets the attribute when it returns)
+            trunk._join_event = side.record_event()
         else:
             feat, saved = fwd(ectx, trunk, x)
         fctx.need, fctx.side = need_grad, side
@@ -282,12 +296,12 @@ class TrunkFunction(torch.autograd.Function):
             #  critical path either way)
             ectx.wgrad_side = False
             main = torch.cuda.current_stream(dfeat.device)
-            ev = _FORK_EVENTS.pop(dfeat.device.index, None)
+            ev = _take_fork_event(fctx.trunk, dfeat)
             if ev is not None and not fresh and os.environ.get("SELAVI_FORK_EVENT", "1") == "1":
                 side.wait_event(ev)                            # behind the heads' backward, not behind the video backward
             else:
+                dfeat = dfeat.contiguous()                     # (a copy, if any, is enqueued on main BEFORE the fork)
                 side.wait_stream(main)
-            dfeat = dfeat.contiguous()
             with torch.cuda.stream(side):
                 bwd(ectx, fctx.saved_rec, dfeat)
             dfeat.record_stream(side)
@@ -418,9 +432,10 @@ def _draw_dropout_masks(p, m1, m2, st):
 
 
 class HeadSpec:
-    def __init__(self, heads, hc, single, has_hidden, training, sync, masks=None, grad_sink=None):
+    def __init__(self, heads, hc, single, has_hidden, training, sync, masks=None, grad_sink=None, fork_for=None):
         self.heads, self.hc, self.single, self.has_hidden = heads, hc, single, has_hidden
         self.training, self.sync, self.masks, self.grad_sink = training, sync, masks, grad_sink
+        self.fork_for = fork_for      # the side-stream trunk whose backward may fork behind this node's backward
 
 
 def _lin_of(head, idx):
@@ -586,8 +601,9 @@ class HeadsFunction(torch.autograd.Function):
             C.slv_heads_sum_groups(ptr(dxg), ptr(dX), hcg, B * dxg.shape[2], st)
             dfv, dfa = dX[0], dX[1]
         hp = head_params(heads)
-        if not spec.single:                   # where a side-stream trunk's backward forks from (TrunkFunction)
-            _FORK_EVENTS[dev.index] = torch.cuda.current_stream(dev).record_event()
+        fork_for = getattr(spec, "fork_for", None)
+        if fork_for is not None and dfa is not None:   # where THIS graph's side-stream trunk forks its backward from
+            fork_for._fork_event = (torch.cuda.current_stream(dev).record_event(), dfa.data_ptr())
         if spec.grad_sink is not None:        # the grouped gradient tensors are views of one bucket: one all-reduce
             for p in hp:
                 p.grad = grads[id(p)]

@@ -142,7 +142,24 @@ class DataParallel(torch.nn.Module):
                 dist.broadcast(t, src=src, group=group)
         module.set_sync_bn(True, group)
         self.sink = GradSink(group)
+        from .comm import NativeComm
+        if not NativeComm.preflight(group):       # loud fall-back: the exchanges are re-created on torch.distributed
+            module.set_sync_bn(True, group)
+            self.sink = GradSink(group)
+            assert self.sink.native is None
         module.set_grad_sink(self.sink)
+        self.group = group
+        self._checked_batch = None
 
     def forward(self, *args, **kwargs):
+        # slv_bn_sync_finalize and the mean all-reduce of the buckets assume EQUAL per-rank batches (the reference's loader
+        # drops the ragged last batch, main.py:95-103): checked once per batch size, not per step
+        b = args[0].shape[0] if args and hasattr(args[0], "shape") else None
+        if b is not None and b != self._checked_batch:
+            t = torch.tensor([b, -b], dtype=torch.int64, device=args[0].device if dist.get_backend(self.group) == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            if int(t[0]) != -int(t[1]):
+                raise RuntimeError(f"selavi_amd.DataParallel: per-rank batch sizes differ (this rank {b}, max {int(t[0])}, "
+                                   f"min {-int(t[1])}); SyncBN / the averaged buckets assume equal batches")
+            self._checked_batch = b
         return self.module(*args, **kwargs)

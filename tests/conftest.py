@@ -26,8 +26,3 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
-
-# the BatchNorm-sums-from-the-weight-gradient path (csrc/wgrad_cl16_t2.hip) on EVERY stride-1 temporal layer, not only the
-# layer-1 shape its fast kernel takes: the op tests cover both kernels
-import os as _os
-_os.environ.setdefault("SELAVI_CL16_WGT2", "all")

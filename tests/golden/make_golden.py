@@ -202,11 +202,41 @@ def cfg2_fixture(ref_model, ref_utils, hc=10, K=309, B=16, T=16, fname="cfg2_ful
     print(fname, "full-size fixture: loss", loss.item())
 
 
+def sk_kinetics_fixture(ref_sk, name="sk_kinetics_full", N=230976, K=400, scale=1.0, seed=41, hc=2, head=1):
+    """BASELINE configs[3]'s Sinkhorn-Knopp problem solved by the reference itself (sk_utils.py:359-422 with the gauss
+    branch :368-388, cluster sizes per head GIVEN -- torch's randn stream does not travel): digest / histogram / head and
+    tail of the labels, cost; iteration count and alpha from the oracle after it reproduced the reference's labels."""
+    from oracle import sk_ref
+    PS = synth_PS(N, K, scale, seed)
+    dists = [(portable_fill_(torch.empty(K, 1, dtype=torch.float64), 200 + h, kind="normal") * 0.1 + 1.0) * N / K
+             for h in range(hc)]
+    dist_in = np.stack([d.numpy().ravel() for d in dists])
+    args = Args(distribution='gauss', dist=[d.clone() for d in dists], headcount=hc)
+    cost, newL = ref_sk.optimize_L_sk_gpu(args, torch.from_numpy(PS.copy()), head, logging.getLogger("golden"))
+    newL = newL.numpy()
+    kd = sk_ref.marginals(K, N, PS, 'gauss', dist_in[head])
+    cost_o, L_o, info = sk_ref.optimize_L_sk(PS, lamb=20, K_dist=kd)
+    assert (L_o == newL).all()
+    assert abs(cost_o - cost) <= 1e-12 * abs(cost), (cost_o, cost)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), N=N, K=K, scale=scale, seed=seed, lamb=20, cost=cost, iters=info["iters"],
+        alpha=info["alpha"], labels=np.zeros(0, np.int16), labels_head=newL[:4096].astype(np.int16),
+        labels_tail=newL[-4096:].astype(np.int16), hist=np.bincount(newL, minlength=K).astype(np.int32),
+        digest=np.frombuffer(label_digest(newL).encode(), dtype=np.uint8), dist_in=dist_in,
+        dist_after=np.stack([d.numpy().ravel() for d in args.dist]), head=head)
+    print(name, "iters", info["iters"], "cost", cost)
+
+
 def main():
     if "--only-cfg1" in sys.argv or "--only-cfg2" in sys.argv:
         ref_model, ref_utils, ref_sk = import_reference()
         torch.set_num_threads(os.cpu_count())
         (cfg1_fixture if "--only-cfg1" in sys.argv else cfg2_fixture)(ref_model, ref_utils)
+        return
+    if "--only-sk-kinetics" in sys.argv:      # configs[3]: N = 230 976, K = 400, gauss marginals per head, the reference on CPU (~minutes)
+        ref_model, ref_utils, ref_sk = import_reference()
+        torch.set_num_threads(os.cpu_count())
+        sk_kinetics_fixture(ref_sk)
         return
     if "--only-cfg4" in sys.argv:             # configs[3]: 30-frame clips, K=400, hc=10 (per-GPU bs 16 as in scripts/master.sh:82; ~2 min of CPU)
         ref_model, ref_utils, ref_sk = import_reference()

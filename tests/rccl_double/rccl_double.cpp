@@ -165,6 +165,8 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommAbort(ncclComm_t comm) { return ncclCommDestroy(comm); }     // (optional symbol of the product's watchdog path)
+
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm,
                            hipStream_t stream) {
   Comm* c = (Comm*)comm;

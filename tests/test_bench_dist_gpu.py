@@ -1,0 +1,49 @@
+"""The driver's multi-GPU command, end to end, before the first 8-GPU node sees it.
+
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2
+--steps 3 --warmup 1` is what SCALE_rNN runs (with real RCCL, one rank per GPU).  The test boxes have ONE GPU and RCCL
+refuses two ranks on a device, so the dry-run knobs of bench.py put both ranks on cuda:0 (SELAVI_BENCH_SHARE_GPU=1) with
+gloo as the bootstrap and the library's own communicator paths forced on over the librccl test double
+(SELAVI_NATIVE_COMM=force, SELAVI_RCCL_LIB): the WHOLE script -- data-parallel step with SyncBN + gradient buckets, the
+preflight watchdog, forward timing, row-sharded SK through slv_sk_iterate_sharded, the cfg5 bf16 leg under data
+parallelism, max-over-ranks timing, ONE JSON line from rank 0 -- runs as the driver will run it.
+Reference wiring: /root/reference/main.py:117-118,156-160, utils.py:133-146."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("transport", ["native_double", "torch_gloo"])
+def test_driver_scale_command_two_ranks_on_one_gpu(transport):
+    from tests.rccl_double.build import build_double
+    env = dict(os.environ, SELAVI_BENCH_SHARE_GPU="1", SELAVI_BENCH_DIST_BACKEND="gloo", SLV_DBL_TIMEOUT_S="120",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if transport == "native_double":
+        env.update(SELAVI_NATIVE_COMM="force", SELAVI_RCCL_LIB=build_double())
+    else:
+        env.pop("SELAVI_RCCL_LIB", None)
+        env["SELAVI_NATIVE_COMM"] = "0"
+    port = 24100 + os.getpid() % 500 + (0 if transport == "native_double" else 500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--cfg5-batch", "16", "--cfg5-steps", "2", "--cfg5-warmup", "1"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-6000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line from rank 0, got {len(lines)}"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2" and out["config"]["sync_bn"] is True
+    assert out["value"] > 0 and abs(out["value"] - 32 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
+    assert out["sk"]["rows_per_gpu"] == 170752 // 2 and out["sk"]["iters_per_s"] > 0          # SK rows sharded over the ranks
+    c5 = out["cfg5_bf16"]
+    assert "error" not in c5 and c5["n_gpus"] == 2 and c5["config"]["parallelism"] == "dp2" and c5["value"] > 0
+    assert out["cpu_baseline"] is None                                                         # rank 0 at N = 1 only
+    assert "FAILED their preflight" not in p.stderr

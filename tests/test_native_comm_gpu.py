@@ -18,18 +18,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-DOUBLE_SRC = os.path.join(HERE, "rccl_double", "rccl_double.cpp")
-DOUBLE_LIB = os.path.join(HERE, "rccl_double", "librccl_double.so")
-
-
-def build_double(force=False):
-    """g++ (host code only) against the HIP runtime and RCCL's header; in-tree so that it travels to the GPU box."""
-    if force or not os.path.exists(DOUBLE_LIB) or os.path.getmtime(DOUBLE_LIB) < os.path.getmtime(DOUBLE_SRC):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__",
-                               "-I/opt/rocm/include", DOUBLE_SRC, "-o", DOUBLE_LIB,
-                               "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
-    return DOUBLE_LIB
+from tests.rccl_double.build import DOUBLE_LIB, build_double  # noqa: E402,F401
 
 
 @pytest.fixture
@@ -169,3 +158,25 @@ def test_two_rank_native_step_is_bit_identical_to_the_gloo_rig(monkeypatch, prec
     assert not diverged, f"ranks diverged in {len(diverged)} tensors: {diverged[:6]}"
     assert not differs, f"{len(differs)} of {len(ret_nat[0][2])} tensors differ from the gloo rig: {differs[:6]}"
     assert ret_nat[0][0] == ret_gloo[0][0] and ret_nat[0][1] == ret_gloo[0][1]
+
+
+def test_preflight_failure_falls_back_to_torch_distributed_on_every_rank(monkeypatch, capfd):
+    """comm.NativeComm.preflight (the watchdog around the first collectives of the three concurrently driven communicators):
+    a failure on ONE rank (injected on rank 1) makes EVERY rank abort its native communicators, say so loudly and re-create
+    SyncBN and the gradient buckets on torch.distributed -- and the step is then bit-identical to the plain gloo rig."""
+    import torch.multiprocessing as mp
+    from tests.test_cluster_gpu import _ddp_worker
+    monkeypatch.setenv("SLV_DBL_TIMEOUT_S", "90")
+    ret_gloo, ret_fb = mp.Manager().dict(), mp.Manager().dict()
+    monkeypatch.delenv("SELAVI_RCCL_LIB", raising=False)
+    monkeypatch.delenv("SELAVI_NATIVE_COMM", raising=False)
+    mp.spawn(_ddp_worker, args=(2, 25100 + os.getpid() % 300, ret_gloo, "native", "fp32"), nprocs=2, join=True)
+    monkeypatch.setenv("SELAVI_RCCL_LIB", build_double())
+    monkeypatch.setenv("SELAVI_NATIVE_COMM", "force")
+    monkeypatch.setenv("SELAVI_COMM_PREFLIGHT_INJECT", "rank1")
+    mp.spawn(_ddp_worker, args=(2, 25500 + os.getpid() % 300, ret_fb, "native", "fp32"), nprocs=2, join=True)
+    err = capfd.readouterr().err
+    assert "FAILED their preflight" in err and "falling back to torch.distributed" in err
+    assert ret_fb[0][3] == 0 and ret_fb[1][3] == 0, "native communicators survived a failed preflight"
+    assert ret_fb[0][2] == ret_fb[1][2] == ret_gloo[0][2]
+    assert ret_fb[0][1] == ret_gloo[0][1]

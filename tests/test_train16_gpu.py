@@ -149,12 +149,16 @@ def test_weight_gradient_matches_autograd(case):
                                   # workgroups (csrc/wgrad_cl16_tacc.hip): ragged last column (9 000 pixels), 4 or 5 columns
                                   # per workgroup, 7 steps per column with the virtual frame
                                   (4, 144, 6, 90, 100, 64)])
-def test_temporal_weight_gradient_yields_the_source_batchnorm_sums(case):
+def test_temporal_weight_gradient_yields_the_source_batchnorm_sums(case, monkeypatch):
     """conv_wgrad(bnr=...) on the stride-1 (3,1,1) convs (csrc/wgrad_cl16_t2.hip): dW = s G2 + h G1 from the gradients
     against the masked raw activation (G2) and against the mask (G1), and the BatchNorm-backward sums of the layer the
     conv reads as contractions of the same two tensors with the weights -- against fp64: the weight gradient of
     relu(bn(y)), and sum g m / sum g m xhat of the exact backward-data gradient g."""
     from selavi_amd import ops16
+    # the path on EVERY stride-1 temporal layer, not only the layer-1 shape its fast kernel takes (the production default,
+    # which every end-to-end test runs): this test covers both kernels.  Plans are cached per shape: drop them on both sides.
+    monkeypatch.setenv("SELAVI_CL16_WGT2", "all")
+    monkeypatch.setattr(ops16.Plan16, "_cache", {})
     N, Cin, T, H, W, Cout = case
     k, st, pd = (3, 1, 1), (1, 1, 1), (1, 0, 0)
     gen = torch.Generator().manual_seed(Cin + 3 * Cout + T)
@@ -570,7 +574,8 @@ def _oracle_step_on_rounded(B, T, S, hc, K, round_activations):
     return float(loss), grads
 
 
-def test_bf16_step_against_the_cpu_oracle_on_rounded_operands():
+@pytest.mark.parametrize("shape", [(8, 8, 64), (4, 8, 112)], ids=["b8_t8_64px", "b4_t8_112px_layer1_maps_56x56"])
+def test_bf16_step_against_the_cpu_oracle_on_rounded_operands(shape):
     """DIRECT oracle check of the 16-bit step (no HIP-vs-HIP transitivity, no damped init): oracle/step_ref.train_step in
     fp32 arithmetic on the bf16-rounded conv weights and clip, at the reference's own initialisation, against the HIP bf16
     step.  The loss is held to 5e-3.  For the gradients the oracle is run twice -- plain, and with every conv output
@@ -578,9 +583,12 @@ def test_bf16_step_against_the_cpu_oracle_on_rounded_operands():
     chaotic in its parameter gradients (tests/diag/bf16_grad_cos.py): the cosine f BETWEEN the two oracle runs measures
     what bf16 storage alone does to a tensor's gradient.  Two independent realisations of that rounding (the oracle's and
     the HIP path's: other accumulation orders, so other roundings) then agree to about f * f -- the HIP step is held to
-    that, per tensor (h >= f^2 - 0.12), to > 0.9 wherever the oracles agree to 0.98, and in the median over tensors."""
+    that, per tensor (h >= f^2 - 0.12), to > 0.9 wherever the oracles agree to 0.98, and in the median over tensors.
+    Second shape: 112 x 112 clips, i.e. 56 x 56 layer-1 maps -- the native tile geometry of the register-resident layer-1
+    kernels (conv_cl16_sr / _sd / _tr, wgrad_cl16_acc / _tacc), so that those kernels sit inside an oracle-pinned step."""
     from selavi_amd.utils import get_loss
-    B, T, S, hc, K = 8, 8, 64, 2, 7
+    B, T, S = shape
+    hc, K = 2, 7
     m, opt, video, audio, sl, sel, _ = _step_setup("bf16", hc=hc, K=K, B=4, T=T, S=S)
     from oracle.model_ref import portable_fill_
     video = portable_fill_(torch.empty(B, 3, T, S, S), 5).cuda()
