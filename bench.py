@@ -30,6 +30,11 @@ CFG2 = dict(batch=16, T=16, S=112, F=129, Tp=100, K=309, hc=10, N=170752)
 # + heads 0.0168 GFLOP; step = 3x forward (dgrad + wgrad)
 FWD_GFLOP_PER_CLIP = 81.04 + 0.506 + 0.0168
 PEAK_FP32_MFMA_TF = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
+# the fp32 convs as they run by default (csrc/igemm3.hpp): every fp32 operand cut exactly into 3 bf16 pieces, a product =
+# 6 partial products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -> the binding roofline of an fp32 conv FLOP is the
+# dense bf16 MFMA peak / 6
+PEAK_BF16_MFMA_TF_DENSE = 2500.0
+PEAK_X3_TF = PEAK_BF16_MFMA_TF_DENSE / 6.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -39,7 +44,7 @@ FWD_MB_PER_CLIP = 518.1 + 3.38          # sum over convs of (in + out
 def _pmc_traffic(key):
     """Measured HBM bytes/launch recorded by the PMC passes of this round (tools/pmc_traffic.sh ->
     profiles/r01_pmc.json; None if not recorded)."""
-    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             v = d.get(key)
@@ -81,6 +86,7 @@ def parse():
     ap.add_argument("--no-sk", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=CFG2["batch"], help="batch of the CPU baseline (cfg2: 16, the GPU step's)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the 16-bit leg (BASELINE configs[4])")
+    ap.add_argument("--no-native-leg", action="store_true", help="skip the comparison leg on the native fp32 MFMA kernels")
     ap.add_argument("--cfg5-batch", type=int, default=CFG5["batch"], help="per-GPU batch of the 16-bit leg (cfg5: 128)")
     ap.add_argument("--cfg5-steps", type=int, default=15)
     ap.add_argument("--cfg5-warmup", type=int, default=5)
@@ -112,9 +118,13 @@ def hot_conv_roofline(batch, dev):
     ms = e0.elapsed_time(e1) / reps
     flop = 2.0 * batch * 16 * 56 * 56 * 144 * 64 * 9
     cfg = plan.cfg_fwd
-    tile = "MT=%d,NT=%d,K-slices=%d" % (cfg & 255, (cfg >> 8) & 255, cfg >> 16) if cfg else "heuristic tile (MT=9,NT=2)"
-    return dict(kernel="igemm_kernel<MODE_CONV, %s, BN+ReLU prologue, tap-major K> layer1 (1,3,3) 64->144 forward" % tile,
-                ms=ms, flop=flop, tflops=flop / ms / 1e9)
+    tile = "MT=%d,NT=%d,K-slices=%d" % (cfg & 255, (cfg >> 8) & 15, cfg >> 16) if cfg else "heuristic tile (MT=9,NT=2)"
+    x3 = ops.conv_arithmetic() == "x3"
+    name = ("igemm3_kernel<%s, BN+ReLU prologue> (fp32 tensors, operands split into 3 bf16 pieces in registers, 6 x "
+            "v_mfma_f32_16x16x32_bf16 per product tile, fp32 accumulate)" if x3 else
+            "igemm_kernel<MODE_CONV, %s, BN+ReLU prologue, tap-major K> (v_mfma_f32_16x16x4_f32)") % tile
+    return dict(kernel=name + " layer1 (1,3,3) 64->144 forward", ms=ms, flop=flop, tflops=flop / ms / 1e9, x3=x3,
+                grid=plan.nblk * ((144 + (cfg & 255 or 9) * 16 - 1) // ((cfg & 255 or 9) * 16)))
 
 
 def sk_bench(rank, world, dev, iters=50):
@@ -240,6 +250,7 @@ FWD_MB_PER_CLIP_T32_BF16 = 1036.2 / 2 + 3.38           # video bytes halve in bf
 PEAK_BF16_MFMA_TF = 2500.0
 
 
+HOT_X3_KERNEL = "igemm3_kernel<9, 2, 1, 0, 4, 2>"     # csrc/igemm3.hpp: MT, NT, PRO, EPI, WAVES, OCC of the layer-1 spatial forward
 HOT16_KERNEL = "conv_cl16_sr_kernel<1, 1>"      # csrc/conv_cl16_sr.hip: one persistent workgroup per CU (grid 256)
 
 
@@ -507,6 +518,38 @@ def main():
     hot = hot_conv_roofline(B, dev)
     sk = None if a.no_sk else sk_bench(rank, world, dev)
     sk_round = sk_round_estimate(m, dev, world, clips, sk) if sk else None
+    # the same step on the NATIVE fp32-input MFMA kernels (csrc/igemm.hpp, v_mfma_f32_16x16x4_f32): what the headline was in
+    # rounds 1-3, for comparison with the split-operand arithmetic the headline runs on now (csrc/igemm3.hpp)
+    native = None
+    if not a.no_native_leg and ops.conv_arithmetic() == "x3":
+        ops.set_conv_arithmetic("native")
+        try:
+            step()
+            for _ in range(2):
+                loss_n = step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            tn0 = time.perf_counter()
+            nsteps = max(3, a.steps // 2)
+            for _ in range(nsteps):
+                loss_n = step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dtn = time.perf_counter() - tn0
+            if world > 1:
+                t = torch.tensor([dtn], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtn = t.item()
+            hot_n = hot_conv_roofline(B, dev)
+            native = {"value": world * B * nsteps / dtn, "unit": "clips/s", "steps": nsteps, "ms_per_step": dtn / nsteps * 1e3,
+                      "loss_last_step": float(loss_n.item()),
+                      "hot_kernel": {"kernel": hot_n["kernel"], "ms_per_launch": hot_n["ms"], "achieved": hot_n["tflops"],
+                                     "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s", "frac": hot_n["tflops"] / PEAK_FP32_MFMA_TF},
+                      "note": "SELAVI_CONV_X3=0 / ops.set_conv_arithmetic('native'): every conv on v_mfma_f32_16x16x4_f32"}
+        finally:
+            ops.set_conv_arithmetic("x3")
     cfg5 = None
     if not a.no_cfg5:
         del video, audio
@@ -539,21 +582,39 @@ def main():
             "config": {"workload": "cfg2: R(2+1)D-18 + ResNet-9, per-GPU bs=%d, 16x112x112 video, 1x129x100 "
                                    "log-mel, K=309, headcount=10, SGD(m=0.9, wd=1e-5), fp32" % B,
                        "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "conv_arithmetic": ("fp32 tensors and fp32 accumulation; every conv product of all but the two 3 / 1-channel "
+                                           "stem launches is evaluated on the bf16 matrix cores from operands cut EXACTLY into three "
+                                           "bf16 pieces (a1 b1 + a1 b2 + a2 b1 + a1 b3 + a2 b2 + a3 b1: the dropped terms are <= "
+                                           "3 x 2^-24 |a b|, one fp32 rounding; per-op error against fp64 equal to the native fp32 "
+                                           "MFMA kernels': tests/test_ops_gpu.py) -- csrc/igemm3.hpp; native_fp32_mfma = the same "
+                                           "step on v_mfma_f32_16x16x4_f32") if hot["x3"] else "native fp32-input MFMA",
                        "sync_bn": world > 1, "loss_last_step": loss_v,
                        "peak_hbm_gb": round(peak_hbm / 2 ** 30, 2)},
-            "roofline": {"bound": "mfma", "achieved": hot["tflops"], "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
-                         "frac": hot["tflops"] / PEAK_FP32_MFMA_TF,
+            "roofline": {"bound": "mfma", "achieved": hot["tflops"],
+                         # x3: an fp32 conv FLOP costs six bf16 MFMA FLOPs -> peak = dense bf16 MFMA peak / 6
+                         "peak": PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF, "unit": "TFLOP/s (fp32 conv FLOPs)",
+                         "frac": hot["tflops"] / (PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF),
+                         "peak_note": ("2500 TFLOP/s dense bf16 MFMA / 6 partial products per fp32 product; the native fp32-input "
+                                       "MFMA peak is 157.3") if hot["x3"] else "fp32-input MFMA = fp32 vector peak",
+                         "frac_of_native_fp32_mfma_peak": hot["tflops"] / PEAK_FP32_MFMA_TF,
+                         "bf16_mfma_issued": {"achieved": 6 * hot["tflops"], "peak": PEAK_BF16_MFMA_TF_DENSE,
+                                              "frac": 6 * hot["tflops"] / PEAK_BF16_MFMA_TF_DENSE} if hot["x3"] else None,
                          # HBM bytes per launch of this kernel at B=16 from rocprofv3 PMC passes
-                         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r01_pmc.json
-                         "traffic": _pmc_traffic("hot_conv_fwd") if B == CFG2["batch"] else None,
+                         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r04_pmc.json
+                         "traffic": _pmc_traffic("hot_conv_fwd_x3" if hot["x3"] else "hot_conv_fwd") if B == CFG2["batch"] else None,
                          "kernel": hot["kernel"], "ms_per_launch": hot["ms"], "flop_per_launch": hot["flop"],
                          # the same launch inside the step (rocprofv3 average of the committed trace of this command)
                          "in_step": (lambda r: None if r is None else dict(
-                             r, achieved=hot["flop"] / r["ms"] / 1e9, frac=hot["flop"] / r["ms"] / 1e9 / PEAK_FP32_MFMA_TF))(
-                             _rocprof_in_step("igemm_kernel<0, 9, 2, true, 1, 1, 0, 0, 0>", 6272) if B == CFG2["batch"] else None)},
-            "step_roofline": {"bound": "mfma", "achieved": step_tflops, "peak": PEAK_FP32_MFMA_TF,
+                             r, achieved=hot["flop"] / r["ms"] / 1e9,
+                             frac=hot["flop"] / r["ms"] / 1e9 / (PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF)))(
+                             _rocprof_in_step(HOT_X3_KERNEL if hot["x3"] else "igemm_kernel<0, 9, 2, true, 1, 1, 0, 0, 0>", 6272,
+                                              ("r04_bench_kernel_summary.txt",) if hot["x3"] else
+                                              ("r03_bench_kernel_summary.txt", "r02_bench_kernel_summary.txt"))
+                             if B == CFG2["batch"] else None)},
+            "step_roofline": {"bound": "mfma", "achieved": step_tflops, "peak": PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF,
                               "unit": "TFLOP/s per GPU (algorithmic 3 x %.2f GFLOP/clip)" % FWD_GFLOP_PER_CLIP,
-                              "frac": step_tflops / PEAK_FP32_MFMA_TF},
+                              "frac": step_tflops / (PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF),
+                              "frac_of_native_fp32_mfma_peak": step_tflops / PEAK_FP32_MFMA_TF},
             "forward": {"ms": fwd_ms, "clips_per_s_per_gpu": B / fwd_ms * 1e3,
                         "mfma": {"achieved": FWD_GFLOP_PER_CLIP * B / fwd_ms, "peak": PEAK_FP32_MFMA_TF,
                                  "unit": "TFLOP/s", "frac": FWD_GFLOP_PER_CLIP * B / fwd_ms / PEAK_FP32_MFMA_TF},
@@ -564,6 +625,7 @@ def main():
             "sk": sk,
             "sk_round": sk_round,
             "cfg5_bf16": cfg5,
+            "native_fp32_mfma": native,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

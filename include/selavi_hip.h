@@ -134,6 +134,13 @@ int slv_sk_labels(const double* P, int64_t N_local, int K, const double* beta, v
  */
 /* gather tables (host side, upload once per layer): dgrad == 0 -> forward / weight-gradient table,
  * dgrad == 1 -> one table block per stride-parity class of the backward-data conv.  _len = int32 words. */
+/* Arithmetic of the fp32 convolutions (all but the stems' channel-major launches): 1 (default; SELAVI_CONV_X3) = every fp32
+ * operand is cut exactly into three bf16 pieces and a product is six partial products on v_mfma_f32_16x16x32_bf16 with fp32
+ * accumulation (csrc/igemm3.hpp: the dropped terms are <= 3 * 2^-24 |a b|, one fp32 rounding; 2.67x the native rate);
+ * 0 = the native fp32-input MFMA (csrc/igemm.hpp).  Weight images (slv_conv_w_transform), their sizes and the launch
+ * configurations depend on the setting: make them again after switching. */
+int slv_conv_set_arithmetic(int split_bf16x3);
+int32_t slv_conv_get_arithmetic(void);
 int32_t slv_conv_table_len(const int32_t* geom, int dgrad);
 int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out /* host, table_len words */);
 /* Launch configuration `cfg`: 0 = built-in heuristic, otherwise one of the values enumerated by

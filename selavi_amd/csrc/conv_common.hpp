@@ -44,7 +44,16 @@ struct Desc {
   size_t gen_words;        // forward only: words of the channel-major table that precedes a tap-major one
                            // (the weight-gradient kernel always reads the channel-major table)
   size_t wt_off;           // backward-data: float offset of this class' weight matrix
+  int x3;                  // this launch runs on the split-operand kernels (igemm3.hpp): the weight image is three bf16 planes
+  size_t a_floats;         // size of the launch's weight image in floats (M*Kd fp32, or the x3 image)
 };
+
+// the split-operand kernels (igemm3.hpp), instantiated in conv_x3_*.hip: 0 = launched, -1 = no such tile
+int x3_enabled();
+struct IgemmArgs;
+// x3 weight image: [K chunk of 32][plane 3][Mp = round16(M) rows][32 k] bf16, rows of 64 bytes with the 16-byte slots
+// XOR-swizzled (cl_swz) -- the LDS image of igemm3_kernel's A tile, copied by LDS-DMA
+static size_t x3_image_floats(int M, int Kd) { return (size_t)((Kd + 31) / 32) * 3 * ((M + 15) / 16 * 16) * 16; }
 
 // the loader waves run two chunks past the end (branch-free schedule): 48 invalid pad entries
 static int kpad(int Kd) { return ((Kd + 15) / 16) * 16 + 48; }
@@ -69,6 +78,8 @@ static void finish(Desc& d, const Geom& g, bool with_generic) {
     d.gen_words = 0;
     d.tab_words = gen;
   }
+  d.x3 = d.kord == KORD_TAP && x3_enabled();
+  d.a_floats = d.x3 ? x3_image_floats(d.M, d.Kd) : (size_t)d.M * d.Kd;
 }
 
 static Desc fwd_desc(const Geom& g) {
@@ -137,7 +148,7 @@ static int dgrad_descs(const Geom& g, Desc* out8) {
         d.tab_off = tab_off;
         d.wt_off = wt_off;
         tab_off += d.tab_words;
-        wt_off += (size_t)g.Cin * d.Kd;
+        wt_off += d.a_floats;
         out8[n++] = d;
       }
   return n;
@@ -253,6 +264,10 @@ static void plan_conv(int M, long long ncols, int Kd, int* mt_out, int* nt_out, 
   pick_tile(M, ncols, mt_out, nt_out);
 }
 
+int launch_x3_fwd(const IgemmArgs& a, int mt, int nt, int splits, hipStream_t st);
+int launch_x3_dgrad(const IgemmArgs& a, int mt, int nt, int splits, hipStream_t st);
+int launch_x3_wgrad(const IgemmArgs& a, int mt, int nt, int splits, bool vec_a, hipStream_t st);
+
 // out[i] = sum_s partial[s][i] (+ addend[i])   (fixed order; addend may alias out)
 template <int MODE, int SUBSET = SUB_ALL>
 static int dispatch(const IgemmArgs& a0, int mt, int nt, int splits, hipStream_t st, int mf = 0) {
@@ -261,11 +276,20 @@ static int dispatch(const IgemmArgs& a0, int mt, int nt, int splits, hipStream_t
   a.nblkM = (a.M + bm - 1) / bm;
   a.nblkN = (int)((a.Ntot + bn - 1) / bn);
   if (a.nblkN == 0) return 0;
+  if constexpr (MODE == MODE_CONV && (SUBSET == SUB_FWD || SUBSET == SUB_DGRAD)) {
+    // tap-major layers (all but the stems): fp32 on the bf16 matrix cores with split operands (igemm3.hpp)
+    if (a.kord == KORD_TAP && !mf && x3_enabled())
+      return SUBSET == SUB_FWD ? launch_x3_fwd(a, mt, nt, splits, st) : launch_x3_dgrad(a, mt, nt, splits, st);
+  }
   // 16-byte A loads when the layout allows it (see igemm.hpp, template flag VA)
   bool vec_a;
   if (MODE == MODE_WGRAD) vec_a = ((a.To * a.Ho * a.Wo) % 4 == 0) && (a.Ptot % 4 == 0);
   else vec_a = (a.Kd % 4 == 0) && (((size_t)a.A & 15) == 0);
   if (getenv("SLV_NO_VECA")) vec_a = false;
+  if constexpr (MODE == MODE_WGRAD) {
+    // split operands on the bf16 matrix cores (igemm3.hpp: quads of positions where the geometry allows, else element-wise)
+    if (!mf && x3_enabled()) return launch_x3_wgrad(a, mt, nt, splits, vec_a, st);
+  }
 #define SLV_CASE(MT_, NT_) \
   if (mt == MT_ && nt == NT_) { launch_igemm<MODE, MT_, NT_, 0, SUBSET>(a, splits, vec_a, st); return 0; }
 #define SLV_CASE_MF(MT_, MT32_) \
@@ -296,7 +320,7 @@ static void conv_args(IgemmArgs& a, const Geom& g, const Desc& d, const int32_t*
   a.dmul0 = d.dmul[0]; a.dmul1 = d.dmul[1]; a.dmul2 = d.dmul[2];
   a.dorg0 = d.dorg[0]; a.dorg1 = d.dorg[1]; a.dorg2 = d.dorg[2];
   a.D0 = d.D[0]; a.D1 = d.D[1]; a.D2 = d.D[2];
-  a.A_bytes = (unsigned)((size_t)d.M * d.Kd * 4);
+  a.A_bytes = (unsigned)(d.a_floats * 4);
   a.B_bytes = (unsigned)((size_t)g.Bn * a.sbatch * 4);
 }
 
@@ -367,6 +391,7 @@ struct Cfg {
 };
 static bool tile_ok(int mt, int nt, int mf) {
   if (mf) return nt == 2 && (mt == 4 || mt == 6 || mt == 8);
+  if (nt == 4) return mt == 4 || mt == 8 || mt == 9;      // 8-wave workgroups of the split-operand kernels (igemm3.hpp) only
   return ((mt == 4 || mt == 8 || mt == 9) && (nt == 1 || nt == 2)) || (mt == 15 && nt == 1);
 }
 static int32_t pack_cfg(int mt, int nt, int sp, int mf) { return mt | (nt << 8) | (mf << 12) | (sp << 16); }

@@ -63,9 +63,56 @@ __global__ void w_transform_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-// dW[i] = sum_s partial[s][i], fixed order.  The weight gradients have few elements (83 k for layer1)
-// but up to hundreds of K-slices, so the slice loop is spread over G waves per element group and
-// unrolled 8-fold (independent loads in flight); partial sums are combined in a fixed tree.
+// The x3 weight image of one launch (conv_common.hpp: x3_image_floats): every 16-byte slot of the image is produced by one
+// thread -- 8 consecutive k of one row, gathered from w (fp32, [Cout][Cin][taps]), cut into the three bf16 pieces
+// (igemm3.hpp: split3) and stored to the three planes; padding (channels beyond C, rows beyond M, the odd half chunk) is
+// written as zeros, so no memset.  transposed = 0: rows = Cout, gathered channel = ci (forward); 1: rows = Cin,
+// gathered channel = co (backward data, taps = this parity class' taps).
+struct SplitTaps {
+  int t[64];
+};
+__global__ __launch_bounds__(256) void w_split_kernel(const float* __restrict__ w, unsigned* __restrict__ img, int M, int Cg,
+                                                      int Kd, int ntaps, const SplitTaps taps, int Cin, int taps_all,
+                                                      int transposed) {
+  const int Mp = (M + 15) / 16 * 16, nch = (Kd + 31) / 32;
+  const size_t total = (size_t)nch * Mp * 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int slot = (int)(i & 3);
+    const size_t rr = i >> 2;
+    const int row = (int)(rr % Mp), ch = (int)(rr / Mp);
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = ch * 32 + slot * 8 + e;
+      float v = 0.f;
+      if (k < Kd && row < M) {
+        const int grp = k >> 4, j = grp % ntaps, c = (grp / ntaps) * 16 + (k & 15);
+        if (c < Cg) v = transposed ? w[((size_t)c * Cin + row) * taps_all + taps.t[j]] : w[((size_t)row * Cin + c) * taps_all + taps.t[j]];
+      }
+      const unsigned u = __float_as_uint(v);
+      h[e] = u & 0xffff0000u;
+      const float r1 = v - __uint_as_float(h[e]);
+      m[e] = __float_as_uint(r1) & 0xffff0000u;
+      l[e] = __float_as_uint(r1 - __uint_as_float(m[e]));
+    }
+    const size_t base = ((size_t)ch * 3 * Mp + row) * 16 + (size_t)((slot ^ ((-(row >> 2)) & 3)) << 2);   // dwords
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      img[base + e] = (h[2 * e] >> 16) | h[2 * e + 1];
+      img[base + (size_t)Mp * 16 + e] = (m[2 * e] >> 16) | m[2 * e + 1];
+      img[base + (size_t)Mp * 32 + e] = (l[2 * e] >> 16) | (l[2 * e + 1] & 0xffff0000u);
+    }
+  }
+}
+static void launch_w_split(const float* w, float* img, const Desc& d, int Cin, int taps_all, int transposed, hipStream_t st) {
+  SplitTaps tp;
+  for (int j = 0; j < 64; ++j) tp.t[j] = j < d.ntaps ? d.taps[j] : 0;
+  const size_t total = (size_t)((d.Kd + 31) / 32) * ((d.M + 15) / 16 * 16) * 4;
+  if (total == 0 || d.ntaps == 0) return;          // a parity class no tap reaches: no weights, the launch has no K steps
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(w_split_kernel, dim3(blocks), dim3(256), 0, st, w, (unsigned*)img, d.M, d.C, d.Kd, d.ntaps, tp, Cin,
+                     taps_all, transposed);
+}
 }  // namespace slv
 
 using namespace slv;
@@ -101,8 +148,8 @@ int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out) {
 int32_t slv_conv_configs(const int32_t* geom, int op, int32_t* out, int32_t max_out) {
   Geom g;
   if (read_geom(geom, g) != 0 || !out || max_out <= 0 || op < 0 || op > 2) return -1;
-  static const int tiles[10][3] = {{9, 2, 0}, {8, 2, 0}, {15, 1, 0}, {4, 2, 0}, {9, 1, 0}, {8, 1, 0}, {4, 1, 0},
-                                   {8, 2, 1}, {6, 2, 1}, {4, 2, 1}};
+  static const int tiles[13][3] = {{9, 2, 0}, {8, 2, 0}, {15, 1, 0}, {4, 2, 0}, {9, 1, 0}, {8, 1, 0}, {4, 1, 0},
+                                   {8, 2, 1}, {6, 2, 1}, {4, 2, 1}, {9, 4, 0}, {8, 4, 0}, {4, 4, 0}};
   const int taps = g.kt * g.kh * g.kw;
   int M;
   long long N, chunks;
@@ -127,6 +174,9 @@ int32_t slv_conv_configs(const int32_t* geom, int op, int32_t* out, int32_t max_
     const long long bm = t[0] * 16, bn = t[1] * 64;
     const long long nb = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     if ((double)(nb * bm * bn) > 1.35 * (double)minpad) continue;   // too much padded work
+    const bool x3 = op != 2 && x3_enabled() && want_tap_major(op == 0 ? g.Cin : g.Cout);
+    if (t[2] && x3) continue;            // split-operand kernels: 16 x 16 tiles only
+    if (t[1] == 4 && !x3) continue;      // 256-column (8-wave) tiles: split-operand conv kernels only
     int cand[12], nc = 0;
     if (op != 2) {
       static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
@@ -251,7 +301,7 @@ size_t slv_conv_wf_elems(const int32_t* geom) {
   Geom g;
   if (read_geom(geom, g) != 0) return 0;
   const Desc d = fwd_desc(g);
-  return d.kord == KORD_TAP ? (size_t)d.M * d.Kd : 0;
+  return d.kord == KORD_TAP ? d.a_floats : 0;
 }
 
 size_t slv_conv_wt_elems(const int32_t* geom) {
@@ -260,7 +310,7 @@ size_t slv_conv_wt_elems(const int32_t* geom) {
   Desc ds[8];
   const int n = dgrad_descs(g, ds);
   size_t t = 0;
-  for (int i = 0; i < n; ++i) t += (size_t)g.Cin * ds[i].Kd;
+  for (int i = 0; i < n; ++i) t += ds[i].a_floats;
   return t > 0 ? t : 1;
 }
 
@@ -271,6 +321,21 @@ int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf, float* 
   if (df.kord != KORD_TAP) wf = nullptr;   // the forward conv of this layer reads w directly
   Desc ds[8];
   const int n = dgrad_descs(g, ds);
+  hipStream_t st = (hipStream_t)stream;
+  // split-operand launches (igemm3.hpp) read a three-plane bf16 image instead of the fp32 re-layout
+  if (wf && df.x3) {
+    launch_w_split(w, wf, df, g.Cin, g.kt * g.kh * g.kw, 0, st);
+    SLV_LAUNCH_CHECK();
+    wf = nullptr;
+  }
+  if (wt && n > 0 && ds[0].x3) {
+    for (int i = 0; i < n; ++i) {
+      launch_w_split(w, wt + ds[i].wt_off, ds[i], g.Cin, g.kt * g.kh * g.kw, 1, st);
+      SLV_LAUNCH_CHECK();
+    }
+    wt = nullptr;
+  }
+  if (!wf && !wt) return 0;
   TapMap tm;
   memset(&tm, 0, sizeof(tm));
   const int taps = g.kt * g.kh * g.kw;
@@ -288,7 +353,6 @@ int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf, float* 
   }
   // taps whose parity class has an empty lattice (input extent smaller than the stride) keep nt = 0:
   // no input position ever sees them, the kernel skips them
-  hipStream_t st = (hipStream_t)stream;
   if (taps <= 9) {
     const int cin_ext = wf ? df.Cp : g.Cin, cout_ext = cp_out ? cp_out : g.Cout;
     hipLaunchKernelGGL(w_transform_tiled_kernel, dim3((cin_ext + 15) / 16, (cout_ext + 15) / 16), dim3(256), 0, st, w,

@@ -71,7 +71,7 @@ class ConvPlan:
         self.wt_elems = C.slv_conv_wt_elems(self.gp)
         self.set_configs(0, 0, 0)
         if benchmark:
-            key = ",".join(str(int(v)) for v in self.geom)
+            key = ",".join(str(int(v)) for v in self.geom) + ("" if C.slv_conv_get_arithmetic() else ",native")
             hit = _tune_cache().get(key)
             if hit is not None:
                 self.set_configs(*hit)
@@ -107,6 +107,19 @@ class ConvPlan:
         if p is None:
             p = cls._cache[key] = cls(*in_shape, Cout, k, stride, pad, device)
         return p
+
+
+def set_conv_arithmetic(mode):
+    """"x3" (default): the fp32 convs run on the bf16 matrix cores with operands split exactly into three bf16 pieces, six
+    partial products, fp32 accumulation (csrc/igemm3.hpp); "native": the fp32-input MFMA kernels (csrc/igemm.hpp).
+    Plans (weight-image sizes, launch configurations) depend on it: they are dropped."""
+    assert mode in ("x3", "native")
+    C.slv_conv_set_arithmetic(1 if mode == "x3" else 0)
+    ConvPlan._cache.clear()
+
+
+def conv_arithmetic():
+    return "x3" if C.slv_conv_get_arithmetic() else "native"
 
 
 def plan_for(xin, conv):

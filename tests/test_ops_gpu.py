@@ -7,6 +7,17 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["x3", "native"], autouse=True)
+def conv_arithmetic(request):
+    """Every op test runs on both conv arithmetics of the fp32 path: "x3" (default; csrc/igemm3.hpp: operands split exactly
+    into three bf16 pieces, six partial products on the bf16 matrix cores, fp32 accumulation) and "native" (csrc/igemm.hpp:
+    v_mfma_f32_16x16x4_f32) -- same tolerances for both (5e-6 L2 against fp64 where the test has an fp64 reference)."""
+    from selavi_amd import ops
+    ops.set_conv_arithmetic(request.param)
+    yield request.param
+    ops.set_conv_arithmetic("x3")
+
 # (Bn, Cin, T, H, W, Cout, k, stride, pad)  -- every conv family of R(2+1)D-18 / ResNet-9, odd channels,
 # stride 2, odd T (T=15 -> 8), tails in M, N and K
 GEOMS = [
@@ -376,3 +387,43 @@ def test_batch_sliced_conv_equals_unsliced(geo, monkeypatch):
     monkeypatch.setattr(ops, "CONV_BUF_LIMIT", per_clip // 2)
     with pytest.raises(ValueError):
         ops.ConvPlan(Bn, Cin, T, H, W, Cout, k, st, pd, dev)
+
+
+@pytest.mark.parametrize("geo", [GEOMS[2], GEOMS[3], GEOMS[4], GEOMS[7], GEOMS[9]])
+def test_split_operand_arithmetic_is_as_accurate_as_the_native_fp32_mfma(geo, conv_arithmetic):
+    """The claim behind the default arithmetic (csrc/igemm3.hpp header): cutting both fp32 operands exactly into three bf16
+    pieces and dropping the three smallest of the nine partial products leaves an error of the size of ONE fp32 rounding
+    per product -- forward, backward data and weight gradient against fp64, side by side with the native fp32-input MFMA
+    kernels on the same data: the split path's L2 error must not exceed 1.5 x the native path's (measured: 0.6-1.0 x; both
+    ~3-6e-7), and on operands that ARE bf16 values (pieces 2 and 3 zero) it is as exact as fp32 accumulation allows."""
+    if conv_arithmetic != "x3":
+        pytest.skip("compares both arithmetics in one run")
+    from selavi_amd import ops
+    Bn, Cin, T, H, W, Cout, k, st, pd = geo
+    dev = torch.device("cuda")
+    x = _mk((Bn, Cin, T, H, W), 11)
+    w = _mk((Cout, Cin) + k, 12, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv3d(xr, wr, stride=st, padding=pd)
+    dy = _mk(tuple(y64.shape), 13)
+    y64.backward(dy.double())
+    errs = {}
+    for mode in ("native", "x3"):
+        ops.set_conv_arithmetic(mode)
+        plan = ops.ConvPlan.get((Bn, Cin, T, H, W), Cout, k, st, pd, dev)
+        y, _, _ = ops.conv_fwd(plan, x.to(dev), w.to(dev))
+        dx = ops.conv_dgrad(plan, dy.to(dev), ops.conv_wt_transform(plan, w.to(dev)))
+        dw = ops.conv_wgrad(plan, dy.to(dev), x.to(dev))
+        rel = lambda got, want: float((got.detach().cpu().double().flatten() - want.flatten()).norm() / want.norm())
+        errs[mode] = (rel(y, y64.detach()), rel(dx, xr.grad), rel(dw.view_as(w), wr.grad))
+    ops.set_conv_arithmetic("x3")
+    print("L2 error vs fp64 (fwd, dgrad, wgrad): native %s  x3 %s" % (["%.2e" % e for e in errs["native"]], ["%.2e" % e for e in errs["x3"]]))
+    for en, e3 in zip(errs["native"], errs["x3"]):
+        assert e3 <= 5e-6 and e3 <= 1.5 * en + 1e-7, (errs["native"], errs["x3"])
+    # bf16-valued operands: the split is (x, 0, 0) and every product exact -> the x3 result equals fp32 accumulation of exact
+    # products, i.e. as close to fp64 as the native kernel on the same values
+    xb, wb = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    yb64 = F.conv3d(xb.double(), wb.double(), stride=st, padding=pd)
+    plan = ops.ConvPlan.get((Bn, Cin, T, H, W), Cout, k, st, pd, dev)
+    yb, _, _ = ops.conv_fwd(plan, xb.to(dev), wb.to(dev))
+    _close_l2(yb, yb64, rtol=2e-6)

@@ -543,7 +543,7 @@ def test_bf16_training_step_against_fp32_step():
     assert l16 == l16b and torch.equal(w16, w16b)
 
 
-def _oracle_step_on_rounded(B, T, S, hc, K, round_activations):
+def _oracle_step_on_rounded(B, T, S, hc, K, round_activations, damp=None):
     """oracle/step_ref (torch CPU, fp32 arithmetic) on the operands the 16-bit path sees: the conv weights of both trunks,
     the clip and the spectrogram rounded to bf16; with ``round_activations`` every conv output is additionally stored as bf16 (forward value and
     the gradient that flows back through it), which is what the channels-last bf16 tensors of the HIP path do."""
@@ -557,6 +557,8 @@ def _oracle_step_on_rounded(B, T, S, hc, K, round_activations):
         for p in list(m.video_network.parameters()) + list(m.audio_network.parameters()):
             if p.dim() >= 4:
                 p.copy_(p.to(torch.bfloat16).float())
+    if damp is not None:
+        _damp(m, damp)
     hooks = []
     if round_activations:
         for mod in list(m.video_network.modules()) + list(m.audio_network.modules()):
@@ -574,7 +576,7 @@ def _oracle_step_on_rounded(B, T, S, hc, K, round_activations):
     return float(loss), grads
 
 
-@pytest.mark.parametrize("shape", [(8, 8, 64), (4, 8, 112)], ids=["b8_t8_64px", "b4_t8_112px_layer1_maps_56x56"])
+@pytest.mark.parametrize("shape", [(8, 8, 64, None), (4, 8, 112, 0.1)], ids=["b8_t8_64px", "b4_t8_112px_layer1_maps_56x56"])
 def test_bf16_step_against_the_cpu_oracle_on_rounded_operands(shape):
     """DIRECT oracle check of the 16-bit step (no HIP-vs-HIP transitivity, no damped init): oracle/step_ref.train_step in
     fp32 arithmetic on the bf16-rounded conv weights and clip, at the reference's own initialisation, against the HIP bf16
@@ -585,11 +587,17 @@ def test_bf16_step_against_the_cpu_oracle_on_rounded_operands(shape):
     the HIP path's: other accumulation orders, so other roundings) then agree to about f * f -- the HIP step is held to
     that, per tensor (h >= f^2 - 0.12), to > 0.9 wherever the oracles agree to 0.98, and in the median over tensors.
     Second shape: 112 x 112 clips, i.e. 56 x 56 layer-1 maps -- the native tile geometry of the register-resident layer-1
-    kernels (conv_cl16_sr / _sd / _tr, wgrad_cl16_acc / _tacc), so that those kernels sit inside an oracle-pinned step."""
+    kernels (conv_cl16_sr / _sd / _tr, wgrad_cl16_acc / _tacc), so that those kernels sit inside an oracle-pinned step.
+    With 4 clips the chaos is worse still (oracle-vs-oracle median 0.50, minimum 0.29: the f^2 floor says nothing there), so
+    that case starts the residual blocks close to the identity (last BatchNorm gamma 0.1 in the oracle AND the HIP model,
+    the zero-init-residual recipe of test_bf16_training_step_against_fp32_step): the backward is well conditioned and the
+    HIP gradients must follow the oracle's."""
     from selavi_amd.utils import get_loss
-    B, T, S = shape
+    B, T, S, damp = shape
     hc, K = 2, 7
     m, opt, video, audio, sl, sel, _ = _step_setup("bf16", hc=hc, K=K, B=4, T=T, S=S)
+    if damp is not None:
+        _damp(m, damp)
     from oracle.model_ref import portable_fill_
     video = portable_fill_(torch.empty(B, 3, T, S, S), 5).cuda()
     audio = portable_fill_(torch.empty(B, 1, 40, 36), 6).cuda()
@@ -600,8 +608,8 @@ def test_bf16_step_against_the_cpu_oracle_on_rounded_operands(shape):
     opt.zero_grad()
     loss.backward()
     g16 = {n: p.grad.detach().cpu().double().flatten() for n, p in m.named_parameters() if n.startswith("video_network")}
-    l_plain, g_plain = _oracle_step_on_rounded(B, T, S, hc, K, False)
-    l_store, g_store = _oracle_step_on_rounded(B, T, S, hc, K, True)
+    l_plain, g_plain = _oracle_step_on_rounded(B, T, S, hc, K, False, damp)
+    l_store, g_store = _oracle_step_on_rounded(B, T, S, hc, K, True, damp)
     l16 = float(loss.detach())
     # the loss inherits the chaos: the two ORACLE runs differ by 0.4 % here, and on the HIP side swapping one early conv
     # for a kernel with another fp32 summation order (a handful of last-place bf16 flips in its output, same statistics

@@ -29,7 +29,7 @@ def main(path, pattern):
     lines = txt.split("\n")
     meta = {m.group(1): m.group(2) for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S)}
     for name, body_meta in meta.items():
-        if pattern not in name or ("igemm_kernel" not in name and "conv_cl16_kernel" not in name and "conv_cl16_s3_kernel" not in name and "cl16_wgrad_kernel" not in name):
+        if pattern not in name or ("igemm_kernel" not in name and "igemm3" not in name and "conv_cl16_kernel" not in name and "conv_cl16_s3_kernel" not in name and "cl16_wgrad_kernel" not in name):
             continue
         start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
         end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
