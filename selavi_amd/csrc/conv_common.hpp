@@ -392,6 +392,7 @@ struct Cfg {
 static bool tile_ok(int mt, int nt, int mf) {
   if (mf) return nt == 2 && (mt == 4 || mt == 6 || mt == 8);
   if (nt == 4) return mt == 4 || mt == 8 || mt == 9;      // 8-wave workgroups of the split-operand kernels (igemm3.hpp) only
+  if (nt == 3) return mt == 4 || mt == 8 || mt == 9;      // 192-column tiles: split-operand weight gradient only (N = 576 = 3 x 192)
   return ((mt == 4 || mt == 8 || mt == 9) && (nt == 1 || nt == 2)) || (mt == 15 && nt == 1);
 }
 static int32_t pack_cfg(int mt, int nt, int sp, int mf) { return mt | (nt << 8) | (mf << 12) | (sp << 16); }
@@ -442,6 +443,10 @@ static int wgrad_cfg(const Geom& g, int32_t cfg, Cfg& c) {
   if (cfg == 0) {
     c.mt = pick_mt(g.Cout);
     c.nt = c.mt >= 15 ? 1 : 2;
+    if (c.nt == 2 && x3_enabled()) {        // split-operand kernel: 192-column tiles where they pad less (Cin * taps = 576)
+      const long long N = (long long)g.Cin * g.kt * g.kh * g.kw;
+      if ((N + 191) / 192 * 192 < (N + 127) / 128 * 128) c.nt = 3;
+    }
     c.sp = wgrad_splits(g, c.mt, c.nt);
     return 0;
   }

@@ -68,12 +68,19 @@ __global__ void w_transform_kernel(const float* __restrict__ w, float* __restric
 // (igemm3.hpp: split3) and stored to the three planes; padding (channels beyond C, rows beyond M, the odd half chunk) is
 // written as zeros, so no memset.  transposed = 0: rows = Cout, gathered channel = ci (forward); 1: rows = Cin,
 // gathered channel = co (backward data, taps = this parity class' taps).
-struct SplitTaps {
-  int t[64];
+struct SplitDesc {
+  unsigned long long off;      // dword offset of this launch's image inside the buffer
+  int M, Cg, Kd, ntaps, transposed;
+  int taps[27];
 };
-__global__ __launch_bounds__(256) void w_split_kernel(const float* __restrict__ w, unsigned* __restrict__ img, int M, int Cg,
-                                                      int Kd, int ntaps, const SplitTaps taps, int Cin, int taps_all,
-                                                      int transposed) {
+struct SplitArgs {
+  SplitDesc d[9];              // the forward image + up to 8 stride-parity classes of the backward data: ONE launch per layer
+};
+__global__ __launch_bounds__(256) void w_split_kernel(const float* __restrict__ w, unsigned* __restrict__ wf_img,
+                                                      unsigned* __restrict__ wt_img, const SplitArgs args, int Cin, int taps_all) {
+  const SplitDesc& d = args.d[blockIdx.y];
+  const int M = d.M, Cg = d.Cg, Kd = d.Kd, ntaps = d.ntaps, transposed = d.transposed;
+  unsigned* img = (transposed ? wt_img : wf_img) + d.off;
   const int Mp = (M + 15) / 16 * 16, nch = (Kd + 31) / 32;
   const size_t total = (size_t)nch * Mp * 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256) void w_split_kernel(const float* __restrict__ 
       float v = 0.f;
       if (k < Kd && row < M) {
         const int grp = k >> 4, j = grp % ntaps, c = (grp / ntaps) * 16 + (k & 15);
-        if (c < Cg) v = transposed ? w[((size_t)c * Cin + row) * taps_all + taps.t[j]] : w[((size_t)row * Cin + c) * taps_all + taps.t[j]];
+        if (c < Cg) v = transposed ? w[((size_t)c * Cin + row) * taps_all + d.taps[j]] : w[((size_t)row * Cin + c) * taps_all + d.taps[j]];
       }
       const unsigned u = __float_as_uint(v);
       h[e] = u & 0xffff0000u;
@@ -104,14 +111,12 @@ __global__ __launch_bounds__(256) void w_split_kernel(const float* __restrict__ 
     }
   }
 }
-static void launch_w_split(const float* w, float* img, const Desc& d, int Cin, int taps_all, int transposed, hipStream_t st) {
-  SplitTaps tp;
-  for (int j = 0; j < 64; ++j) tp.t[j] = j < d.ntaps ? d.taps[j] : 0;
-  const size_t total = (size_t)((d.Kd + 31) / 32) * ((d.M + 15) / 16 * 16) * 4;
-  if (total == 0 || d.ntaps == 0) return;          // a parity class no tap reaches: no weights, the launch has no K steps
-  const unsigned blocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  hipLaunchKernelGGL(w_split_kernel, dim3(blocks), dim3(256), 0, st, w, (unsigned*)img, d.M, d.C, d.Kd, d.ntaps, tp, Cin,
-                     taps_all, transposed);
+static bool split_desc(SplitDesc& o, const Desc& d, size_t off_floats, int transposed) {
+  if (d.ntaps == 0 || d.Kd == 0 || d.ntaps > 27) return false;      // a parity class no tap reaches: no weights, no K steps
+  o.off = off_floats;
+  o.M = d.M; o.Cg = d.C; o.Kd = d.Kd; o.ntaps = d.ntaps; o.transposed = transposed;
+  for (int j = 0; j < 27; ++j) o.taps[j] = j < d.ntaps ? d.taps[j] : 0;
+  return true;
 }
 }  // namespace slv
 
@@ -148,8 +153,9 @@ int slv_conv_table(const int32_t* geom, int dgrad, int32_t* tab_host_out) {
 int32_t slv_conv_configs(const int32_t* geom, int op, int32_t* out, int32_t max_out) {
   Geom g;
   if (read_geom(geom, g) != 0 || !out || max_out <= 0 || op < 0 || op > 2) return -1;
-  static const int tiles[13][3] = {{9, 2, 0}, {8, 2, 0}, {15, 1, 0}, {4, 2, 0}, {9, 1, 0}, {8, 1, 0}, {4, 1, 0},
-                                   {8, 2, 1}, {6, 2, 1}, {4, 2, 1}, {9, 4, 0}, {8, 4, 0}, {4, 4, 0}};
+  static const int tiles[16][3] = {{9, 2, 0}, {8, 2, 0}, {15, 1, 0}, {4, 2, 0}, {9, 1, 0}, {8, 1, 0}, {4, 1, 0},
+                                   {8, 2, 1}, {6, 2, 1}, {4, 2, 1}, {9, 4, 0}, {8, 4, 0}, {4, 4, 0},
+                                   {9, 3, 0}, {8, 3, 0}, {4, 3, 0}};
   const int taps = g.kt * g.kh * g.kw;
   int M;
   long long N, chunks;
@@ -177,6 +183,7 @@ int32_t slv_conv_configs(const int32_t* geom, int op, int32_t* out, int32_t max_
     const bool x3 = op != 2 && x3_enabled() && want_tap_major(op == 0 ? g.Cin : g.Cout);
     if (t[2] && x3) continue;            // split-operand kernels: 16 x 16 tiles only
     if (t[1] == 4 && !x3) continue;      // 256-column (8-wave) tiles: split-operand conv kernels only
+    if (t[1] == 3 && !(op == 2 && x3_enabled())) continue;   // 192-column tiles: split-operand weight gradient only
     int cand[12], nc = 0;
     if (op != 2) {
       static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
@@ -322,18 +329,30 @@ int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf, float* 
   Desc ds[8];
   const int n = dgrad_descs(g, ds);
   hipStream_t st = (hipStream_t)stream;
-  // split-operand launches (igemm3.hpp) read a three-plane bf16 image instead of the fp32 re-layout
-  if (wf && df.x3) {
-    launch_w_split(w, wf, df, g.Cin, g.kt * g.kh * g.kw, 0, st);
-    SLV_LAUNCH_CHECK();
-    wf = nullptr;
-  }
-  if (wt && n > 0 && ds[0].x3) {
-    for (int i = 0; i < n; ++i) {
-      launch_w_split(w, wt + ds[i].wt_off, ds[i], g.Cin, g.kt * g.kh * g.kw, 1, st);
+  // split-operand launches (igemm3.hpp) read a three-plane bf16 image instead of the fp32 re-layout: one launch makes the
+  // forward image and the images of every stride-parity class of the backward data
+  {
+    SplitArgs sa;
+    int nd = 0;
+    size_t maxtot = 0;
+    auto tot = [](const Desc& d) { return (size_t)((d.Kd + 31) / 32) * ((d.M + 15) / 16 * 16) * 4; };
+    if (wf && df.x3) {
+      SLV_CHECK_ARG(df.ntaps <= 27, "more than 27 taps");
+      if (split_desc(sa.d[nd], df, 0, 0)) { maxtot = tot(df); ++nd; }
+    }
+    if (wt && n > 0 && ds[0].x3)
+      for (int i = 0; i < n; ++i) {
+        SLV_CHECK_ARG(ds[i].ntaps <= 27, "more than 27 taps in one stride-parity class");
+        if (split_desc(sa.d[nd], ds[i], ds[i].wt_off, 1)) { if (tot(ds[i]) > maxtot) maxtot = tot(ds[i]); ++nd; }
+      }
+    if (nd > 0) {
+      const unsigned bx = (unsigned)((maxtot + 255) / 256 < 1024 ? (maxtot + 255) / 256 : 1024);
+      hipLaunchKernelGGL(w_split_kernel, dim3(bx, nd), dim3(256), 0, st, w, (unsigned*)wf, (unsigned*)wt, sa, g.Cin,
+                         g.kt * g.kh * g.kw);
       SLV_LAUNCH_CHECK();
     }
-    wt = nullptr;
+    if (df.x3) wf = nullptr;
+    if (n > 0 && ds[0].x3) wt = nullptr;
   }
   if (!wf && !wt) return 0;
   TapMap tm;

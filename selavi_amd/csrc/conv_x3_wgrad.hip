@@ -10,6 +10,7 @@ int launch_x3_wgrad(const IgemmArgs& a, int mt, int nt, int splits, bool vec_a, 
 #define SLV_CASE3(MT_, NT_) \
   if (mt == MT_ && nt == NT_) { launch_igemm3_wgrad<MT_, NT_>(a, splits, vec_a, st); return 0; }
   SLV_CASE3(4, 1) SLV_CASE3(4, 2) SLV_CASE3(8, 1) SLV_CASE3(8, 2) SLV_CASE3(9, 1) SLV_CASE3(9, 2) SLV_CASE3(15, 1)
+  SLV_CASE3(4, 3) SLV_CASE3(8, 3) SLV_CASE3(9, 3)
 #undef SLV_CASE3
   return -1;
 }

@@ -116,6 +116,25 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
   const int ntab = ((g.Kd >> 4) + 4) & ~1;                      // entries (even: 16-byte pairs)
   int2* ttab = (int2*)dyn_lds;
   float* ptab = (float*)(dyn_lds + 2 * ntab);
+  // (the first A stage is requested before anything else: it needs no table, and the prologue is two memory round trips
+  //  otherwise -- tables, then operands)
+  const int nch16_ = g.Kd >> 4;
+  const int cbase0 = g.chunks_per_split > 0 ? split * g.chunks_per_split : 0;
+  const bool any_chunk = g.chunks_per_split > 0 ? (cbase0 < ((nch16_ + 1) >> 1)) : (nch16_ > 0);
+  const unsigned voffA = (unsigned)(lane * 16) + (unsigned)m0 * 64u;
+  const unsigned lds_base = (unsigned)(unsigned long)(lds_void)smem;
+  if (any_chunk) {
+    const unsigned chunk_off = (unsigned)cbase0 * 3u * (unsigned)Mp * 64u;
+#pragma unroll
+    for (int t = 0; t < (NDMA + WAVES - 1) / WAVES; ++t) {
+      const int idx = wave + WAVES * t;
+      if (idx < NDMA && SLV_X3_ABL != 2) {
+        const int p = idx / MT, rt = idx - p * MT;
+        x3_dma16(__builtin_amdgcn_readfirstlane(lds_base + (unsigned)(p * (BM * 64) + rt * 1024)), voffA, rA,
+                 __builtin_amdgcn_readfirstlane(chunk_off + (unsigned)(p * Mp + rt * 16) * 64u));
+      }
+    }
+  }
   for (int i = tid; i < ntab; i += NTHR) ttab[i] = g.tab[i];
   if constexpr (PRO == PRO_ACT) {
     for (int i = tid; i < 2 * CbP; i += NTHR) {
@@ -172,8 +191,6 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
 
   // ---- A: LDS-DMA of this block's rows of the x3 image.  Piece idx = wave + 4 t: plane idx / MT, 16-row tile idx % MT;
   // a lane moves 16 bytes: memory (chunk, plane, row m0 + 16 rt + lane / 4, slot lane % 4) -> the same place of the LDS stage
-  const unsigned voffA = (unsigned)(lane * 16) + (unsigned)m0 * 64u;
-  const unsigned lds_base = (unsigned)(unsigned long)(lds_void)smem;
   auto dma_a = [&](int c) __attribute__((always_inline)) {
     const unsigned chunk_off = (unsigned)(cbase + c) * 3u * (unsigned)Mp * 64u;
     const unsigned dst = lds_base + (unsigned)((c & 1) * A_BYTES);
@@ -329,8 +346,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1{};
     X3_T(1);
-    dma_a(0);
-    load_chunk(0, P0);
+    load_chunk(0, P0);                                    // (stage 0 was requested at the top of the kernel)
     if (nchunks > 1) load_chunk(1, P1);
     asm volatile("s_waitcnt vmcnt(0)");                   // this wave's DMA pieces (the compiler does not count them)
     __syncthreads();                 // ... everybody's
@@ -513,7 +529,8 @@ inline void launch_igemm3(IgemmArgs a, int splits, hipStream_t st) {
     a.chunks_per_split = (ch32 + splits - 1) / splits;
   }
   const bool act = a.b_pro == PRO_ACT;
-  constexpr int OCC_ = WAVES == 8 ? 1 : 2;
+  // workgroups per CU the register budget is cut for: the LDS (two A stages) admits 2 at MT = 9, 3 at MT = 8, 6 at MT = 4
+  constexpr int OCC_ = WAVES == 8 ? 1 : (MT <= 4 ? 4 : (MT <= 8 ? 3 : 2));
   const size_t dyn = (size_t)((((a.Kd >> 4) + 4) & ~1) * 8) + (act ? (size_t)2 * ((a.Cb + 15) / 16 * 16) * sizeof(float) : 0);
 #define SLV_K3(PRO_, EPI_) \
   hipLaunchKernelGGL((igemm3_kernel<MT, NT, PRO_, EPI_, WAVES, OCC_>), grid, dim3(64 * WAVES), dyn, st, a)
