@@ -250,7 +250,7 @@ FWD_MB_PER_CLIP_T32_BF16 = 1036.2 / 2 + 3.38           # video bytes halve in bf
 PEAK_BF16_MFMA_TF = 2500.0
 
 
-HOT_X3_KERNEL = "igemm3_kernel<9, 2, 1, 0, 4, 2>"     # csrc/igemm3.hpp: MT, NT, PRO, EPI, WAVES, OCC of the layer-1 spatial forward
+HOT_X3_KERNEL = "igemm3_kernel<9, 2, 1, 0, 4, 2, true>"     # csrc/igemm3.hpp: MT, NT, PRO, EPI, WAVES, OCC, FUSE of the layer-1 spatial forward
 HOT16_KERNEL = "conv_cl16_sr_kernel<1, 1>"      # csrc/conv_cl16_sr.hip: one persistent workgroup per CU (grid 256)
 
 
@@ -378,6 +378,58 @@ def bf16_leg(a, rank, world, local, dev):
                     "hbm_frac": FWD_MB_PER_CLIP_T32_BF16 * B / fwd_ms / PEAK_HBM_GBS,
                     "mfma_frac": FWD_GFLOP_PER_CLIP_T32 * B / fwd_ms / PEAK_BF16_MFMA_TF},
     }
+
+
+def cfg2_bf16_leg(a, dev):
+    """The HEADLINE shape (cfg2: 16 clips x 16 frames per GPU) on the 16-bit MFMA path -- what configs[1] costs when the
+    convs run in bf16 (fp32 master weights, fp32 BatchNorm statistics; not the parity path).  At this size the step is
+    ~700 short kernels: eager it is bound by the host's enqueue time, so the leg also replays it as ONE HIP graph
+    (train.GraphedStep: the three streams of the step stay concurrent inside the capture).  Single GPU only."""
+    from selavi_amd import model as smodel, optim, train
+    B, T, hc, K = CFG2["batch"], CFG2["T"], CFG2["hc"], CFG2["K"]
+    torch.manual_seed(31)
+    m = smodel.load_model(vid_base_arch='r2plus1d_18', aud_base_arch='resnet9', use_mlp=True, num_classes=K,
+                          pretrained=False, norm_feat=False, use_max_pool=False, headcount=hc).to(dev)
+    m.set_precision("bf16")
+    m.train()
+    opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+    g = torch.Generator(device=dev).manual_seed(99)
+    video = torch.randn(B, 3, T, CFG2["S"], CFG2["S"], device=dev, generator=g)
+    audio = torch.randn(B, 1, CFG2["F"], CFG2["Tp"], device=dev, generator=g)
+    selflabels = torch.randint(0, K, (4096, hc), device=dev, generator=g)
+    selected = torch.randint(0, 4096, (B,), device=dev, generator=g)
+
+    def timed(fn, n):
+        for _ in range(3):
+            loss = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, float(loss)
+    n = max(a.steps, 10)
+    eager_ms, loss_e = timed(lambda: train.train_step(m, opt, video, audio, selflabels, selected, hc), n)
+    t0 = time.perf_counter()
+    train.train_step(m, opt, video, audio, selflabels, selected, hc)
+    host_ms = (time.perf_counter() - t0) * 1e3            # enqueue time of one eager step (no device wait)
+    torch.cuda.synchronize()
+    out = {"metric": "clips/sec (video+audio fwd/bwd + loss + SGD), 16-bit MFMA path at the headline shape", "unit": "clips/s",
+           "dtype": "bf16", "steps": n,
+           "config": {"workload": "cfg2 shape (bs=16, 16x112x112, 1x129x100, K=309, headcount=10), both trunks bf16, heads fp32",
+                      "loss_last_step": loss_e},
+           "eager": {"value": B / eager_ms * 1e3, "ms_per_step": eager_ms, "host_enqueue_ms_per_step": host_ms}}
+    try:
+        gs = train.GraphedStep(m, opt, video, audio, selflabels, selected, hc)
+        graph_ms, loss_g = timed(gs.replay, n)
+        out["graph_replay"] = {"value": B / graph_ms * 1e3, "ms_per_step": graph_ms, "loss_last_step": loss_g}
+    except Exception as e:
+        out["graph_replay"] = {"error": repr(e)}
+    best = min(eager_ms, out["graph_replay"].get("ms_per_step", eager_ms))
+    out["value"], out["ms_per_step"] = B / best * 1e3, best
+    out["step_roofline"] = {"hbm": {"frac": 3 * (FWD_MB_PER_CLIP / 2) * B / best / PEAK_HBM_GBS},
+                            "mfma": {"frac": 3 * FWD_GFLOP_PER_CLIP * B / best / PEAK_BF16_MFMA_TF}}
+    return out
 
 
 def cpu_baseline(batch, warm=3, timed=3):
@@ -561,6 +613,12 @@ def main():
             if world > 1:
                 raise                                # (but ranks must not diverge inside collectives)
             cfg5 = {"error": repr(e)}
+    cfg2_16 = None
+    if world == 1 and not a.no_cfg5:
+        try:
+            cfg2_16 = cfg2_bf16_leg(a, dev)
+        except Exception as e:                       # an extra leg: never take the headline line down with it
+            cfg2_16 = {"error": repr(e)}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.cpu_batch)
@@ -625,6 +683,7 @@ def main():
             "sk": sk,
             "sk_round": sk_round,
             "cfg5_bf16": cfg5,
+            "cfg2_bf16": cfg2_16,
             "native_fp32_mfma": native,
             "cpu_baseline": cpu,
         }

@@ -69,12 +69,18 @@ __device__ unsigned long long slv_x3_trace_buf[64][160];
 constexpr int X3_MAXC = 1152;     // widest gathered tensor of the two trunks (prologue table in LDS)
 // WAVES: 4 or 8 waves per workgroup (8: the A stage is fetched once per (NT*128) columns instead of per (NT*64) -- the
 // weight traffic L2 -> LDS per MFMA halves; same LDS, same waves per SIMD as two 4-wave workgroups)
-template <int MT, int NT, int PRO, int EPI, int WAVES, int OCC>
+// FUSE: B two chunks deep with the split between the MFMAs (above); false: one chunk deep, the split behind the chunk's
+// MFMAs -- ~90 registers fewer (no second operand set, none of the rematerialisation the long live ranges cause: 140
+// instead of 290 VALU instructions per chunk), which buys a third workgroup per CU for the tiles whose LDS admits it (MT <= 8).
+template <int MT, int NT, int PRO, int EPI, int WAVES, int OCC, bool FUSE>
 __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs g) {
   constexpr int BM = MT * 16, BN = NT * 16 * WAVES, NTHR = 64 * WAVES;
   constexpr int A_BYTES = 3 * BM * 64;
   constexpr int EPI_BYTES = (2 * WAVES + 4) * BM * 4;
-  constexpr int SMEM = 2 * A_BYTES > EPI_BYTES ? 2 * A_BYTES : EPI_BYTES;
+#ifndef SLV_X3_LDS_PAD
+#define SLV_X3_LDS_PAD 0          // experiment: extra LDS bytes per workgroup (forces fewer workgroups per CU)
+#endif
+  constexpr int SMEM = (2 * A_BYTES > EPI_BYTES ? 2 * A_BYTES : EPI_BYTES) + SLV_X3_LDS_PAD;
   constexpr int NDMA = 3 * MT;          // 1 KiB pieces of an A stage (16 rows of one plane each)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
   // dynamic LDS: the tap table of this launch ([Kd / 16 + 4] entries {offset, tap | first channel << 8}: read per chunk
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
   // fragment registers and puts a full LDS round trip in front of every MFMA pair); the region's order is laid down with
   // sched_group_barrier: per step 3 G LDS reads, then its 6 G NT MFMAs each followed by two VALU instructions.
   // A step = G row tiles (G = 2 when NT == 1), so that two independent accumulators alternate in the MFMA stream.
-  auto compute = [&](int buf, auto par, auto with_split, auto full_tag) __attribute__((always_inline)) {
+  auto compute = [&](int buf, auto par, auto with_split, auto full_tag, int cnext = 0) __attribute__((always_inline)) {
     constexpr int P = decltype(par)::value;
     constexpr bool SPLIT = decltype(with_split)::value;
     constexpr bool FULL = decltype(full_tag)::value;
@@ -294,7 +300,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
     for (int gi = 0; gi < G; ++gi)
 #pragma unroll
       for (int p = 0; p < 3; ++p) a[0][gi][p] = *(const bf16x8*)(As + (gi < MT ? gi : 0) * 1024 + p * BM * 64);
-    if constexpr (SPLIT && FULL) split_chunk(std::integral_constant<int, P ^ 1>{});
+    if constexpr (SPLIT && FULL && FUSE) split_chunk(std::integral_constant<int, P ^ 1>{});
+    (void)cnext;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if (s + 1 < NS) {
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
           for (int p = 0; p < 3; ++p) a[(s + 1) & 1][gi][p] = *(const bf16x8*)(As + i * 1024 + p * BM * 64);
         }
       }
-      if constexpr (!FULL) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!FULL || !FUSE) __builtin_amdgcn_sched_barrier(0);
       // products (plane of A, plane of B), small terms first; the G x NT accumulators of the step alternate
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -321,9 +328,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
             }
           }
         }
-      if constexpr (!FULL) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!FULL || !FUSE) __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (FULL) {
+    if constexpr (FULL && FUSE) {
       // the order of the region: [reads of step 0 (+ the table reads of the split)] then per step [reads of step s + 1]
       // [its MFMAs, two VALU behind each]
       __builtin_amdgcn_sched_group_barrier(0x100, 3 * G + (SPLIT && PRO == PRO_ACT ? 4 : 0), 0);
@@ -347,12 +354,13 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
     constexpr std::integral_constant<int, 1> P1{};
     X3_T(1);
     load_chunk(0, P0);                                    // (stage 0 was requested at the top of the kernel)
-    if (nchunks > 1) load_chunk(1, P1);
+    if (FUSE && nchunks > 1) load_chunk(1, P1);
     asm volatile("s_waitcnt vmcnt(0)");                   // this wave's DMA pieces (the compiler does not count them)
     __syncthreads();                 // ... everybody's
     split_chunk(P0);
     X3_T(2);
     // iteration c: stage / fragment set c & 1 is multiplied, raw set (c + 1) & 1 is split, raw set c & 1 is re-loaded (chunk c + 2)
+    // (!FUSE: raw set (c + 1) & 1 is loaded at the top of the iteration and split at its end)
     auto iter = [&](int c, auto par) __attribute__((always_inline)) {
       constexpr int P = decltype(par)::value;
 #ifdef SLV_X3_TRACE
@@ -361,9 +369,13 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
       X3_T(tb + 0);
       dma_a(c + 1);                  // into the stage every wave finished reading before the previous barrier
       X3_T(tb + 1);
-      if (c + 2 < nchunks) load_chunk(c + 2, par);
+      if constexpr (FUSE) {
+        if (c + 2 < nchunks) load_chunk(c + 2, par);       // (placing these loads between the MFMAs as well: measured, no gain)
+      } else {
+        load_chunk(c + 1, std::integral_constant<int, P ^ 1>{});
+      }
       X3_T(tb + 2);
-      compute(P, par, std::true_type{}, full_tag);
+      compute(P, par, std::true_type{}, full_tag, c + 2);  // (!FUSE: the split of raw set P ^ 1 follows the MFMAs inside)
       X3_T(tb + 3);
       asm volatile("s_waitcnt vmcnt(0)");                 // this wave's DMA pieces of chunk c + 1 (the barrier's fence pins the order)
       __syncthreads();               // stage (c + 1) & 1 has landed for everybody and stage c & 1 is free
@@ -530,10 +542,13 @@ inline void launch_igemm3(IgemmArgs a, int splits, hipStream_t st) {
   }
   const bool act = a.b_pro == PRO_ACT;
   // workgroups per CU the register budget is cut for: the LDS (two A stages) admits 2 at MT = 9, 3 at MT = 8, 6 at MT = 4
-  constexpr int OCC_ = WAVES == 8 ? 1 : (MT <= 4 ? 4 : (MT <= 8 ? 3 : 2));
+  // MT = 9 (two A stages = 55 KB: two workgroups per CU at most): fused two-deep pipeline; MT <= 8: the lean pipeline, three
+  // workgroups per CU (the fused one spills under that register cap)
+  constexpr bool FUSE_ = WAVES == 8 || MT >= 9;
+  constexpr int OCC_ = WAVES == 8 ? 1 : (FUSE_ ? 2 : 3);
   const size_t dyn = (size_t)((((a.Kd >> 4) + 4) & ~1) * 8) + (act ? (size_t)2 * ((a.Cb + 15) / 16 * 16) * sizeof(float) : 0);
 #define SLV_K3(PRO_, EPI_) \
-  hipLaunchKernelGGL((igemm3_kernel<MT, NT, PRO_, EPI_, WAVES, OCC_>), grid, dim3(64 * WAVES), dyn, st, a)
+  hipLaunchKernelGGL((igemm3_kernel<MT, NT, PRO_, EPI_, WAVES, OCC_, FUSE_>), grid, dim3(64 * WAVES), dyn, st, a)
   if constexpr (SUBSET != SUB_FWD) {
     if (a.R) { SLV_K3(PRO_NONE, EPI_BNR); return; }
   }
@@ -719,8 +734,12 @@ __global__ __launch_bounds__(256, OCC) void igemm3_wgrad_kernel(const IgemmArgs 
       if (row < BM) put(As + row * 64 + (((aq >> 1) ^ cl_swz(row & 15)) << 4) + (aq & 1) * 8, BM * 64, ra4[i]);
     }
   };
-  bf16x8 bfr[NT][3];
-  auto split_b = [&]() __attribute__((always_inline)) {
+  // FUSE: the next chunk's split runs between this chunk's MFMAs and needs a second fragment set (NT <= 2; the 192-column
+  // tiles have no registers for it: their split stands between two chunks)
+  constexpr bool FUSE = NT <= 2;
+  bf16x8 bfr[FUSE ? 2 : 1][NT][3];   // the B fragments of the chunk being multiplied (set = its parity) and of the next one
+  auto split_b = [&](auto par) __attribute__((always_inline)) {
+    constexpr int P = FUSE ? decltype(par)::value : 0;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       unsigned w[3][4];
@@ -746,7 +765,7 @@ __global__ __launch_bounds__(256, OCC) void igemm3_wgrad_kernel(const IgemmArgs 
         w[2][2 * qd] = pack_hi16(l[0], l[1]); w[2][2 * qd + 1] = pack_hi16(l[2], l[3]);
       }
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bfr[j][p] = __builtin_bit_cast(bf16x8, (u32x4){w[p][0], w[p][1], w[p][2], w[p][3]});
+      for (int p = 0; p < 3; ++p) bfr[P][j][p] = __builtin_bit_cast(bf16x8, (u32x4){w[p][0], w[p][1], w[p][2], w[p][3]});
     }
   };
 
@@ -758,17 +777,28 @@ __global__ __launch_bounds__(256, OCC) void igemm3_wgrad_kernel(const IgemmArgs 
   const int mtv = __builtin_amdgcn_readfirstlane((mrem + 15) / 16);
   const int foff = fi * 64 + ((fk ^ cl_swz(fi)) << 4);
 
-  auto compute = [&](int buf, auto full_tag) __attribute__((always_inline)) {
+  // One chunk of MFMAs on stage / fragment set P; WITH_NEXT: the raw elements of the next chunk (requested at the top of the
+  // iteration) are cut into their pieces in the SAME scheduling region -- the gradient quads into LDS stage P ^ 1, the
+  // gathered quads into fragment set P ^ 1 -- between the MFMAs of the later row-tile steps (the loads have landed by then):
+  // ~350 VALU instructions and 15 LDS writes per chunk ride in the MFMAs' issue gaps instead of standing between two chunks.
+  auto compute = [&](auto par, auto with_next, auto full_tag) __attribute__((always_inline)) {
+    constexpr int P = decltype(par)::value, PF = FUSE ? P : 0;
+    constexpr bool NEXT = decltype(with_next)::value;
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr int G = NT == 1 ? 2 : 1;
     constexpr int NS = (MT + G - 1) / G;
-    const unsigned char* As = smem + buf * A_BYTES + foff;
+    constexpr int S0 = NS >= 6 ? 2 : 1;                     // first step that carries split work
+    const unsigned char* As = smem + P * A_BYTES + foff;
     bf16x8 a[2][G][3];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
 #pragma unroll
       for (int p = 0; p < 3; ++p) a[0][gi][p] = *(const bf16x8*)(As + (gi < MT ? gi : 0) * 1024 + p * BM * 64);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NEXT && FULL && FUSE) {
+      store_a(P ^ 1);
+      split_b(std::integral_constant<int, P ^ 1>{});
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if (s + 1 < NS) {
@@ -779,7 +809,7 @@ __global__ __launch_bounds__(256, OCC) void igemm3_wgrad_kernel(const IgemmArgs 
           for (int p = 0; p < 3; ++p) a[(s + 1) & 1][gi][p] = *(const bf16x8*)(As + i * 1024 + p * BM * 64);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!FULL || !FUSE) __builtin_amdgcn_sched_barrier(0);
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
       for (int t = 0; t < 6; ++t)
@@ -789,25 +819,56 @@ __global__ __launch_bounds__(256, OCC) void igemm3_wgrad_kernel(const IgemmArgs 
           if (i < MT && (FULL || i < mtv)) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][gi][PA[t]], bfr[j][PB[t]], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][gi][PA[t]], bfr[PF][j][PB[t]], acc[i][j], 0, 0, 0);
           }
         }
+      if constexpr (!FULL || !FUSE) __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (FULL && FUSE) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * G, 0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 3 * G, 0);
+#pragma unroll
+        for (int t = 0; t < 6 * G * NT; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (NEXT && s >= S0) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            if ((t & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (NEXT) {
+      store_a(P ^ 1);
+      split_b(std::integral_constant<int, P ^ 1>{});
     }
   };
   auto main_loop = [&](auto full_tag) __attribute__((always_inline)) {
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
     load_chunk(0);
     store_a(0);
-    split_b();
+    split_b(P0);
     __syncthreads();
-    for (int c = 0; c + 1 < nchunks; ++c) {
+    // iteration c: stage / fragment set c & 1 is multiplied; the raw elements of chunk c + 1 are loaded at its top and cut
+    // into stage / set (c + 1) & 1 inside it (every wave finished reading that stage before the previous barrier)
+    auto iter = [&](int c, auto par) __attribute__((always_inline)) {
       load_chunk(c + 1);
-      compute(c & 1, full_tag);
-      store_a((c + 1) & 1);          // the stage every wave finished reading before the previous barrier
-      split_b();
+      compute(par, std::true_type{}, full_tag);
       __syncthreads();
+    };
+    int c = 0;
+    for (; c + 2 < nchunks; c += 2) {
+      iter(c, P0);
+      iter(c + 1, P1);
     }
-    compute((nchunks - 1) & 1, full_tag);
+    if (c + 1 < nchunks) {
+      iter(c, P0);
+      compute(P1, std::false_type{}, full_tag);
+    } else {
+      compute(P0, std::false_type{}, full_tag);
+    }
   };
   if (nchunks > 0) {
     if (mtv >= MT) main_loop(std::true_type{});

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the two roofline kernels from PMC counters: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3
 # passes (--kernel-trace only), averaged per dispatch, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950
-# reports 1/2 of wide reads).  Writes gpurun_out/pmc_traffic.json; copy it to profiles/r03_pmc.json.
+# reports 1/2 of wide reads).  Writes gpurun_out/pmc_traffic.json; copy it to profiles/r04_pmc.json.
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -18,7 +18,7 @@ for tag in ("conv", "sk", "c16"):
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
-                if r["Counter_Name"] != c or not ("igemm_kernel" in k or "sk_pass_kernel" in k or "conv_cl16" in k or "cl16_wgrad" in k): continue
+                if r["Counter_Name"] != c or not ("igemm_kernel" in k or "igemm3_" in k or "sk_pass_kernel" in k or "conv_cl16" in k or "cl16_wgrad" in k): continue
                 acc[(k, r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
             for (k, grid), v in acc.items():
                 name = k.replace("void slv::", "").replace("(slv::IgemmArgs)", "").split("(")[0] + " grid=" + grid
@@ -36,6 +36,9 @@ for k, d in list(res.items()):          # aliases bench.py looks up
     m = re.match(r"igemm_kernel<(\d+), (\d+), (\d+), (\w+), (\d+)", k)
     if m and m.group(1) == "0" and m.group(5) == "1":
         out["hot_conv_fwd"] = dict(d, kernel=k)
+    m3 = re.match(r"igemm3_kernel<9, 2, 1, 0", k)          # the split-operand forward of the same layer (csrc/igemm3.hpp)
+    if m3:
+        out["hot_conv_fwd_x3"] = dict(d, kernel=k)
     if "sk_pass_kernel" in k and k.endswith("grid=262144"):
         out["sk_pass"] = dict(d, kernel=k)
     if k.startswith("conv_cl16_sr_kernel<1, 1>") or ((k.startswith("conv_cl16_s3_kernel<9, 1, 1>") or k.startswith("conv_cl16_kernel<9, 1, 1>")) and "hot_conv16_fwd" not in out):
