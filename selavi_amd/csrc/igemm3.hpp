@@ -296,6 +296,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
     const unsigned char* As = smem + buf * A_BYTES + foff;
     bf16x8 a[2][G][3];
     __builtin_amdgcn_sched_barrier(0);
+#ifdef SLV_X3_PRIO
+    __builtin_amdgcn_s_setprio(SLV_X3_PRIO);      // the wave in its MFMA stream wins the SIMD's arbitration: the co-resident wave
+#endif                                          // does its loads / split meanwhile instead of both hitting the matrix pipe in phase
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
 #pragma unroll
@@ -344,7 +347,13 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef SLV_X3_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     } else {
+#ifdef SLV_X3_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if constexpr (SPLIT) split_chunk(std::integral_constant<int, P ^ 1>{});
     }
   };

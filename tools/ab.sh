@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of two builds of the library in ONE gpurun call (boxes differ by +-5 %): tools/ab.sh <variant-name> [layers...]
+# A/B of builds of the library in ONE gpurun call (boxes differ by +-5 %): tools/ab.sh "<variant names>" layers...
 cd "$(dirname "$0")/.."
-v=$1; shift
+vs=$1; shift
 for rep in 1 2; do
-  for lib in base $v; do
+  for lib in base $vs; do
     if [ $lib = base ]; then unset SELAVI_HIP_LIB; else export SELAVI_HIP_LIB=$PWD/tools/proto/libselavi_$lib.so; fi
     echo "== $lib (rep $rep)"
     for L in "$@"; do python tools/conv_bench.py $L 10 2>&1 | grep "^$L"; done
