@@ -151,6 +151,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
   __syncthreads();
 
   // ---- B: this lane's column of each of the wave's NT column tiles
+  const int my_tapd = g.tapd[lane];
   unsigned lbase[NT], mlo[NT], mhi[NT];
   size_t obase[NT];                      // where this lane's column of tile j goes in the output (epilogue)
   bool cok[NT];
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
     mlo[j] = mhi[j] = 0;
     if (nvalid) {
       for (int t = 0; t < g.ntaps; ++t) {
-        const int d = g.tapd[t];
+        const int d = __builtin_amdgcn_readlane(my_tapd, t);      // (one vector load of the 64-entry table up front: a scalar
+                                                                  //  load per tap put 9 dependent round trips into the prologue)
         const bool ok = (unsigned)(c0 + (d & 255) - 64) < (unsigned)g.S0 &&
                         (unsigned)(c1 + ((d >> 8) & 255) - 64) < (unsigned)g.S1 &&
                         (unsigned)(c2 + ((d >> 16) & 255) - 64) < (unsigned)g.S2;
