@@ -173,18 +173,20 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
                (size_t)(q1 * g.dmul1 + g.dorg1) * g.D2 + (size_t)(q2 * g.dmul2 + g.dorg2);
     const int c0 = q0 * g.mul0, c1 = q1 * g.mul1, c2 = q2 * g.mul2;
     lbase[j] = (unsigned)((long long)b * g.sbatch + (long long)c0 * (g.S1 * g.S2) + c1 * g.S2 + c2) + (unsigned)cof * (g.sprod4 >> 2);
-    mlo[j] = mhi[j] = 0;
-    if (nvalid) {
-      for (int t = 0; t < g.ntaps; ++t) {
-        const int d = __builtin_amdgcn_readlane(my_tapd, t);      // (one vector load of the 64-entry table up front: a scalar
-                                                                  //  load per tap put 9 dependent round trips into the prologue)
-        const bool ok = (unsigned)(c0 + (d & 255) - 64) < (unsigned)g.S0 &&
-                        (unsigned)(c1 + ((d >> 8) & 255) - 64) < (unsigned)g.S1 &&
-                        (unsigned)(c2 + ((d >> 16) & 255) - 64) < (unsigned)g.S2;
-        if (t < 32) mlo[j] |= (ok ? 1u : 0u) << t;
-        else mhi[j] |= (ok ? 1u : 0u) << (t - 32);
-      }
+    unsigned lo = 0, hi = 0;
+    // (no branch on nvalid around this loop: v_readlane reads a lane whether or not it is active, and inside a divergent
+    //  region the table load may be sunk into it, leaving the inactive lanes' register unwritten)
+    for (int t = 0; t < g.ntaps; ++t) {
+      const int d = __builtin_amdgcn_readlane(my_tapd, t);      // (one vector load of the 64-entry table up front: a scalar
+                                                                //  load per tap put 9 dependent round trips into the prologue)
+      const bool ok = (unsigned)(c0 + (d & 255) - 64) < (unsigned)g.S0 &&
+                      (unsigned)(c1 + ((d >> 8) & 255) - 64) < (unsigned)g.S1 &&
+                      (unsigned)(c2 + ((d >> 16) & 255) - 64) < (unsigned)g.S2;
+      if (t < 32) lo |= (ok ? 1u : 0u) << t;
+      else hi |= (ok ? 1u : 0u) << (t - 32);
     }
+    mlo[j] = nvalid ? lo : 0u;
+    mhi[j] = nvalid ? hi : 0u;
   }
   // ---- chunk range (32-deep chunks; split-K slices in units of them)
   const int nch16 = g.Kd >> 4;

@@ -37,6 +37,9 @@ GEOMS = [
     (1, 5, 1, 3, 1, 7, (1, 3, 3), (1, 1, 1), (0, 1, 1)),         # degenerate W = 1
     (2, 16, 1, 4, 4, 8, (3, 1, 1), (2, 1, 1), (1, 0, 0)),        # T = 1 under temporal stride 2 (empty parity class)
     (2, 8, 3, 5, 5, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0)),        # 1x1x1 stride 2 on odd extents
+    (2, 256, 1, 2, 2, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # 8 output positions: a column tile with fewer valid
+    (1, 512, 3, 1, 2, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),     #  lanes than taps (2 clips at 32x32 reach layer 4 so)
+    (2, 64, 1, 3, 3, 96, (1, 3, 3), (1, 2, 2), (0, 1, 1)),       # same, strided (backward data by parity classes)
 ]
 
 
