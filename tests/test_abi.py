@@ -60,36 +60,46 @@ def test_conv_tables_and_launch_configurations_host_logic():
             (16, 230, 16, 28, 28, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0)),      # padded channels (230 -> 240), stride 2
             (16, 512, 2, 7, 7, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1)),        # layer4: split-K
             (16, 64, 16, 56, 56, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0))]       # downsample: 8 parity classes
-    for f in fams:
-        g = _geom(*f)
-        gp = g.ctypes.data
-        Bn, Cin, T, H, W, Cout, k, st, pd = f
-        taps = k[0] * k[1] * k[2]
-        n_f, n_d = C.slv_conv_table_len(gp, 0), C.slv_conv_table_len(gp, 1)
-        assert n_f > 0 and n_d > 0
-        tf = np.zeros(n_f, dtype=np.int32)
-        C.slv_conv_table(gp, 0, tf.ctypes.data)
-        # the channel-major table comes first (the weight-gradient kernel reads it): entry (c, j) = {offset, j | c << 8}
-        ent = tf[:2 * Cin * taps].reshape(Cin * taps, 2)
-        assert (ent[:, 1] & 63 == np.tile(np.arange(taps), Cin)).all()
-        assert (ent[:, 1] >> 8 == np.repeat(np.arange(Cin), taps)).all()
-        assert tf[2 * Cin * taps + 1] == 63                     # padding entries carry the never-valid tap 63
-        wf = C.slv_conv_wf_elems(gp)
-        cp = (Cin + 15) // 16 * 16
-        tap_major = Cin >= 16 and cp * 10 <= Cin * 11
-        assert wf == (Cout * taps * cp if tap_major else 0)
-        assert C.slv_conv_wt_elems(gp) >= Cout * Cin * taps
-        for op in range(3):
-            buf = np.zeros(128, dtype=np.int32)
-            n = C.slv_conv_configs(gp, op, buf.ctypes.data, 128)
-            assert 0 < n <= 128 and len(set(buf[:n].tolist())) == n
-            for cfg in buf[:n].tolist():
-                mt, nt, mf, sp = cfg & 255, (cfg >> 8) & 15, (cfg >> 12) & 15, cfg >> 16
-                assert sp >= 1 and mf in (0, 1) and mt in (4, 6, 8, 9, 15) and nt in (1, 2)
-                if op == 0:
-                    assert C.slv_conv_fwd_nblk(gp, cfg) == -(-(Bn * g[6] * g[7] * g[8]) // (nt * 64))
-                    assert (C.slv_conv_fwd_ws_bytes(gp, cfg) > 0) == (sp > 1)
-        assert C.slv_conv_fwd_nblk(gp, 3 | (2 << 8) | (1 << 16)) == -1          # 48-row tile does not exist
+    before = C.slv_conv_get_arithmetic()
+    assert before in (0, 1)
+    for x3 in (1, 0):                                           # split-operand (csrc/igemm3.hpp) and native fp32 MFMA
+        C.slv_conv_set_arithmetic(x3)                            # (the checked caller raises on a non-zero status)
+        assert C.slv_conv_get_arithmetic() == x3
+        for f in fams:
+            g = _geom(*f)
+            gp = g.ctypes.data
+            Bn, Cin, T, H, W, Cout, k, st, pd = f
+            taps = k[0] * k[1] * k[2]
+            n_f, n_d = C.slv_conv_table_len(gp, 0), C.slv_conv_table_len(gp, 1)
+            assert n_f > 0 and n_d > 0
+            tf = np.zeros(n_f, dtype=np.int32)
+            C.slv_conv_table(gp, 0, tf.ctypes.data)
+            # the channel-major table comes first (the weight-gradient kernel reads it): entry (c, j) = {offset, j | c << 8}
+            ent = tf[:2 * Cin * taps].reshape(Cin * taps, 2)
+            assert (ent[:, 1] & 63 == np.tile(np.arange(taps), Cin)).all()
+            assert (ent[:, 1] >> 8 == np.repeat(np.arange(Cin), taps)).all()
+            assert tf[2 * Cin * taps + 1] == 63                     # padding entries carry the never-valid tap 63
+            wf = C.slv_conv_wf_elems(gp)
+            cp = (Cin + 15) // 16 * 16
+            tap_major = Cin >= 16 and cp * 10 <= Cin * 11
+            if x3:                                                  # three bf16 planes, 32-deep chunks, 16-row tiles
+                image = -(-(taps * cp) // 32) * 3 * (-(-Cout // 16) * 16) * 16
+                assert wf == (image if tap_major else 0)
+            else:
+                assert wf == (Cout * taps * cp if tap_major else 0)
+            assert C.slv_conv_wt_elems(gp) >= Cout * Cin * taps
+            for op in range(3):
+                buf = np.zeros(128, dtype=np.int32)
+                n = C.slv_conv_configs(gp, op, buf.ctypes.data, 128)
+                assert 0 < n <= 128 and len(set(buf[:n].tolist())) == n
+                for cfg in buf[:n].tolist():
+                    mt, nt, mf, sp = cfg & 255, (cfg >> 8) & 15, (cfg >> 12) & 15, cfg >> 16
+                    assert sp >= 1 and mf in (0, 1) and mt in (4, 6, 8, 9, 15) and nt in ((1, 2, 3, 4) if x3 else (1, 2))
+                    if op == 0:
+                        assert C.slv_conv_fwd_nblk(gp, cfg) == -(-(Bn * g[6] * g[7] * g[8]) // (nt * 64))
+                        assert (C.slv_conv_fwd_ws_bytes(gp, cfg) > 0) == (sp > 1)
+            assert C.slv_conv_fwd_nblk(gp, 3 | (2 << 8) | (1 << 16)) == -1      # 48-row tile does not exist
+    C.slv_conv_set_arithmetic(before)
 
 
 def test_invalid_arguments_are_reported_not_crashed():
