@@ -40,6 +40,8 @@ GEOMS = [
     (2, 256, 1, 2, 2, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # 8 output positions: a column tile with fewer valid
     (1, 512, 3, 1, 2, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),     #  lanes than taps (2 clips at 32x32 reach layer 4 so)
     (2, 64, 1, 3, 3, 96, (1, 3, 3), (1, 2, 2), (0, 1, 1)),       # same, strided (backward data by parity classes)
+    (2, 16, 4, 6, 6, 40, (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # 27 taps (not in the trunks: the widest class the weight images take)
+    (1, 32, 5, 7, 7, 24, (3, 3, 3), (2, 2, 2), (1, 1, 1)),       # 27 taps, stride 2 everywhere: 8 parity classes of 1-8 taps
 ]
 
 
