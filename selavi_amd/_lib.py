@@ -125,6 +125,20 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = None
+
+
 def stream():
-    import torch
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on the current device, as an int.  Through the raw getters: the public
+    torch.cuda.current_stream() costs ~8 us a call (device-index resolution, a Stream object), ~350 calls per step --
+    a quarter of the host time of the launch-bound 16-clip step (tools/host_profile.py)."""
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
+        get_dev = getattr(torch._C, "_cuda_getDevice", None)
+        get_raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if get_dev is not None and get_raw is not None:
+            _raw_stream = lambda: get_raw(get_dev())
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+    return _raw_stream()

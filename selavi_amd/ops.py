@@ -230,7 +230,7 @@ _ws_cache = {}
 def workspace(nbytes, device):
     """Grow-only split-K scratch buffer, one per (device, stream): calls on one stream are ordered, the two
     trunks run on different streams and must not share it."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, stream())       # (tensors' devices carry their index; the raw getter: 8 us per public current_stream call)
     t = _ws_cache.get(key)
     if t is None or t.numel() * 4 < nbytes:
         t = _ws_cache[key] = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
