@@ -241,9 +241,21 @@ static int conv_max_splits() {
   }
   return v;
 }
-static void plan_conv(int M, long long ncols, int Kd, int* mt_out, int* nt_out, int* splits_out) {
+// Tile of a split-operand conv launch (igemm3.hpp) when the host did not time the candidates.  What benchmark mode picks
+// on the trunks' shapes (profiles/r04_notes.md, table of tuned configurations): 144 x 128 where 144-row blocks pad no more
+// than 128-row ones (M = 144, 288, 576, 921), else 128 x 64 -- the lean 128-row pipeline at three workgroups per CU; its
+// 128-column form spills under that register cap and the 240-row tile is the slowest per FLOP -- and 64 x 128 up to 64 rows.
+static void pick_tile_x3(int M, int Kd, int* mt_out, int* nt_out) {
+  if (M <= 64) { *mt_out = 4; *nt_out = 2; return; }
+  const int pad9 = (M + 143) / 144 * 144, pad8 = (M + 127) / 128 * 128;
+  if (pad9 < pad8 || (pad9 == pad8 && M <= 144)) { *mt_out = 9; *nt_out = 2; }
+  else if (Kd >= 4096) { *mt_out = 8; *nt_out = 4; }      // layer 4.1 spatial: K = 4608, 1568 columns -- the 8-wave 128 x 256 tile
+  else { *mt_out = 8; *nt_out = 1; }
+}
+static void plan_conv(int M, long long ncols, int Kd, int* mt_out, int* nt_out, int* splits_out, bool x3 = false) {
   *splits_out = 1;
-  const int mt = pick_mt(M), nt = mt >= 15 ? 1 : 2;
+  int mt = pick_mt(M), nt = mt >= 15 ? 1 : 2;
+  if (x3) pick_tile_x3(M, Kd, &mt, &nt);
   const long long blocks = (long long)((M + mt * 16 - 1) / (mt * 16)) * ((ncols + nt * 64 - 1) / (nt * 64));
   if (blocks > 0 && blocks < 768) {
     const int chunks = (Kd + 15) / 16;
@@ -261,6 +273,7 @@ static void plan_conv(int M, long long ncols, int Kd, int* mt_out, int* nt_out, 
       return;
     }
   }
+  if (x3) { *mt_out = mt; *nt_out = nt; return; }
   pick_tile(M, ncols, mt_out, nt_out);
 }
 
@@ -371,7 +384,9 @@ static int wgrad_splits(const Geom& g, int mt, int nt) {
   const long long chunks = (Ptot + 15) / 16;
   const int taps = g.kt * g.kh * g.kw;
   const long long tiles = (long long)((g.Cout + mt * 16 - 1) / (mt * 16)) * ((g.Cin * taps + nt * 64 - 1) / (nt * 64));
-  long long s = 768 / tiles;                     // one full round of 3 workgroups per CU (measured best: 765 of 768)
+  // one full round of 3 workgroups per CU (measured best: 765 of 768); the 144-row split-operand tile runs 2 per CU: three rounds
+  // of 512 (what benchmark mode picks: 512 slices for the 3 tiles of layer 1, 84 for the 18 of layer 2.1, 42 for the 36 of 3.0)
+  long long s = (x3_enabled() && mt == 9 ? 1536 : 768) / tiles;
   const long long maxs = (chunks + 15) / 16;     // at least 16 chunks (256 positions) per slice
   if (s > maxs) s = maxs;
   if (s > 512) s = 512;
@@ -410,7 +425,7 @@ static int fwd_cfg(const Geom& g, int32_t cfg, Cfg& c) {
   const long long P = (long long)g.Bn * g.To * g.Ho * g.Wo;
   const int Kd = g.Cin * g.kt * g.kh * g.kw;
   c.mf = 0;
-  if (cfg == 0) { plan_conv(g.Cout, P, Kd, &c.mt, &c.nt, &c.sp); return 0; }
+  if (cfg == 0) { plan_conv(g.Cout, P, Kd, &c.mt, &c.nt, &c.sp, x3_enabled() && want_tap_major(g.Cin)); return 0; }
   if (unpack_cfg(cfg, c) != 0 || c.sp > 64) return -1;
   c.sp = clamp_splits(c.sp, (Kd + 15) / 16);
   return 0;
@@ -421,7 +436,7 @@ static int dgrad_cfg(const Geom& g, const Desc* ds, int n, int32_t cfg, Cfg* per
   if (cfg == 0) {
     for (int i = 0; i < n; ++i) {
       per_class[i].mf = 0;
-      plan_conv(ds[i].M, ds[i].Ntot, ds[i].Kd, &per_class[i].mt, &per_class[i].nt, &per_class[i].sp);
+      plan_conv(ds[i].M, ds[i].Ntot, ds[i].Kd, &per_class[i].mt, &per_class[i].nt, &per_class[i].sp, ds[i].x3 != 0);
       if (per_class[i].sp > sp) sp = per_class[i].sp;
     }
   } else {
@@ -443,6 +458,7 @@ static int wgrad_cfg(const Geom& g, int32_t cfg, Cfg& c) {
   if (cfg == 0) {
     c.mt = pick_mt(g.Cout);
     c.nt = c.mt >= 15 ? 1 : 2;
+    if (x3_enabled()) pick_tile_x3(g.Cout, 0, &c.mt, &c.nt), c.nt = 2;      // (no 240-row tile: the slowest per FLOP)
     if (c.nt == 2 && x3_enabled()) {        // split-operand kernel: 192-column tiles where they pad less (Cin * taps = 576)
       const long long N = (long long)g.Cin * g.kt * g.kh * g.kw;
       if ((N + 191) / 192 * 192 < (N + 127) / 128 * 128) c.nt = 3;
