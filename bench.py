@@ -44,7 +44,7 @@ FWD_MB_PER_CLIP = 518.1 + 3.38          # sum over convs of (in + out
 def _pmc_traffic(key):
     """Measured HBM bytes/launch recorded by the PMC passes of this round (tools/pmc_traffic.sh ->
     profiles/r01_pmc.json; None if not recorded)."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             v = d.get(key)
@@ -55,24 +55,36 @@ def _pmc_traffic(key):
     return None
 
 
-def _rocprof_in_step(kernel, grid, files=("r03_bench_kernel_summary.txt", "r02_bench_kernel_summary.txt",
-                                           "r01_bench_kernel_summary_final.txt")):
-    """Average duration (ms) of `kernel [grid]` INSIDE the training step, from the committed rocprofv3 --kernel-trace
-    summary of this very command (profiles/r03_bench_kernel_summary.txt, tools/prof_r3.sh; earlier rounds' as a
-    fallback): the isolated launch timed live by hot_conv_roofline runs alone on the chip, in the step it shares the CUs
-    with the weight-gradient side stream and the audio trunk.  A FROZEN figure (the committed trace was taken on another
-    box of the pool, +-3 % run to run; rocprofv3 cannot wrap the bench from inside): the live figures of the line are
-    ms_per_launch and ms_per_step.  None if no summary is committed."""
+def _library_digest():
+    try:
+        return open(os.path.join(ROOT, "selavi_amd", "libselavi_hip.so.stamp")).read().strip()
+    except OSError:
+        return None
+
+
+def _rocprof_in_step(kernel, grid, files):
+    """Average duration (ms) of `kernel [grid]` INSIDE the training step, from a committed rocprofv3 --kernel-trace
+    summary of this very command (tools/prof_r5.sh -> tools/rocprof_summary.py).  A FROZEN figure (the trace was taken on
+    another box of the pool, +-3 % run to run; rocprofv3 cannot wrap the bench from inside), reported only when the summary
+    carries the digest of the library this run loaded ("library digest ..." line, = selavi_amd/build.py:_digest()): a summary
+    of other kernels would go stale silently.  The LIVE in-step figure of the line is roofline.in_step_live (HIP events
+    around the launch inside the step); None if no matching summary is committed."""
     import re
+    dig = _library_digest()
     for name in files:
         try:
-            for line in open(os.path.join(ROOT, "profiles", name)):
-                m = re.match(r"\s*[\d.]+\s+[\d.]+\s+(\d+)\s+([\d.]+)\s+\d+\s+\d+\s+\d+\s+(.*?)\s*\[(\d+)\]\s*$", line)
-                if m and m.group(3).startswith(kernel) and int(m.group(4)) == grid:
-                    return dict(ms=float(m.group(2)) / 1e3, launches=int(m.group(1)), source="profiles/" + name,
-                                frozen="committed rocprofv3 trace of this command, not measured by this run")
+            lines = open(os.path.join(ROOT, "profiles", name)).read().splitlines()
         except OSError:
             continue
+        m0 = re.match(r"library digest (\S+)", lines[0]) if lines else None
+        if not (m0 and dig and m0.group(1) == dig):
+            continue
+        for line in lines:
+            m = re.match(r"\s*[\d.]+\s+[\d.]+\s+(\d+)\s+([\d.]+)\s+\d+\s+\d+\s+\d+\s+(.*?)\s*\[(\d+)\]\s*$", line)
+            if m and m.group(3).startswith(kernel) and int(m.group(4)) == grid:
+                return dict(ms=float(m.group(2)) / 1e3, launches=int(m.group(1)), source="profiles/" + name,
+                            library_digest=dig[:16],
+                            frozen="committed rocprofv3 trace of this command on the same library build, not measured by this run")
     return None
 
 
@@ -366,8 +378,7 @@ def bf16_leg(a, rank, world, local, dev):
                      "in_step": (lambda r: None if r is None else dict(
                          r, achieved=B // 2 * T * 56 * 56 * (64 + 144) * 2.0 / r["ms"] / 1e6,      # (a launch = one batch slice of 64 clips)
                          frac=B // 2 * T * 56 * 56 * (64 + 144) * 2.0 / r["ms"] / 1e6 / PEAK_HBM_GBS))(
-                         _rocprof_in_step(HOT16_KERNEL, 256,
-                                          ("r03_step16_cfg5_kernel_summary.txt", "r02_step16_cfg5_kernel_summary.txt"))
+                         _rocprof_in_step(HOT16_KERNEL, 256, ("r05_step16_cfg5_kernel_summary.txt",))
                          if B == CFG5["batch"] else None),
                      "note": "bf16: this conv's arithmetic intensity (128 FLOP/B) is below the ridge (312): HBM-bound"},
         "step_roofline": {"mfma": {"achieved": step_tf, "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s per GPU",
@@ -568,6 +579,23 @@ def main():
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - tf0) / 5 * 1e3
     hot = hot_conv_roofline(B, dev)
+    # the same launch INSIDE the step, live: HIP events around every forward launch of that layer shape with the BatchNorm +
+    # ReLU prologue, on the stream it runs on, over extra (untimed) steps -- in the step it shares the chip with the audio
+    # trunk's stream, isolated it runs alone
+    in_step_live = None
+    try:
+        hot_plan = ops.ConvPlan.get((B, 64, 16, 56, 56), 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), dev)
+        with ops.probe_conv_fwd(hot_plan, prologue=True) as pr:
+            for _ in range(3):
+                step()
+        tms = pr.ms()
+        if tms:
+            in_step_live = dict(ms=sum(tms) / len(tms), launches=len(tms), min_ms=min(tms), max_ms=max(tms),
+                                how="HIP events around the launch on its stream, 3 extra steps after the timed region")
+    except Exception as e:          # measurement garnish: never take the line down
+        if world > 1:
+            raise                   # (but ranks must not diverge inside the step's collectives)
+        in_step_live = dict(error=repr(e))
     sk = None if a.no_sk else sk_bench(rank, world, dev)
     sk_round = sk_round_estimate(m, dev, world, clips, sk) if sk else None
     # the same step on the NATIVE fp32-input MFMA kernels (csrc/igemm.hpp, v_mfma_f32_16x16x4_f32): what the headline was in
@@ -646,6 +674,10 @@ def main():
                                            "3 x 2^-24 |a b|, one fp32 rounding; per-op error against fp64 equal to the native fp32 "
                                            "MFMA kernels': tests/test_ops_gpu.py) -- csrc/igemm3.hpp; native_fp32_mfma = the same "
                                            "step on v_mfma_f32_16x16x4_f32") if hot["x3"] else "native fp32-input MFMA",
+                       "launch_configs": ("benchmark mode: every (tile, K-split) candidate timed once per layer shape in the "
+                                          "untimed plan-building step -- main.py:187 cudnn.benchmark = True; tests, smoke() and "
+                                          "library users without ops.set_benchmark(True) run the built-in heuristics (~3-5 % slower)"),
+                       "library_digest": (_library_digest() or "")[:16],
                        "sync_bn": world > 1, "loss_last_step": loss_v,
                        "peak_hbm_gb": round(peak_hbm / 2 ** 30, 2)},
             "roofline": {"bound": "mfma", "achieved": hot["tflops"],
@@ -661,21 +693,26 @@ def main():
                          # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r04_pmc.json
                          "traffic": _pmc_traffic("hot_conv_fwd_x3" if hot["x3"] else "hot_conv_fwd") if B == CFG2["batch"] else None,
                          "kernel": hot["kernel"], "ms_per_launch": hot["ms"], "flop_per_launch": hot["flop"],
-                         # the same launch inside the step (rocprofv3 average of the committed trace of this command)
+                         "in_step_live": (lambda r: r if (r is None or "error" in r) else dict(
+                             r, achieved=hot["flop"] / r["ms"] / 1e9,
+                             frac=hot["flop"] / r["ms"] / 1e9 / (PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF)))(in_step_live),
+                         # the same launch inside the step (rocprofv3 average of the committed trace of this command; null
+                         # unless that trace was taken on the library build this run loaded)
                          "in_step": (lambda r: None if r is None else dict(
                              r, achieved=hot["flop"] / r["ms"] / 1e9,
                              frac=hot["flop"] / r["ms"] / 1e9 / (PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF)))(
                              _rocprof_in_step(HOT_X3_KERNEL if hot["x3"] else "igemm_kernel<0, 9, 2, true, 1, 1, 0, 0, 0>", 6272,
-                                              ("r04_bench_kernel_summary.txt",) if hot["x3"] else
-                                              ("r03_bench_kernel_summary.txt", "r02_bench_kernel_summary.txt"))
+                                              ("r05_bench_kernel_summary.txt",))
                              if B == CFG2["batch"] else None)},
             "step_roofline": {"bound": "mfma", "achieved": step_tflops, "peak": PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF,
                               "unit": "TFLOP/s per GPU (algorithmic 3 x %.2f GFLOP/clip)" % FWD_GFLOP_PER_CLIP,
                               "frac": step_tflops / (PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF),
                               "frac_of_native_fp32_mfma_peak": step_tflops / PEAK_FP32_MFMA_TF},
             "forward": {"ms": fwd_ms, "clips_per_s_per_gpu": B / fwd_ms * 1e3,
-                        "mfma": {"achieved": FWD_GFLOP_PER_CLIP * B / fwd_ms, "peak": PEAK_FP32_MFMA_TF,
-                                 "unit": "TFLOP/s", "frac": FWD_GFLOP_PER_CLIP * B / fwd_ms / PEAK_FP32_MFMA_TF},
+                        # (priced against the peak the headline runs on: dense bf16 MFMA / 6 for the split-operand convs)
+                        "mfma": {"achieved": FWD_GFLOP_PER_CLIP * B / fwd_ms, "peak": PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF,
+                                 "unit": "TFLOP/s", "frac": FWD_GFLOP_PER_CLIP * B / fwd_ms / (PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF),
+                                 "frac_of_native_fp32_mfma_peak": FWD_GFLOP_PER_CLIP * B / fwd_ms / PEAK_FP32_MFMA_TF},
                         "hbm": {"achieved": FWD_MB_PER_CLIP * B / fwd_ms, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": FWD_MB_PER_CLIP * B / fwd_ms / PEAK_HBM_GBS,
                                 "note": "algorithmic fused-forward bytes (SURVEY 8d: 518.1 + 3.4 MB/clip); the fp32 "

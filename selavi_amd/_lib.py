@@ -128,8 +128,8 @@ def ptr(t):
 _raw_stream = None
 
 
-def stream():
-    """hipStream_t of torch's current stream on the current device, as an int.  Through the raw getters: the public
+def stream(index=None):
+    """hipStream_t of torch's current stream on the current device (or on device ``index``), as an int.  Through the raw getters: the public
     torch.cuda.current_stream() costs ~8 us a call (device-index resolution, a Stream object), ~350 calls per step --
     a quarter of the host time of the launch-bound 16-clip step (tools/host_profile.py)."""
     global _raw_stream
@@ -138,7 +138,7 @@ def stream():
         get_dev = getattr(torch._C, "_cuda_getDevice", None)
         get_raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
         if get_dev is not None and get_raw is not None:
-            _raw_stream = lambda: get_raw(get_dev())
+            _raw_stream = lambda i=None: get_raw(get_dev() if i is None else i)
         else:
-            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
-    return _raw_stream()
+            _raw_stream = lambda i=None: torch.cuda.current_stream(i).cuda_stream
+    return _raw_stream(index)

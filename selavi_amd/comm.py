@@ -30,7 +30,16 @@ class NativeComm:
     _disabled = None        # reason string once the preflight has switched the native path off for this process
 
     def __init__(self, handle, rank, world, group):
-        self.h, self.rank, self.world, self.group = handle, rank, world, group
+        self._h, self.rank, self.world, self.group = handle, rank, world, group
+
+    @property
+    def h(self):
+        """The library's communicator handle; raises once a failed preflight has aborted (= freed) it, so that a holder of
+        this object from before the failure (a sync_pair, an SK solver) cannot hand a dangling pointer to the C ABI."""
+        if self._h is None:
+            raise RuntimeError("selavi_amd.comm: this communicator was aborted by a failed preflight "
+                               f"({NativeComm._disabled}); re-create the exchange (comm.sync_pair) on torch.distributed")
+        return self._h
 
     @staticmethod
     def mode():
@@ -93,8 +102,9 @@ class NativeComm:
         import sys
         import time
         import torch.distributed as dist
-        comms = {k: v for k, v in cls._cache.items() if v.world > 1}
-        if not comms:
+        gid_ = 0 if (group is None or group is dist.group.WORLD) else id(group)
+        comms = {k: v for k, v in cls._cache.items() if v.world > 1 and k[0] == gid_}     # THIS group's communicators only:
+        if not comms:                                                                   # the verdict below is agreed over it
             return True
         if timeout_s is None:
             timeout_s = float(os.environ.get("SELAVI_COMM_TIMEOUT_S", "120"))
@@ -144,12 +154,13 @@ class NativeComm:
                          "(SELAVI_NATIVE_COMM=0 behaviour).\n" % (dist.get_rank(), why or "another rank reported the failure")
                          + "!" * 100 + "\n")
         sys.stderr.flush()
-        for comm in cls._cache.values():
+        for key, comm in comms.items():
             try:
                 C.slv_comm_abort(comm.h)
             except Exception:
                 pass
-        cls._cache.clear()
+            comm._h = None             # slv_comm_abort frees the handle: a holder of this object (a sync_pair made before
+            cls._cache.pop(key, None)  # the failure) raises in allreduce_ instead of touching freed memory
         cls._disabled = why or "preflight failed on another rank"
         return False
 

@@ -427,6 +427,9 @@ static int fwd_cfg(const Geom& g, int32_t cfg, Cfg& c) {
   c.mf = 0;
   if (cfg == 0) { plan_conv(g.Cout, P, Kd, &c.mt, &c.nt, &c.sp, x3_enabled() && want_tap_major(g.Cin)); return 0; }
   if (unpack_cfg(cfg, c) != 0 || c.sp > 64) return -1;
+  // a split-operand layer's weight buffers hold the three-plane bf16 image (slv_conv_w_transform): the native 32x32x2 tiles
+  // (mf = 1) would read it as an fp32 matrix -- such a configuration (a tune cache written for the native kernels) is invalid
+  if (c.mf && x3_enabled() && want_tap_major(g.Cin)) return -1;
   c.sp = clamp_splits(c.sp, (Kd + 15) / 16);
   return 0;
 }
@@ -444,6 +447,7 @@ static int dgrad_cfg(const Geom& g, const Desc* ds, int n, int32_t cfg, Cfg* per
     if (unpack_cfg(cfg, c) != 0 || c.sp > 64) return -1;
     int maxchunks = 1;
     for (int i = 0; i < n; ++i) {
+      if (c.mf && ds[i].x3) return -1;      // (see fwd_cfg: the class reads an x3 weight image)
       per_class[i] = c;
       if ((ds[i].Kd + 15) / 16 > maxchunks) maxchunks = (ds[i].Kd + 15) / 16;
     }

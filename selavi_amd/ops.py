@@ -71,7 +71,9 @@ class ConvPlan:
         self.wt_elems = C.slv_conv_wt_elems(self.gp)
         self.set_configs(0, 0, 0)
         if benchmark:
-            key = ",".join(str(int(v)) for v in self.geom) + ("" if C.slv_conv_get_arithmetic() else ",native")
+            # (bare keys = the native kernels, as every cache written before the split-operand kernels existed: their
+            #  configurations -- mf = 1 tiles among them -- must never reach the x3 kernels)
+            key = ",".join(str(int(v)) for v in self.geom) + (",x3" if C.slv_conv_get_arithmetic() else "")
             hit = _tune_cache().get(key)
             if hit is not None:
                 self.set_configs(*hit)
@@ -230,7 +232,10 @@ _ws_cache = {}
 def workspace(nbytes, device):
     """Grow-only split-K scratch buffer, one per (device, stream): calls on one stream are ordered, the two
     trunks run on different streams and must not share it."""
-    key = (device.index, stream())       # (tensors' devices carry their index; the raw getter: 8 us per public current_stream call)
+    # the current stream OF THAT DEVICE (device.index is None for a bare "cuda": the current device then); the raw getter: 8 us per
+    # public current_stream call
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, stream(idx))
     t = _ws_cache.get(key)
     if t is None or t.numel() * 4 < nbytes:
         t = _ws_cache[key] = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
@@ -256,9 +261,41 @@ def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True, wf=None, ou
         ssum = _f32(plan.Cout, plan.nblk, device=x.device)
         ssq = _f32(plan.Cout, plan.nblk, device=x.device)
     ws = workspace(plan.ws_fwd, x.device) if plan.ws_fwd else None
+    probe = _probe is not None and _probe["plan"] is plan and (in_ss is not None) == _probe["prologue"]
+    if probe:          # bench.py: HIP events around THIS launch, on the stream it runs on, inside the training step
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     C.slv_conv_fwd(plan.gp, ptr(x), ptr(w), ptr(wf), ptr(plan.tab_fwd), ptr(in_ss), int(in_relu), ptr(y), ptr(ssum),
                    ptr(ssq), ptr(ws), plan.ws_fwd, plan.cfg_fwd, stream())
+    if probe:
+        e1.record()
+        _probe["events"].append((e0, e1))
     return y, ssum, ssq
+
+
+_probe = None
+
+
+class probe_conv_fwd:
+    """``with ops.probe_conv_fwd(plan, prologue=True) as p: step()`` -- every forward launch of ``plan`` (with / without the
+    BatchNorm + ReLU prologue) inside the block is bracketed by HIP events on its own stream; ``p.ms()`` lists the durations
+    after a synchronize.  Measurement only (bench.py's live ``roofline.in_step``): two event records per probed launch."""
+
+    def __init__(self, plan, prologue=True):
+        self.state = dict(plan=plan, prologue=prologue, events=[])
+
+    def __enter__(self):
+        global _probe
+        _probe = self.state
+        return self
+
+    def __exit__(self, *exc):
+        global _probe
+        _probe = None
+
+    def ms(self):
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self.state["events"]]
 
 
 def conv_w_transform(plan, w, need_wf=True, need_wt=True):

@@ -149,17 +149,47 @@ class DataParallel(torch.nn.Module):
             assert self.sink.native is None
         module.set_grad_sink(self.sink)
         self.group = group
-        self._checked_batch = None
+        self._last_batch = None
+        self._batch_checks = []        # [(event | None, tensor [max b, max -b], b of this rank)] not yet read
+
+    def _read_batch_checks(self, block):
+        while self._batch_checks:
+            ev, t, b = self._batch_checks[0]
+            if ev is not None:
+                if block:
+                    ev.synchronize()
+                elif not ev.query():
+                    return
+            self._batch_checks.pop(0)
+            hi, lo = int(t[0]), -int(t[1])
+            if hi != lo:
+                raise RuntimeError(f"selavi_amd.DataParallel: per-rank batch sizes differ (this rank {b}, max {hi}, "
+                                   f"min {lo}); SyncBN / the averaged buckets assume equal batches")
+
+    def check_equal_batches(self, b, device):
+        """slv_bn_sync_finalize and the mean all-reduce of the buckets assume EQUAL per-rank batches (the reference's loader
+        drops the ragged last batch, main.py:95-103).  The check is a collective, so EVERY rank issues it on EVERY call (a
+        rank-local condition would leave the one rank with the ragged batch alone in the all-reduce: a hang on the native
+        communicators, a mismatched pairing on torch.distributed).  It never stalls the host in the steady state: on RCCL
+        the result lands in pinned memory behind an event and is read at a later call; only a rank whose OWN batch size
+        just changed (the first call, a ragged batch) waits for it before launching the step."""
+        if dist.get_backend(self.group) == "nccl":
+            t = torch.full((2,), b, dtype=torch.int64, device=device)
+            t[1] = -b                                                  # (fill kernels: no host-to-device copy, no sync)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)      # stream-ordered, asynchronous to the host
+            host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+            host.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._batch_checks.append((ev, host, b))
+        else:
+            t = torch.tensor([b, -b], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            self._batch_checks.append((None, t, b))
+        self._read_batch_checks(block=(b != self._last_batch))
+        self._last_batch = b
 
     def forward(self, *args, **kwargs):
-        # slv_bn_sync_finalize and the mean all-reduce of the buckets assume EQUAL per-rank batches (the reference's loader
-        # drops the ragged last batch, main.py:95-103): checked once per batch size, not per step
-        b = args[0].shape[0] if args and hasattr(args[0], "shape") else None
-        if b is not None and b != self._checked_batch:
-            t = torch.tensor([b, -b], dtype=torch.int64, device=args[0].device if dist.get_backend(self.group) == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            if int(t[0]) != -int(t[1]):
-                raise RuntimeError(f"selavi_amd.DataParallel: per-rank batch sizes differ (this rank {b}, max {int(t[0])}, "
-                                   f"min {-int(t[1])}); SyncBN / the averaged buckets assume equal batches")
-            self._checked_batch = b
+        if args and hasattr(args[0], "shape"):
+            self.check_equal_batches(int(args[0].shape[0]), args[0].device)
         return self.module(*args, **kwargs)

@@ -99,6 +99,13 @@ def test_conv_tables_and_launch_configurations_host_logic():
                         assert C.slv_conv_fwd_nblk(gp, cfg) == -(-(Bn * g[6] * g[7] * g[8]) // (nt * 64))
                         assert (C.slv_conv_fwd_ws_bytes(gp, cfg) > 0) == (sp > 1)
             assert C.slv_conv_fwd_nblk(gp, 3 | (2 << 8) | (1 << 16)) == -1      # 48-row tile does not exist
+            # a 32x32x2 tile (mf = 1: native kernels only) on a layer whose weight buffers hold the split-operand image
+            # (a configuration from a tune cache written for the native kernels): rejected, forward and backward data
+            mf_cfg = 8 | (2 << 8) | (1 << 12) | (1 << 16)
+            bad = bool(x3 and tap_major)
+            assert (C.slv_conv_fwd_nblk(gp, mf_cfg) == -1) == bad
+            dg_tap_major = Cout >= 16 and (Cout + 15) // 16 * 16 * 10 <= Cout * 11
+            assert (C.slv_conv_dgrad_bnr_slots(gp, mf_cfg) == -1) == bool(x3 and dg_tap_major)
     C.slv_conv_set_arithmetic(before)
 
 

@@ -47,3 +47,29 @@ def test_driver_scale_command_two_ranks_on_one_gpu(transport):
     assert "error" not in c5 and c5["n_gpus"] == 2 and c5["config"]["parallelism"] == "dp2" and c5["value"] > 0
     assert out["cpu_baseline"] is None                                                         # rank 0 at N = 1 only
     assert "FAILED their preflight" not in p.stderr
+
+
+def test_driver_scale_command_eight_ranks_on_one_gpu():
+    """The driver's `--gpus 8` command with all eight ranks on the one test GPU over the librccl double (per-GPU batch 2 so
+    that eight copies of the step fit the box's patience): the host logic a real 8-GPU run executes -- 8-way SyncBN and
+    buckets, the preflight over 8 ranks, Sinkhorn-Knopp rows in 8 shards of 21 344, the cfg5 leg under dp8, ONE JSON line."""
+    from tests.rccl_double.build import build_double
+    env = dict(os.environ, SELAVI_BENCH_SHARE_GPU="1", SELAVI_BENCH_DIST_BACKEND="gloo", SLV_DBL_TIMEOUT_S="300",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", SELAVI_NATIVE_COMM="force", SELAVI_RCCL_LIB=build_double(), SELAVI_BENCHMARK="0")
+    port = 23100 + os.getpid() % 500
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--no-native-leg", "--cfg5-batch", "2", "--cfg5-steps", "1", "--cfg5-warmup", "1"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1100)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-6000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line from rank 0, got {len(lines)}"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp8" and out["config"]["sync_bn"] is True
+    assert out["value"] > 0 and abs(out["value"] - 16 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
+    assert out["sk"]["rows_per_gpu"] == 21344 and out["sk"]["iters_per_s"] > 0
+    c5 = out["cfg5_bf16"]
+    assert "error" not in c5 and c5["n_gpus"] == 8 and c5["config"]["parallelism"] == "dp8" and c5["value"] > 0
+    assert out["cpu_baseline"] is None
+    assert "FAILED their preflight" not in p.stderr

@@ -109,10 +109,12 @@ def _ddp_worker(rank, world, port, ret, wrap=False, precision="fp32"):
         else:
             net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)
         opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
-        video = portable_fill_(torch.empty(4, 3, 4, 32, 32), 5)[rank * 2:(rank + 1) * 2].cuda()
-        audio = portable_fill_(torch.empty(4, 1, 40, 36), 6)[rank * 2:(rank + 1) * 2].cuda()
+        # two clips per rank (world 2: the four clips / indices the single-process comparison below uses)
+        video = portable_fill_(torch.empty(2 * world, 3, 4, 32, 32), 5)[rank * 2:(rank + 1) * 2].cuda()
+        audio = portable_fill_(torch.empty(2 * world, 1, 40, 36), 6)[rank * 2:(rank + 1) * 2].cuda()
         sl = torch.from_numpy((np.arange(64 * hc).reshape(64, hc) * 7919 % K).astype(np.int64)).cuda()
-        sel = torch.tensor([3, 17, 42, 63])[rank * 2:(rank + 1) * 2].cuda()
+        sel_all = torch.tensor([3, 17, 42, 63]) if world == 2 else (torch.arange(2 * world) * 11 + 3) % 64
+        sel = sel_all[rank * 2:(rank + 1) * 2].cuda()
         loss = train.train_step(net, opt, video, audio, sl, sel, hc)
         if wrap:      # several steps (DDP rebuilds its buckets after the first), then hash the whole state
             first = float(loss)
@@ -205,6 +207,55 @@ def test_two_rank_native_data_parallel_is_bit_identical_to_ddp():
     # downsample BatchNorm share one exchange in both directions.  R(2+1)D-18 + ResNet-9 + the grouped heads: 88
     # (100 before the pairs were packed; 49 of them on the audio trunk's own stream and communicator)
     assert ret[0][4] == ret[1][4] and ret[0][4] <= 88, ret[0][4]
+
+
+def _ragged_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=300))
+    try:
+        from selavi_amd import model as smodel, train
+        torch.cuda.set_device(0)
+        m = smodel.load_model(use_mlp=True, num_classes=7, norm_feat=False, headcount=2)
+        portable_init_(m, seed=31)
+        m = m.cuda().train()
+        net = train.data_parallel(m, [0], kind="native")
+        dev = torch.device("cuda", 0)
+        out = []
+        net.check_equal_batches(2, dev)                  # equal batches: no error, on the first call or later
+        net.check_equal_batches(2, dev)
+        # (a) the ragged last batch: ONE rank's size changes, the other keeps its size -- both must still meet in the
+        #     collective (a rank-local "size changed" condition around it hangs here) and both must see the error
+        try:
+            net.check_equal_batches(2 if rank == 0 else 1, dev)
+            net._read_batch_checks(block=True)
+            out.append("no error")
+        except RuntimeError as e:
+            out.append(str(e))
+        # (b) both sizes change, to different values
+        try:
+            net.check_equal_batches(3 if rank == 0 else 4, dev)
+            out.append("no error")
+        except RuntimeError as e:
+            out.append(str(e))
+        net.check_equal_batches(4, dev)                  # and the check recovers
+        ret[rank] = out
+        from selavi_amd.comm import NativeComm
+        NativeComm.destroy_all()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_reports_a_ragged_batch_on_every_rank():
+    """parallel.DataParallel's equal-batch check (what slv_bn_sync_finalize and the averaged buckets assume): the collective
+    is issued by every rank on every call, so the rank whose loader delivered a ragged last batch does not sit alone in it."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_ragged_worker, args=(2, 28350 + os.getpid() % 150, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        a, b = ret[r]
+        assert "batch sizes differ" in a and "max 2, min 1" in a, a
+        assert "batch sizes differ" in b and "max 4, min 3" in b, b
 
 
 def test_two_rank_native_data_parallel_on_the_16bit_path_stays_in_lock_step():

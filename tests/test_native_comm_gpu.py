@@ -180,3 +180,71 @@ def test_preflight_failure_falls_back_to_torch_distributed_on_every_rank(monkeyp
     assert ret_fb[0][3] == 0 and ret_fb[1][3] == 0, "native communicators survived a failed preflight"
     assert ret_fb[0][2] == ret_fb[1][2] == ret_gloo[0][2]
     assert ret_fb[0][1] == ret_gloo[0][1]
+
+
+# ---- W = 8 rehearsal on one GPU: the host logic of an 8-rank run (rank-order sums over 8 addends, row assembly of 8 shards,
+# buckets averaged over 8, 8-way SyncBN) before the first 8-GPU node executes it ------------------------
+def test_eight_rank_sk_iterate_sharded_matches_reference_golden(double_env, golden_dir):
+    """BASELINE configs[2]'s Sinkhorn-Knopp as 8 ranks run it: N = 170 752 rows in 8 shards of 21 344, slv_sk_iterate_sharded
+    over the library's communicator (the librccl double: 8 processes on the one GPU), labels bit-exact against the executed
+    reference, identical alpha / cost / iteration count on all 8 ranks."""
+    import torch.multiprocessing as mp
+    from tests.test_sk_gpu import _digest, _sharded_worker
+    ret = mp.Manager().dict()
+    mp.spawn(_sharded_worker, args=(8, 27900 + os.getpid() % 400, "sk_vggsound_full", golden_dir, ret, True), nprocs=8, join=True)
+    g = np.load(os.path.join(golden_dir, "sk_vggsound_full.npz"))
+    assert all(len(ret[r][1]) == 21344 for r in range(8))
+    L = np.concatenate([ret[r][1] for r in range(8)])
+    assert all(ret[r][4] for r in range(8)), "the solve did not go through the native communicator"
+    assert all(ret[r][2] == int(g["iters"]) for r in range(8))
+    assert _digest(L) == bytes(g["digest"]).decode()
+    assert np.array_equal(np.bincount(L, minlength=int(g["K"])), g["hist"])
+    for r in range(1, 8):
+        assert ret[r][0] == ret[0][0]
+        np.testing.assert_array_equal(ret[r][3], ret[0][3])
+    assert abs(ret[0][0] - float(g["cost"])) <= 1e-9 * abs(float(g["cost"]))
+    np.testing.assert_allclose(ret[0][3], g["alpha"], rtol=1e-9)
+
+
+def test_eight_rank_native_step_keeps_the_ranks_in_lock_step_and_equals_one_large_batch(monkeypatch):
+    """parallel.DataParallel on EIGHT ranks (two clips each, 8 processes on the one GPU): SyncBN sums over 8 ranks in rank
+    order, the 7 gradient buckets averaged over 8 -- through the library's communicators (librccl double) and through
+    torch.distributed/gloo.  After three steps every parameter and BatchNorm buffer is bit-identical across the 8 ranks on
+    either transport; the transports agree to rounding (gloo's ring sums 8 addends in another order than the double's rank
+    order: no bit identity between them beyond two ranks); and the mean of the 8 first-step losses is the loss of ONE process
+    on the 16 clips (SyncBN makes the statistics global: SURVEY.md Appendix B)."""
+    import torch.multiprocessing as mp
+    from oracle import step_ref
+    from oracle.model_ref import portable_fill_, portable_init_
+    from tests.test_cluster_gpu import _ddp_worker
+    monkeypatch.setenv("SLV_DBL_TIMEOUT_S", "120")
+    monkeypatch.setenv("SELAVI_NATIVE_COMM", "0")
+    ret_gloo = mp.Manager().dict()
+    mp.spawn(_ddp_worker, args=(8, 25900 + os.getpid() % 300, ret_gloo, "native", "fp32"), nprocs=8, join=True)
+    monkeypatch.setenv("SELAVI_NATIVE_COMM", "force")
+    monkeypatch.setenv("SELAVI_RCCL_LIB", build_double())
+    ret_nat = mp.Manager().dict()
+    mp.spawn(_ddp_worker, args=(8, 26900 + os.getpid() % 300, ret_nat, "native", "fp32"), nprocs=8, join=True)
+    assert all(ret_nat[r][3] >= 3 for r in range(8)), "the native run did not create the library's communicators"
+    assert all(ret_gloo[r][3] == 0 for r in range(8))
+    for ret in (ret_gloo, ret_nat):
+        for r in range(1, 8):
+            diverged = [k for k in ret[0][2] if ret[0][2][k] != ret[r][2][k]]
+            assert not diverged, f"rank {r} diverged from rank 0 in {len(diverged)} tensors: {diverged[:6]}"
+        assert np.isfinite([ret[r][1] for r in range(8)]).all()
+    np.testing.assert_allclose([ret_nat[r][0] for r in range(8)], [ret_gloo[r][0] for r in range(8)], rtol=1e-5)
+    # one process, 16 clips
+    from selavi_amd import model as smodel, optim, train
+    hc, K = 2, 7
+    m = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
+    portable_init_(m, seed=31)
+    step_ref.set_dropout_p(m, 0.0)
+    m = m.cuda().train()
+    opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+    video = portable_fill_(torch.empty(16, 3, 4, 32, 32), 5).cuda()
+    audio = portable_fill_(torch.empty(16, 1, 40, 36), 6).cuda()
+    sl = torch.from_numpy((np.arange(64 * hc).reshape(64, hc) * 7919 % K).astype(np.int64)).cuda()
+    sel = ((torch.arange(16) * 11 + 3) % 64).cuda()
+    loss = float(train.train_step(m, opt, video, audio, sl, sel, hc))
+    mean8 = float(np.mean([ret_nat[r][0] for r in range(8)]))
+    assert abs(mean8 - loss) <= 2e-4 * abs(loss), (mean8, loss)

@@ -432,3 +432,101 @@ def test_split_operand_arithmetic_is_as_accurate_as_the_native_fp32_mfma(geo, co
     plan = ops.ConvPlan.get((Bn, Cin, T, H, W), Cout, k, st, pd, dev)
     yb, _, _ = ops.conv_fwd(plan, xb.to(dev), wb.to(dev))
     _close_l2(yb, yb64, rtol=2e-6)
+
+
+def _conv64(x, w, dy, st, pd):
+    """fp64 forward / backward data / weight gradient + the componentwise error scales sum |a||b| of each."""
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y = F.conv3d(xr, wr, stride=st, padding=pd)
+    y.backward(dy.double())
+    xa, wa = x.double().abs().requires_grad_(True), w.double().abs().requires_grad_(True)
+    ya = F.conv3d(xa, wa, stride=st, padding=pd)
+    ya.backward(dy.double().abs())
+    return (y.detach(), xr.grad, wr.grad), (ya.detach(), xa.grad, wa.grad)
+
+
+RANGE_CASES = {                    # (x scale, w scale, dy scale)
+    "tiny_activations": (1e-30, 1.0, 1.0),
+    "huge_activations": (1e+30, 1.0, 1e-6),
+    "tiny_weights_huge_gradient": (1.0, 1e-30, 1e+30),
+    "huge_weights_tiny_gradient": (1e-6, 1e+30, 1e-30),
+}
+
+
+@pytest.mark.parametrize("case", list(RANGE_CASES) + ["twelve_decades"])
+@pytest.mark.parametrize("geo", [GEOMS[2], GEOMS[3], GEOMS[4]])
+def test_split_operand_arithmetic_over_the_fp32_range(geo, case, conv_arithmetic):
+    """The three-piece split is exact wherever the THIRD piece (2^-16 of the value) is still a normal bf16 number and the
+    first is finite: operands scaled to 1e-30 / 1e+30, and one tensor spanning twelve decades (late-training gradients: a
+    few large entries among many tiny ones).  Held to the native fp32-input MFMA on the same data, against fp64 -- in L2 AND
+    componentwise against sum |a||b| (the bound that says the small outputs of a wide-range tensor are right too)."""
+    if conv_arithmetic != "x3":
+        pytest.skip("compares both arithmetics in one run")
+    from selavi_amd import ops
+    Bn, Cin, T, H, W, Cout, k, st, pd = geo
+    dev = torch.device("cuda")
+    x = _mk((Bn, Cin, T, H, W), 21)
+    w = _mk((Cout, Cin) + k, 22, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5)
+    To, Ho, Wo = ((T + 2 * pd[0] - k[0]) // st[0] + 1, (H + 2 * pd[1] - k[1]) // st[1] + 1, (W + 2 * pd[2] - k[2]) // st[2] + 1)
+    dy = _mk((Bn, Cout, To, Ho, Wo), 23)
+    if case == "twelve_decades":
+        g = torch.Generator().manual_seed(24)
+        x = x * 10.0 ** (torch.rand(x.shape, generator=g) * 12 - 6)
+        dy = dy * 10.0 ** (torch.rand(dy.shape, generator=g) * 12 - 6)
+        w = w * 10.0 ** (torch.rand(w.shape, generator=g) * 6 - 3)
+    else:
+        sx, sw, sd = RANGE_CASES[case]
+        x, w, dy = x * sx, w * sw, dy * sd
+    ref, scale = _conv64(x, w, dy, st, pd)
+    errs = {}
+    for mode in ("native", "x3"):
+        ops.set_conv_arithmetic(mode)
+        plan = ops.ConvPlan.get((Bn, Cin, T, H, W), Cout, k, st, pd, dev)
+        y, _, _ = ops.conv_fwd(plan, x.to(dev), w.to(dev))
+        dx = ops.conv_dgrad(plan, dy.to(dev), ops.conv_wt_transform(plan, w.to(dev)))
+        dw = ops.conv_wgrad(plan, dy.to(dev), x.to(dev)).view_as(w)
+        e = []
+        for got, want, sc in zip((y, dx, dw), ref, scale):
+            got = got.detach().cpu().double()
+            assert torch.isfinite(got).all()
+            e.append((float((got - want).norm() / want.norm()), float(((got - want).abs() / (sc + 1e-300)).max())))
+        errs[mode] = e
+    ops.set_conv_arithmetic("x3")
+    print(case, "(L2, componentwise) fwd/dgrad/wgrad: native", [("%.1e" % a, "%.1e" % b) for a, b in errs["native"]],
+          " x3", [("%.1e" % a, "%.1e" % b) for a, b in errs["x3"]])
+    for (l2n, cwn), (l23, cw3) in zip(errs["native"], errs["x3"]):
+        assert l23 <= 5e-6 and l23 <= 1.5 * l2n + 1e-7, errs
+        # componentwise: fp32 accumulation of n terms stays below ~sqrt(n) eps of sum |a||b|; the split adds <= 3 * 2^-24
+        assert cw3 <= 2e-6 and cw3 <= 1.5 * cwn + 2e-7, errs
+
+
+def test_non_finite_inputs_poison_the_same_outputs_on_both_arithmetics(conv_arithmetic):
+    """+-inf / NaN activations: the native MFMA propagates them (inf or NaN); the split turns an infinity into (inf, NaN, NaN)
+    -- a different non-finite VALUE, the same non-finite SET: every output whose receptive field holds the element is
+    non-finite on both arithmetics, every other output is bit-identical to the clean run."""
+    if conv_arithmetic != "x3":
+        pytest.skip("compares both arithmetics in one run")
+    from selavi_amd import ops
+    Bn, Cin, T, H, W, Cout, k, st, pd = GEOMS[2]
+    dev = torch.device("cuda")
+    x = _mk((Bn, Cin, T, H, W), 31)
+    w = _mk((Cout, Cin) + k, 32, scale=(Cin * 9) ** -0.5)
+    bad = x.clone()
+    bad[0, 5, 1, 4, 7] = float("inf")
+    bad[1, 60, 2, 0, 0] = float("-inf")
+    bad[1, 3, 0, 11, 11] = float("nan")
+    hit = torch.zeros(Bn, 1, T, H, W)
+    hit[0, 0, 1, 4, 7] = hit[1, 0, 2, 0, 0] = hit[1, 0, 0, 11, 11] = 1
+    hit = F.conv3d(hit, torch.ones(1, 1, *k), stride=st, padding=pd)[:, 0] > 0          # outputs that see a poisoned input
+    sets = {}
+    for mode in ("native", "x3"):
+        ops.set_conv_arithmetic(mode)
+        plan = ops.ConvPlan.get((Bn, Cin, T, H, W), Cout, k, st, pd, dev)
+        y_clean, _, _ = ops.conv_fwd(plan, x.to(dev), w.to(dev))
+        y_bad, _, _ = ops.conv_fwd(plan, bad.to(dev), w.to(dev))
+        nonfinite = ~torch.isfinite(y_bad).cpu()
+        assert (nonfinite == hit[:, None].expand_as(nonfinite)).all(), mode
+        assert torch.equal(y_bad.cpu()[~nonfinite], y_clean.cpu()[~nonfinite]), mode
+        sets[mode] = nonfinite
+    ops.set_conv_arithmetic("x3")
+    assert torch.equal(sets["native"], sets["x3"])

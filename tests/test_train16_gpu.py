@@ -148,7 +148,11 @@ def test_weight_gradient_matches_autograd(case):
                                   # >= 1 024 columns of the layer-1 shape: both products in the accumulators of persistent
                                   # workgroups (csrc/wgrad_cl16_tacc.hip): ragged last column (9 000 pixels), 4 or 5 columns
                                   # per workgroup, 7 steps per column with the virtual frame
-                                  (4, 144, 6, 90, 100, 64)])
+                                  (4, 144, 6, 90, 100, 64),
+                                  # OFF-CENTRE source activations (|mean| = 30 sigma; the trunks' conv outputs sit below 3):
+                                  # G2 = sum dY m y and mean * G1 cancel in sum g m (y - mean) and in dW = s G2 + h G1 -- the
+                                  # error may grow with |mean| / sigma and no faster (known limitation)
+                                  (2, 144, 5, 10, 10, 64, 30.0), (4, 144, 6, 90, 100, 64, 30.0)])
 def test_temporal_weight_gradient_yields_the_source_batchnorm_sums(case, monkeypatch):
     """conv_wgrad(bnr=...) on the stride-1 (3,1,1) convs (csrc/wgrad_cl16_t2.hip): dW = s G2 + h G1 from the gradients
     against the masked raw activation (G2) and against the mask (G1), and the BatchNorm-backward sums of the layer the
@@ -159,12 +163,14 @@ def test_temporal_weight_gradient_yields_the_source_batchnorm_sums(case, monkeyp
     # which every end-to-end test runs): this test covers both kernels.  Plans are cached per shape: drop them on both sides.
     monkeypatch.setenv("SELAVI_CL16_WGT2", "all")
     monkeypatch.setattr(ops16.Plan16, "_cache", {})
-    N, Cin, T, H, W, Cout = case
+    off = case[6] if len(case) > 6 else 0.0
+    N, Cin, T, H, W, Cout = case[:6]
     k, st, pd = (3, 1, 1), (1, 1, 1), (1, 0, 0)
     gen = torch.Generator().manual_seed(Cin + 3 * Cout + T)
-    y = _bf(torch.randn(N, Cin, T, H, W, generator=gen))
+    y = _bf(torch.randn(N, Cin, T, H, W, generator=gen) + off)
     ss = torch.stack([torch.rand(Cin, generator=gen) + 0.5, torch.randn(Cin, generator=gen) * 0.3]).contiguous()
-    mi = torch.stack([torch.randn(Cin, generator=gen) * 0.2, torch.rand(Cin, generator=gen) + 0.5]).contiguous()
+    mi = torch.stack([torch.randn(Cin, generator=gen) * 0.2 + off, torch.rand(Cin, generator=gen) + 0.5]).contiguous()
+    ss[1] -= off * ss[0]                                   # shift = beta - mean * scale: the affine still crosses zero mid-distribution
     w = torch.randn(Cout, Cin, *k, generator=gen) * (Cin * 3) ** -0.5
     yc = _cl(y)
     plan = ops16.plan_for(yc, _Conv(Cin, Cout, k, st, pd))
@@ -187,7 +193,9 @@ def test_temporal_weight_gradient_yields_the_source_batchnorm_sums(case, monkeyp
     ssd, mid, wd = ss.cuda(), mi.cuda(), w.cuda()
     dw, part = ops16.conv_wgrad(plan, dyc, yc, in_ss=ssd, in_relu=True, bnr=(mid, wd))
     got = dw.view(Cout, Cin, *k).double().cpu()
-    assert float((got - dw_want).abs().max()) <= 2e-5 * float(dw_want.abs().max())     # exact operands: fp32 summation only
+    grow = 1.0 + off                                                                     # the documented growth with |mean| / sigma
+    print(f"|mean|/sigma {off:g}: dW error {float((got - dw_want).abs().max()) / float(dw_want.abs().max()):.2e} of its scale")
+    assert float((got - dw_want).abs().max()) <= 2e-5 * grow * float(dw_want.abs().max())     # exact operands: fp32 summation only
     p = part.double().cpu()
     assert p.shape == (Cin, 1, 2)
     assert float(((p[:, 0, 0] - s1_want).abs() / l1).max()) <= 2e-5, float(((p[:, 0, 0] - s1_want).abs() / l1).max())

@@ -18,6 +18,13 @@ for name, grid, d, vg, ag, lds in rows:
     name = re.sub(r"\(.*", "", name).replace("void slv::", "").replace("slv::", "")
     a = agg[(name, grid)]
     a[0] += 1; a[1] += d / 1e3; a[2:] = [vg, ag, lds]; tot += d / 1e3
+# the library the trace was taken on: selavi_amd/build.py's digest of csrc/ + include/ + flags (bench.py reports a committed
+# summary's in-step figures only when it matches the library it runs on)
+try:
+    stamp = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "selavi_amd", "libselavi_hip.so.stamp")).read().strip()
+except OSError:
+    stamp = "unknown"
+print(f"library digest {stamp}")
 print(f"total kernel time {tot/1e3:.2f} ms over {len(rows)} launches")
 print(f"{'us_total':>12} {'%':>6} {'count':>6} {'us_avg':>10} {'vgpr':>5} {'agpr':>5} {'lds':>6}  kernel [workgroups]")
 for (name, grid), (c, d, vg, ag, lds) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
