@@ -38,8 +38,11 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
 // the builtin, hipcc orders every LDS read it can see behind a DMA "that may alias" with s_waitcnt vmcnt(0) -- the whole
 // round trip in front of the chunk's MFMAs.  The compiler does not count these requests: the consumer waits explicitly.
 __device__ __forceinline__ void x3_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));      // (no "memory" clobber: it would turn every uniform load
-                                                                   //  behind it -- the tap table -- into a vector load + vmcnt(0))
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "m0");      // m0 is written (declared: the compiler may keep a value of its own there -- readlane / movrel / its own
+                             //  LDS-DMA builtins); no "memory" clobber: it would turn every uniform load behind it -- the tap
+                             //  table -- into a vector load + vmcnt(0).  What orders the LDS reads of a stage behind its DMAs is the
+                             //  explicit s_waitcnt vmcnt + barrier of the chunk loop, and tools/x3_asm_check.py checks the ISA for it
 }
 // upper halves of two dwords -> one dword (lo = a's bf16, hi = b's bf16)
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
