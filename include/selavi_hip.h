@@ -365,6 +365,11 @@ int slv_avgpool_cl16(const void* x_bf16, float* y, int64_t N, int64_t S, int C, 
  * slv_cl16_bn_*: channels-last bf16 versions of slv_bn_act / slv_bn_bwd_reduce / slv_bn_bwd_apply on [P][Cp]. */
 int32_t slv_cl16_conv_words(void);
 int32_t slv_cl16_conv_nblk(const int32_t* clconv);
+/* Which launches of slv_cl16_conv the 8-wave kernel of the wide layers takes (csrc/conv_cl16_g8.hip: 256 positions x 128 /
+ * 256 / 288 channels per workgroup, weight layouts whose rows come in such blocks): 0 = none, 1 = the launches that fill
+ * the chip (default; SELAVI_CL16_G8 sets the initial value), 2 = every launch it can express (tests).  mode < 0 only reads.
+ * Returns the previous mode.  slv_cl16_conv_nblk() follows the mode: set it before plans are made. */
+int32_t slv_cl16_g8_mode(int32_t mode);
 int slv_cl16_conv(const int32_t* clconv, int mt, const void* x_bf16, const void* w_layout_bf16, void* y_bf16,
                   const float* in_scale_shift, const float* scale_shift, const void* res_bf16, int relu,
                   float* stat_sum, float* stat_sq, const void* bnr_x_bf16 /* nullable: no fused reduction */,

@@ -211,6 +211,15 @@ int cl16_s3_try(const ClConv& g, int mt, const void* x, const void* wl, void* y,
                 const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr,
                 hipStream_t st);
 
+// csrc/conv_cl16_g8.hip: the wide layers (2-4), forward and backward data of any geometry: one 8-wave workgroup per CU,
+// 256 positions x 128 / 256 / 288 channels, the two wave groups half a period apart (one holds the matrix pipes while the
+// other stages and reads)
+bool cl16_g8_applies(const ClConv& g);
+int cl16_g8_positions();
+int cl16_g8_set_mode(int mode);
+int cl16_g8_try(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, const float* scale_shift,
+                const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr, hipStream_t st);
+
 // csrc/conv_cl16_tr.hip: stride-1 temporal (3,1,1) convs of the narrow layers, weights resident in registers, one wave
 // per workgroup walking 32-pixel columns frame by frame
 bool cl16_tr_applies(const ClConv& g);

@@ -410,6 +410,10 @@ static int cl16_launch(const slv::ClConv& g, int mt, const void* x, const void* 
     const int r = cl16_tr_try(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, bnr, (hipStream_t)stream);
     if (r != 0) return r < 0 ? r : 0;
   }
+  {   // the wide layers at sizes that fill the chip: the 8-wave ping-pong kernel (csrc/conv_cl16_g8.hip)
+    const int r = cl16_g8_try(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, bnr, (hipStream_t)stream);
+    if (r != 0) return r < 0 ? r : 0;
+  }
   {   // stride-1 (1,3,3) convs: the LDS-resident-patch kernel (csrc/conv_cl16_s3.hip)
     const int r = cl16_s3_try(g, mt, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, bnr, (hipStream_t)stream);
     if (r != 0) return r < 0 ? r : 0;
@@ -475,6 +479,7 @@ int slv_conv_cl16_fwd(const int32_t* geom, int mt, const void* x_bf16, const voi
 }
 
 int32_t slv_cl16_conv_words(void) { return slv::CLC_WORDS; }
+int32_t slv_cl16_g8_mode(int32_t mode) { return slv::cl16_g8_set_mode(mode); }
 int32_t slv_cl16_conv_nblk(const int32_t* clconv);
 
 int32_t slv_cl16_conv_dgrad_bn_apply_ok(const int32_t* clconv) {
@@ -535,7 +540,8 @@ int32_t slv_cl16_conv_nblk(const int32_t* clconv) {
   if (slv::cl16_sr_applies(g)) return slv::cl16_sr_slots(g);      // one partial per persistent workgroup
   if (slv::cl16_tr_applies(g) && slv::cl16_tr_forward(g)) return slv::cl16_tr_columns(g);      // one partial per 32-pixel column
   const long long P = (long long)g.N * g.Lt * g.Lh * g.Lw;
-  const int bn = slv::cl16_s3_applies(g) ? slv::cl16_s3_positions() : slv::CL_BN;     // positions per tile of the kernel that runs
+  // positions per tile of the kernel that runs (the order cl16_launch tries them in)
+  const int bn = slv::cl16_g8_applies(g) ? slv::cl16_g8_positions() : slv::cl16_s3_applies(g) ? slv::cl16_s3_positions() : slv::CL_BN;
   return (int32_t)((P + bn - 1) / bn);
 }
 

@@ -1,0 +1,453 @@
+// 16-bit MFMA path: the WIDE layers (layers 2-4 of R(2+1)D-18, 128..1152 channels: 45 % of the forward's time at 10 % of its
+// bytes) -- forward and backward data of any kernel / stride / padding the lattice description of cl16.hpp expresses, as
+// an implicit GEMM  D[cout][pos] = sum_{tap, c} W[cout][tap][c] * act(X)[pos * stride + tap - pad][c]  whose matrix pipes do
+// not wait for the rest of the kernel.
+//
+// What bounded the tile kernels on these layers (csrc/conv_cl16.hip, conv_cl16_s3.hip: 450-950 TFLOP/s of 2 500): a stage
+// is [issue loads | fragment reads | MFMAs | LDS writes | barrier] and the two workgroups of a CU run it in lockstep -- the
+// phases of a stage follow each other, the matrix cores idle through all but one (profiles/r02_notes.md: no single resource
+// binds).  Here ONE workgroup of 8 waves owns the CU and its two halves run the stage half a period apart ("ping-pong"):
+//   * tile = 256 positions x BM = 2 x MTW x 16 output channels (256 or 288 or 128); wave (h, q) owns channel half h and
+//     position quarter q: MTW x 4 accumulator tiles, MTW + 4 fragment reads for 4 MTW MFMAs per 32-channel chunk;
+//   * group G0 = waves 0-3, G1 = waves 4-7: one wave of each group on every SIMD.  A wave alternates two slots,
+//       R(c): write the activation pieces of chunk c + 1 to LDS (BatchNorm + ReLU on the way), read the fragments of chunk c
+//       M(c): the 4 MTW MFMAs of chunk c back to back (s_setprio 1), with the requests of later chunks riding between them:
+//             the weights of chunk c + 2 by LDS-DMA (buffer_load_dwordx4 ... lds, inline asm), the activation pieces of
+//             chunk c + 3 into registers
+//     and every slot ends in s_barrier; G1 runs ONE barrier behind G0, so while G0's waves hold the matrix pipes G1's waves
+//     do everything else, and vice versa: the pipe of a SIMD sees MFMA slots back to back.
+//   * three chunk buffers in LDS ({weights [BM][64 B], activations [256][64 B]}, XOR-swizzled rows as in cl16.hpp: the
+//     swizzle of a DMA'd image sits on the SOURCE address).  Hazards, with slot numbers (G0: R(c) = 2c, M(c) = 2c + 1; G1 one
+//     later): chunk X's activations are written in R(X - 1) (slots 2X - 2 / 2X - 1), its weights are requested in M(X - 2)
+//     (2X - 3 / 2X - 2) and waited for at the end of R(X - 1); both are read from slot 2X on.  The buffer's previous tenant,
+//     chunk X - 3, was last read in slot 2X - 5.  One s_waitcnt vmcnt(0) per R slot, placed at its END: everything it waits
+//     for was requested a whole slot earlier.  (LDS-DMA requests and register loads do not complete in order with respect to
+//     each other -- profiles/r04_notes.md -- so the wait is never a counted one.)
+// Epilogues: EPI 0 (affine / residual / ReLU -> bf16: eval-mode BatchNorm, backward data + addend) and EPI 1 (raw bf16 +
+// BatchNorm statistics of the rounded tile on the matrix cores), per channel half through a transposed LDS tile, 16-byte
+// stores along the channels.  Reference semantics: torchvision Conv3d / Conv2d forward and backward data as reached from
+// /root/reference/model.py:93-100 (r2plus1d_18 layers 2-4) under main.py:151-153 (--use_fp16).
+#include <type_traits>
+
+#include "cl16.hpp"
+#include "../../include/selavi_hip.h"
+
+namespace slv {
+
+constexpr int G8_BN = 256, G8_THREADS = 512, G8_NB = 3;
+
+// one LDS-DMA piece: 64 lanes x 16 bytes, memory (voff + soff) -> LDS at lds_addr + 16 * lane
+__device__ __forceinline__ void g8_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "m0", "memory");
+}
+// (sched_barrier: the asm's "memory" clobber holds LDS / global accesses in place, not register-only instructions -- hipcc
+//  moves MFMAs across an inline-asm wait or barrier otherwise, out of the slot they were written in)
+__device__ __forceinline__ void g8_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void g8_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+constexpr int g8_orow(int mtw) { return mtw * 32 + 16; }      // bytes per position row of the transposed half tile
+constexpr size_t g8_lds_bytes(int mtw, int cin_p, bool pro) {
+  const size_t loop = (size_t)G8_NB * (2 * mtw * 16 + G8_BN) * 64 + (pro ? (size_t)2 * cin_p * 4 : 0);
+  const size_t epi = (size_t)G8_BN * g8_orow(mtw) + (size_t)(2 + 16) * mtw * 16 * 4 + G8_BN * 4;
+  return loop > epi ? loop : epi;
+}
+
+template <int MTW, int PRO, int EPI>
+__global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsigned short* __restrict__ x,
+                                                                      const unsigned short* __restrict__ wl,
+                                                                      unsigned short* __restrict__ y,
+                                                                      const float* __restrict__ in_ss,
+                                                                      const float* __restrict__ scale_shift,
+                                                                      const unsigned short* __restrict__ res, int relu,
+                                                                      float* __restrict__ stat_sum,
+                                                                      float* __restrict__ stat_sq, ClConv g, FastDiv dLw,
+                                                                      FastDiv dLh, FastDiv dLt, FastDiv dGx) {
+  constexpr int BMH = MTW * 16, BM = 2 * BMH;
+  constexpr int ABYTES = BM * 64, STAGE = ABYTES + G8_BN * 64;
+  constexpr int NDMA = BM / 16;                           // 1 KiB pieces of a chunk's weight image (16 rows each)
+  constexpr int OROW = g8_orow(MTW);
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  typedef __attribute__((address_space(3))) void* lds_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wh = wave & 1, wq = (wave >> 1) & 1 | ((wave >> 2) << 1);      // group, channel half, position quarter
+  const unsigned P = (unsigned)g.N * g.Lt * g.Lh * g.Lw;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)x, 0, (int)((unsigned)g.N * g.Ti * g.Hi * g.Wi * g.Cin_p * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void*)wl, 0, (int)0x7FFFFFF0, 0x00020000);
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (XCD_REMAP) {        // every XCD gets a contiguous range of (channel block, position tile) units: the rows neighbouring
+    const unsigned nb = gridDim.x * gridDim.y, lin = blockIdx.x + blockIdx.y * gridDim.x, q8 = nb >> 3, r8 = nb & 7,      // tiles re-read
+                   xcd = lin & 7, loc = lin >> 3;                                                                         // for their shifted
+    const unsigned unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;                            // taps are in ITS L2
+    by = fdiv(unit, dGx);
+    bx = unit - by * gridDim.x;
+  }
+  const int m0 = by * BM;
+  // ---- activation rows of this thread: 256 rows x 4 pieces of 16 B, 2 per thread (rows tid / 4 and tid / 4 + 128)
+  int bt[2], bh[2], bw[2];
+  unsigned bbase[2];
+  const int piece = tid & 3, brow = tid >> 2;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned p = bx * G8_BN + brow + 128 * i;
+    const unsigned q1 = fdiv(p, dLw), q2 = fdiv(q1, dLh), q = fdiv(q2, dLt);      // q = clip
+    const int lw = p - q1 * g.Lw, lh = q1 - q2 * g.Lh, lt = q2 - q * g.Lt;
+    bt[i] = lt * g.bmt + g.bot;
+    bh[i] = lh * g.bmh + g.boh;
+    bw[i] = lw * g.bmw + g.bow;
+    bbase[i] = (((q * g.Ti + bt[i]) * g.Hi + bh[i]) * g.Wi + bw[i]) * (unsigned)(g.Cin_p * 2) + piece * 16u;
+    if (p >= P) bt[i] = -(1 << 20);          // (bbase wraps for negative coordinates; only used when the tap is valid)
+  }
+  const int kcs = g.Cin_p >> 5, nch = g.ntaps * kcs;
+  float* pro = (float*)(lds_raw + G8_NB * STAGE);                 // PRO 1: [2][Cin_p] scale, shift (zero beyond Cin)
+  const unsigned lds_base = (unsigned)(unsigned long)(lds_void)lds_raw;
+  // weight DMA: piece i = rows 16 i .. 16 i + 15 of the chunk's [BM][64 B] image; lane -> (row lane / 4, slot lane % 4), the
+  // slot's swizzle on the source side (cl_swz(row) = (-(row >> 2)) & 3 does not depend on i)
+  const unsigned voffA = (unsigned)((m0 + (lane >> 2)) * 64 + (((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4));
+  const unsigned bsw = (unsigned)((piece ^ ((-(tid >> 4)) & 3)) << 4);          // this thread's slot in its two activation rows
+  const int fr = lane & 15, fk = lane >> 4, fsw = (fk ^ cl_swz(fr)) << 4;
+
+  // K-step cursors: the chunk whose activation pieces are requested next, the chunk whose weights are requested next
+  int tapL = 0, kcL = 0, cL = 0, tapD = 0, kcD = 0, cD = 0, bufD = 0;
+  // the tap words of the two cursors, fetched in the R slots (scalar loads from the kernel arguments: with the fetch inside an M
+  // slot the wave sat in s_waitcnt between its 4th and 5th MFMA for the whole scalar-memory round trip)
+  int tpL = g.tap[0], tpD = g.tap[0];
+  auto fetch_taps = [&]() __attribute__((always_inline)) {
+    tpL = g.tap[tapL < g.ntaps ? tapL : 0];
+    tpD = g.tap[tapD < g.ntaps ? tapD : 0];
+  };
+  u32x4 rb[2][2];
+  unsigned okl = 0;                    // bit set * 2 + i: that piece lies inside the tensor
+  int kcw[2] = {0, 0};                 // the channel chunk of the pieces in set s (prologue table index)
+  auto issue_loads = [&](auto set_tag) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_tag)::value;
+    if (cL < nch) {
+      const int tp = tpL;
+      const int dt = (tp & 15) - 8, dh = ((tp >> 4) & 15) - 8, dw = ((tp >> 8) & 15) - 8;
+      const unsigned toff = (unsigned)(((dt * g.Hi + dh) * g.Wi + dw) * g.Cin_p * 2 + kcL * 64);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool ok = (unsigned)(bt[i] + dt) < (unsigned)g.Ti && (unsigned)(bh[i] + dh) < (unsigned)g.Hi &&
+                        (unsigned)(bw[i] + dw) < (unsigned)g.Wi;
+        okl = (okl & ~(1u << (S * 2 + i))) | ((unsigned)ok << (S * 2 + i));
+        rb[S][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? bbase[i] + toff : 0xFFFFFFF0u, 0, 0));
+      }
+      kcw[S] = kcL;
+      ++cL;
+      if (++kcL == kcs) {
+        kcL = 0;
+        ++tapL;
+      }
+    }
+  };
+  auto issue_dma = [&]() __attribute__((always_inline)) {
+    if (cD < nch) {
+      const int slab = tpD >> 12;
+      const unsigned soff = (unsigned)((slab * kcs + kcD) * g.Mrows) * 64u;
+      const unsigned dst = lds_base + (unsigned)(bufD * STAGE);
+#pragma unroll
+      for (int t = 0; t < (NDMA + 7) / 8; ++t) {
+        const int i = wave + 8 * t;
+        if (i < NDMA)
+          g8_dma16(__builtin_amdgcn_readfirstlane(dst + (unsigned)(i * 1024)), voffA, rwl,
+                   __builtin_amdgcn_readfirstlane(soff + (unsigned)(i * 1024)));
+      }
+      ++cD;
+      bufD = bufD == G8_NB - 1 ? 0 : bufD + 1;
+      if (++kcD == kcs) {
+        kcD = 0;
+        ++tapD;
+      }
+    }
+  };
+  auto write_b = [&](auto set_tag, int buf) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_tag)::value;
+    unsigned char* B = lds_raw + buf * STAGE + ABYTES;
+    u32x4 v[2] = {rb[S][0], rb[S][1]};
+    if constexpr (PRO == 1) {                                       // the producer's BatchNorm + ReLU, zero padding AFTER it
+      float s[8], h[8];
+      const float* sp = pro + kcw[S] * 32 + piece * 8;
+      *(f32x4*)s = *(const f32x4*)sp;
+      *(f32x4*)(s + 4) = *(const f32x4*)(sp + 4);
+      *(f32x4*)h = *(const f32x4*)(sp + g.Cin_p);
+      *(f32x4*)(h + 4) = *(const f32x4*)(sp + g.Cin_p + 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x4 t = affine_relu8(v[i], s, h);
+        v[i] = ((okl >> (S * 2 + i)) & 1u) ? t : (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(u32x4*)(B + (brow + 128 * i) * 64 + bsw) = v[i];
+  };
+
+  f32x4 acc[MTW][4];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr std::integral_constant<int, 0> S0{};
+  constexpr std::integral_constant<int, 1> S1{};
+  // ---- prologue of the pipeline: chunks 0 and 1 requested, chunk 0's activations in LDS, chunk 2's pieces in flight
+  issue_dma();
+  fetch_taps();
+  issue_dma();
+  issue_loads(S0);
+  fetch_taps();
+  issue_loads(S1);
+  fetch_taps();
+  if constexpr (PRO == 1) {
+    for (int i = tid; i < 2 * g.Cin_p; i += G8_THREADS) {
+      const int c = i % g.Cin_p, which = i / g.Cin_p;
+      pro[i] = c < g.Cin ? in_ss[which * g.Cin + c] : 0.f;
+    }
+    g8_barrier();
+  }
+  g8_wait_vm();
+  write_b(S0, 0);
+  issue_loads(S0);
+  fetch_taps();
+  g8_barrier();
+  if (grp == 1) g8_barrier();                       // G1 runs one slot behind G0 from here on
+
+  int bufR = 0;                                     // buffer of the chunk being multiplied; chunk c + 1 lives in the next one
+  auto iter = [&](auto set_tag) __attribute__((always_inline)) {      // set_tag: parity of chunk c + 1 (= of chunk c + 3)
+    const int bufW = bufR == G8_NB - 1 ? 0 : bufR + 1;
+    // ---- R(c).  (With the prologue the staging arithmetic comes first: its ~25 temporaries on top of the 52 fragment
+    // registers and the 144 accumulators spill at MTW = 9.)
+    const unsigned char* A = lds_raw + bufR * STAGE + (wh * BMH + fr) * 64 + fsw;
+    const unsigned char* B = lds_raw + bufR * STAGE + ABYTES + (wq * 64 + fr) * 64 + fsw;
+    bf16x8 a[MTW], b[4];
+    fetch_taps();
+    if constexpr (PRO == 1) {
+      write_b(set_tag, bufW);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(B + j * 1024);
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) a[i] = *(const bf16x8*)(A + i * 1024);
+    if constexpr (PRO == 0) write_b(set_tag, bufW);
+    g8_wait_vm();                                   // the requests of M(c - 1): chunk c + 1's weights, chunk c + 2's pieces
+    g8_barrier();
+    // ---- M(c)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      if (i == 0) issue_dma();                      // chunk c + 2's weights (its buffer was last read in R(c - 1))
+      if (i == 1) issue_loads(set_tag);             // chunk c + 3's pieces (the set R(c) just emptied)
+    }
+    __builtin_amdgcn_s_setprio(0);
+    g8_barrier();
+    bufR = bufW;
+  };
+  for (int c = 0; c < nch; c += 2) {
+    iter(S1);
+    if (c + 1 < nch) iter(S0);
+  }
+  if (grp == 0) g8_barrier();
+  g8_wait_vm();
+  g8_barrier();
+
+  // ---- epilogue, one channel half at a time: the half's tiles transposed through LDS ([position][cout] rows), statistics
+  // of the rounded tile on the matrix cores (8 waves x 32 rows), 16-byte stores along a position's channels
+  unsigned char* ot = lds_raw;                                    // [256][OROW]
+  float* ssl = (float*)(lds_raw + G8_BN * OROW);                  // EPI 0: [2][BMH] scale, shift of the half
+  float* red = ssl + 2 * BMH;                                     // EPI 1: [8 waves][2][BMH] partials
+  unsigned* opos = (unsigned*)(red + 16 * BMH);                   // [256] output position (row index) or ~0
+  if (tid < G8_BN) {
+    const unsigned p = bx * G8_BN + tid;
+    unsigned o = 0xFFFFFFFFu;
+    if (p < P) {
+      const unsigned q1 = fdiv(p, dLw), q2 = fdiv(q1, dLh), q = fdiv(q2, dLt);
+      const int lw = p - q1 * g.Lw, lh = q1 - q2 * g.Lh, lt = q2 - q * g.Lt;
+      o = ((q * g.To + lt * g.omt + g.oot) * g.Ho + lh * g.omh + g.ooh) * g.Wo + lw * g.omw + g.oow;
+    }
+    opos[tid] = o;
+  }
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    const int c0 = m0 + hh * BMH;                                 // first channel of the half
+    if (EPI == 0 && scale_shift) {
+      for (int i = tid; i < 2 * BMH; i += G8_THREADS) {
+        const int c = c0 + (i % BMH);
+        ssl[i] = c < g.Cout ? scale_shift[(i / BMH) * g.Cout + c] : 0.f;
+      }
+    }
+    g8_barrier();                                                 // opos / ssl written; the previous half's rows stored
+    if (wh == hh) {
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        const int co = c0 + i * 16 + fk * 4;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (EPI == 0 && scale_shift) {
+          sc = *(const f32x4*)(ssl + i * 16 + fk * 4);
+          sh = *(const f32x4*)(ssl + BMH + i * 16 + fk * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int pl = wq * 64 + j * 16 + fr;                   // position inside the block
+          float v[4];
+          if constexpr (EPI == 0) {
+            const unsigned op = opos[pl];
+            uint2 rr = make_uint2(0u, 0u);
+            if (res && op != 0xFFFFFFFFu && co < g.Cout_p) rr = *(const uint2*)(res + (size_t)op * g.Cout_p + co);
+            if (!scale_shift && !relu) {      // backward data: the accumulator (+ addend) as it is
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r];
+                if (res) v[r] += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float t = __builtin_fmaf(acc[i][j][r], sc[r], sh[r]);
+                if (res) t += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
+                if (relu) t = fmaxf(t, 0.f);
+                v[r] = t;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];      // rows >= Cout: zero weights -> 0
+          }
+          *(uint2*)(ot + pl * OROW + (i * 16 + fk * 4) * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
+      }
+    }
+    g8_barrier();
+    if constexpr (EPI == 1) {
+      wave_tile_stats<MTW>(ot + wave * 32 * OROW, OROW, lane, red + (wave * 2 + 0) * BMH, red + (wave * 2 + 1) * BMH);
+      g8_barrier();
+      for (int i = tid; i < 2 * BMH; i += G8_THREADS) {
+        const int c = i % BMH, which = i / BMH;
+        if (c0 + c < g.Cout) {
+          float t = red[which * BMH + c];
+#pragma unroll
+          for (int w = 1; w < 8; ++w) t += red[(w * 2 + which) * BMH + c];      // the 8 waves' partials in fixed order
+          (which ? stat_sq : stat_sum)[(size_t)(c0 + c) * gridDim.x + bx] = t;   // [Cout][tiles]
+        }
+      }
+    }
+    // rows of this half in the output: channels [c0, c0 + BMH) clipped to Cout_p; the last half of the last channel block
+    // also zero-fills the padding channels no tile covers (Mrows < Cout_p)
+    const int c_hi = min(c0 + BMH, g.Cout_p);
+    const int c_end = (by == gridDim.y - 1 && hh == 1) ? g.Cout_p : c_hi;
+    const int pieces = (c_end - c0) >> 3;                 // 16-byte pieces per position
+    if (pieces > 0) {
+      const int rpp = G8_THREADS / pieces, pl0 = tid / pieces, pc = tid - pl0 * pieces;
+      if (pl0 < rpp) {
+        const bool cval = c0 + pc * 8 < c_hi;
+        const unsigned char* src = ot + pl0 * OROW + pc * 16;
+        unsigned char* yb = (unsigned char*)y;
+        const unsigned coff = (unsigned)(c0 + pc * 8) * 2u, rowb = (unsigned)g.Cout_p * 2u;
+        for (int pl = pl0; pl < G8_BN; pl += rpp, src += rpp * OROW) {
+          const unsigned op = opos[pl];
+          if (op == 0xFFFFFFFFu) continue;
+          u32x4 val = {0u, 0u, 0u, 0u};
+          if (cval) val = *(const u32x4*)src;
+          *(u32x4*)(yb + op * rowb + coff) = val;
+        }
+      }
+    }
+  }
+}
+
+// MTW (16-row tiles per channel HALF of a block) from the weight layout's rows: blocks of 288, 256 or 128 rows
+static int g8_mtw(const ClConv& g) {
+  if (g.Mrows % 288 == 0) return 9;
+  if (g.Mrows % 256 == 0) return 8;
+  if (g.Mrows % 128 == 0) return 4;
+  return 0;
+}
+// SELAVI_CL16_G8: 0 = off, 1 (default) = launches that fill the chip, force = every launch the kernel can express (tests);
+// slv_cl16_g8_mode() changes it at run time
+static int g8_mode_value = -1;
+static int g8_mode() {
+  if (g8_mode_value < 0) {
+    const char* e = getenv("SELAVI_CL16_G8");
+    g8_mode_value = !e ? 1 : (e[0] == '0' ? 0 : ((e[0] == 'f' || e[0] == 'F' || e[0] == '2') ? 2 : 1));
+  }
+  return g8_mode_value;
+}
+int cl16_g8_set_mode(int mode) {
+  const int prev = g8_mode();
+  if (mode >= 0 && mode <= 2) g8_mode_value = mode;
+  return prev;
+}
+bool cl16_g8_applies(const ClConv& g) {
+  const int mode = g8_mode();
+  if (!mode) return false;
+  const int mtw = g8_mtw(g);
+  if (!mtw || g.ntaps < 1 || g.Cin_p < 32 || g.Cin_p > CL_PRO_MAXC) return false;
+  if (g8_lds_bytes(mtw, g.Cin_p, true) > 160 * 1024) return false;
+  const long long P = (long long)g.N * g.Lt * g.Lh * g.Lw;
+  const long long blocks = ((P + G8_BN - 1) / G8_BN) * (g.Mrows / (32 * mtw));
+  if (mode == 1) {
+    // one workgroup per CU: a launch of fewer than ~a round of 256 leaves CUs idle that the 128-position tiles would fill;
+    // narrow contractions (the stems) have nothing for the pipeline to overlap
+    if (blocks < 160 || g.Cin_p * g.ntaps < 256) return false;
+    static const bool over_s3 = []() {
+      const char* e = getenv("SELAVI_CL16_G8_S3");
+      return !(e && e[0] == '0');
+    }();
+    if (!over_s3 && cl16_s3_applies(g)) return false;
+  }
+  return true;
+}
+int cl16_g8_positions() { return G8_BN; }
+
+template <int MTW, int PRO, int EPI>
+static int g8_launch_one(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss,
+                         const float* scale_shift, const void* res, int relu, float* stat_sum, float* stat_sq,
+                         hipStream_t st) {
+  const size_t lds = g8_lds_bytes(MTW, g.Cin_p, PRO != 0);
+  static bool attr_set = false;                          // per instantiation; idempotent, so a race is harmless
+  if (!attr_set) {
+    SLV_HIP(hipFuncSetAttribute((const void*)conv_cl16_g8_kernel<MTW, PRO, EPI>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const unsigned P = (unsigned)g.N * g.Lt * g.Lh * g.Lw;
+  dim3 grid((P + G8_BN - 1) / G8_BN, g.Mrows / (32 * MTW));
+  hipLaunchKernelGGL((conv_cl16_g8_kernel<MTW, PRO, EPI>), grid, dim3(G8_THREADS), lds, st, (const unsigned short*)x,
+                     (const unsigned short*)wl, (unsigned short*)y, in_ss, scale_shift, (const unsigned short*)res, relu,
+                     stat_sum, stat_sq, g, make_fastdiv(g.Lw), make_fastdiv(g.Lh), make_fastdiv(g.Lt), make_fastdiv(grid.x));
+  return 0;
+}
+
+// returns 1 when the launch was taken, 0 when it does not apply, < 0 on error
+int cl16_g8_try(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, const float* scale_shift,
+                const void* res, int relu, float* stat_sum, float* stat_sq, const ClBnr& bnr, hipStream_t st) {
+  if (!cl16_g8_applies(g)) return 0;
+  if (bnr.part)        // (slv_cl16_conv_nblk reports THIS kernel's tile count for the geometry: no silent change of kernel)
+    return fail(-2, "%s: the 8-wave conv kernel has no fused BatchNorm-backward sums (SELAVI_CL16_FUSE_BNR=1 needs SELAVI_CL16_G8=0)",
+                "slv_cl16_conv");
+  const int mtw = g8_mtw(g), pro = in_ss ? 1 : 0, epi = stat_sum ? 1 : 0;
+  int rc = 0;
+#define SLV_G8_K(MTW_)                                                                                                    \
+  do {                                                                                                                    \
+    if (pro == 0 && epi == 0) rc = g8_launch_one<MTW_, 0, 0>(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, st); \
+    else if (pro == 1 && epi == 0) rc = g8_launch_one<MTW_, 1, 0>(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, st); \
+    else if (pro == 0 && epi == 1) rc = g8_launch_one<MTW_, 0, 1>(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, st); \
+    else rc = g8_launch_one<MTW_, 1, 1>(g, x, wl, y, in_ss, scale_shift, res, relu, stat_sum, stat_sq, st);                \
+  } while (0)
+  if (mtw == 9) SLV_G8_K(9);
+  else if (mtw == 8) SLV_G8_K(8);
+  else SLV_G8_K(4);
+#undef SLV_G8_K
+  if (rc) return rc;
+  rc = launch_check("slv_cl16_conv");
+  return rc ? rc : 1;
+}
+
+}  // namespace slv

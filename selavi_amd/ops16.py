@@ -33,6 +33,12 @@ def _pick_mt(cout):
         rows = -(-cout // (16 * mt)) * 16 * mt
         if best is None or rows < best[1]:
             best = (mt, rows)
+    # the 8-wave kernel of the wide layers (csrc/conv_cl16_g8.hip) takes weight layouts whose rows come in blocks of 288, 256
+    # or 128: 921 channels -> 1 024 rows instead of 960 (7 % more rows, one kernel for the whole layer)
+    if cout > 256 and best[1] % 128 and best[1] % 288:
+        rows = -(-cout // 256) * 256
+        if rows <= 1.08 * best[1]:
+            best = (8, rows)
     return best
 
 

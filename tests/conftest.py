@@ -26,3 +26,17 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(params=["default", "g8_everywhere"])
+def g8(request):
+    """The 16-bit conv op tests under both dispatch modes of the 8-wave kernel of the wide layers (csrc/conv_cl16_g8.hip):
+    the default (it takes only launches that fill the chip: none of the small test shapes) and slv_cl16_g8_mode(2) = every
+    launch it can express.  Plans carry the statistics-partial count of the kernel that runs: dropped on both sides."""
+    from selavi_amd import ops16
+    from selavi_amd._lib import C
+    prev = C.slv_cl16_g8_mode(2 if request.param == "g8_everywhere" else -1)
+    ops16.Plan16._cache.clear()
+    yield request.param
+    C.slv_cl16_g8_mode(prev)
+    ops16.Plan16._cache.clear()

@@ -18,6 +18,9 @@ CASES = [  # N, Cin, T, H, W, Cout, k, stride, pad        every conv family of t
     (3, 1, 1, 40, 36, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),        # audio stem (2-D: T = 1)
     (2, 128, 1, 9, 7, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # audio BasicBlock conv
     (1, 512, 2, 7, 7, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # layer-4 spatial (many K-steps, 8 M blocks)
+    (2, 128, 4, 14, 14, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # layer-2 spatial: 7 position tiles of the 8-wave kernel
+    (1, 288, 6, 10, 10, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0)),     # layer-2 temporal: 27 chunks (odd)
+    (1, 460, 7, 7, 7, 256, (3, 1, 1), (2, 1, 1), (1, 0, 0)),       # 460 -> 480 channels, stride-2 temporal
 ]
 
 
@@ -26,7 +29,7 @@ def _bf(t):
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_conv_cl16_matches_fp32_conv_on_bf16_values(case):
+def test_conv_cl16_matches_fp32_conv_on_bf16_values(case, g8):
     from selavi_amd import ops16
     N, Cin, T, H, W, Cout, k, st, pd = case
     g = torch.Generator().manual_seed(Cin * 1000 + Cout)

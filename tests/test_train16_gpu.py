@@ -34,6 +34,22 @@ CASES = [  # N, Cin, T, H, W, Cout, k, stride, pad        the conv families of t
 ]
 
 
+# the wide layers on the 8-wave kernel (csrc/conv_cl16_g8.hip), which by default takes only launches that fill the chip: run
+# under slv_cl16_g8_mode(2) = "every launch it can express" (fixture g8): several position tiles with a ragged last one, two
+# channel blocks (576 rows), every half-tile height (128 / 256 / 288 rows), odd and single chunk counts (the pipeline's
+# prologue and tail), stride-2 parity classes, prologue on / off, statistics, the addend
+G8_CASES = [
+    (2, 128, 4, 14, 14, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # layer-2 spatial: 7 tiles (6.1), 288 rows, 36 chunks; dgrad 128 rows
+    (1, 288, 6, 10, 10, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0)),     # layer-2 temporal: 128 rows, 27 chunks (odd); dgrad 288 rows
+    (2, 256, 3, 9, 9, 576, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # two channel blocks of 288, 2 tiles (1.9)
+    (1, 32, 2, 20, 20, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),      # ONE chunk
+    (1, 96, 3, 12, 12, 512, (1, 1, 1), (2, 2, 2), (0, 0, 0)),      # three chunks, stride 2 (dgrad: classes without a tap)
+    (1, 128, 5, 14, 14, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # stride-2 spatial, 230 -> 256 rows; dgrad by parity classes
+    (1, 460, 7, 7, 7, 256, (3, 1, 1), (2, 1, 1), (1, 0, 0)),       # stride-2 temporal, 460 -> 480 channels; dgrad 512 rows
+    (1, 512, 2, 7, 7, 921, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # 921 -> 1 024 rows (4 blocks of 256), one ragged tile
+]
+
+
 def _bf(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
@@ -53,8 +69,8 @@ class _Conv:
         self.in_channels, self.out_channels, self.kernel3, self.stride3, self.padding3 = cin, cout, k, st, pd
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_train_forward_prologue_and_statistics(case):
+@pytest.mark.parametrize("case", CASES + G8_CASES)
+def test_train_forward_prologue_and_statistics(case, g8):
     """conv(relu(bn(x))) with the producer's BatchNorm + ReLU applied on load (zero padding after the affine) and the
     batch statistics of the bf16-rounded output from the epilogue."""
     from selavi_amd import ops16
@@ -87,8 +103,8 @@ def test_train_forward_prologue_and_statistics(case):
         assert n1 is None and torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_backward_data_matches_autograd(case):
+@pytest.mark.parametrize("case", CASES + G8_CASES)
+def test_backward_data_matches_autograd(case, g8):
     from selavi_amd import ops16
     N, Cin, T, H, W, Cout, k, st, pd = case
     g = torch.Generator().manual_seed(3 * Cin + Cout)
