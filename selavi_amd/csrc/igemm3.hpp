@@ -44,6 +44,13 @@ __device__ __forceinline__ void x3_dma16(unsigned lds_addr, unsigned voff, __amd
                              //  table -- into a vector load + vmcnt(0).  What orders the LDS reads of a stage behind its DMAs is the
                              //  explicit s_waitcnt vmcnt + barrier of the chunk loop, and tools/x3_asm_check.py checks the ISA for it
 }
+// A slot boundary of the ping-pong form (8-wave workgroups, below): LDS traffic drained, s_barrier; the sched_barriers keep
+// register-only instructions (MFMAs) on their side of it (an asm's "memory" clobber holds memory accesses only).
+__device__ __forceinline__ void x3_pp_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 // upper halves of two dwords -> one dword (lo = a's bf16, hi = b's bf16)
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
@@ -75,9 +82,20 @@ constexpr int X3_MAXC = 1152;     // widest gathered tensor of the two trunks (p
 // FUSE: B two chunks deep with the split between the MFMAs (above); false: one chunk deep, the split behind the chunk's
 // MFMAs -- ~90 registers fewer (no second operand set, none of the rematerialisation the long live ranges cause: 140
 // instead of 290 VALU instructions per chunk), which buys a third workgroup per CU for the tiles whose LDS admits it (MT <= 8).
+// PING-PONG (WAVES == 8 with the lean pipeline): what the counters said of the 4-wave forms -- MFMA busy 50 %, two waves per
+// SIMD that run in phase, each stalled while the other holds the pipe it wants (profiles/r04_notes.md 2) -- is a scheduling
+// problem between the two waves of a SIMD, not a resource limit.  One 8-wave workgroup owns the CU; an iteration is cut into
+// an M slot (the A-stage DMA and the raw B loads of chunk c + 1 requested, then the 6 MT NT MFMAs of chunk c back to back at
+// s_setprio 1) and an S slot (chunk c + 1's raw elements: BatchNorm + ReLU, cut into the three bf16 planes), each ending in
+// s_barrier, and waves 4-7 run ONE barrier behind waves 0-3: a SIMD's two waves are always in opposite slots, its matrix
+// pipe sees M slots back to back while the VALU does the other wave's split.  Hazards (slots: waves 0-3 M(c) = 2c, S(c) = 2c + 1,
+// waves 4-7 one later): stage c & 1 is read in slots 2c and 2c + 1; the DMA pieces of chunk c + 1 go into the other stage
+// from slot 2c on (its tenant, chunk c - 1, was last read in slot 2c - 1) and are waited for by their issuing wave at the end
+// of its M(c) (slots 2c / 2c + 1): landed before slot 2c + 2.
 template <int MT, int NT, int PRO, int EPI, int WAVES, int OCC, bool FUSE>
 __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs g) {
   constexpr int BM = MT * 16, BN = NT * 16 * WAVES, NTHR = 64 * WAVES;
+  constexpr bool PP = WAVES == 8 && !FUSE;
   constexpr int A_BYTES = 3 * BM * 64;
   constexpr int EPI_BYTES = (2 * WAVES + 4) * BM * 4;
 #ifndef SLV_X3_LDS_PAD
@@ -375,6 +393,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
     __syncthreads();                 // ... everybody's
     split_chunk(P0);
     X3_T(2);
+    if (PP && wave >= 4) x3_pp_barrier();                 // the second wave group runs one slot behind the first from here on
     // iteration c: stage / fragment set c & 1 is multiplied, raw set (c + 1) & 1 is split, raw set c & 1 is re-loaded (chunk c + 2)
     // (!FUSE: raw set (c + 1) & 1 is loaded at the top of the iteration and split at its end)
     auto iter = [&](int c, auto par) __attribute__((always_inline)) {
@@ -391,10 +410,20 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
         load_chunk(c + 1, std::integral_constant<int, P ^ 1>{});
       }
       X3_T(tb + 2);
-      compute(P, par, std::true_type{}, full_tag, c + 2);  // (!FUSE: the split of raw set P ^ 1 follows the MFMAs inside)
-      X3_T(tb + 3);
-      asm volatile("s_waitcnt vmcnt(0)");                 // this wave's DMA pieces of chunk c + 1 (the barrier's fence pins the order)
-      __syncthreads();               // stage (c + 1) & 1 has landed for everybody and stage c & 1 is free
+      if constexpr (PP) {
+        __builtin_amdgcn_s_setprio(1);
+        compute(P, par, std::false_type{}, full_tag);      // M slot: the MFMAs of chunk c, nothing else
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces and raw elements of chunk c + 1
+        x3_pp_barrier();
+        split_chunk(std::integral_constant<int, P ^ 1>{}); // S slot
+        x3_pp_barrier();
+      } else {
+        compute(P, par, std::true_type{}, full_tag, c + 2);  // (!FUSE: the split of raw set P ^ 1 follows the MFMAs inside)
+        X3_T(tb + 3);
+        asm volatile("s_waitcnt vmcnt(0)");                 // this wave's DMA pieces of chunk c + 1 (the barrier's fence pins the order)
+        __syncthreads();               // stage (c + 1) & 1 has landed for everybody and stage c & 1 is free
+      }
       X3_T(tb + 5);
     };
     int c = 0;
@@ -408,6 +437,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
     } else {
       compute(0, P0, std::false_type{}, full_tag);
     }
+    if (PP && wave < 4) x3_pp_barrier();                  // (the barrier the second group was given in front of the loop)
     __syncthreads();
     X3_T(3);
   };
@@ -560,8 +590,9 @@ inline void launch_igemm3(IgemmArgs a, int splits, hipStream_t st) {
   // workgroups per CU the register budget is cut for: the LDS (two A stages) admits 2 at MT = 9, 3 at MT = 8, 6 at MT = 4
   // MT = 9 (two A stages = 55 KB: two workgroups per CU at most): fused two-deep pipeline; MT <= 8: the lean pipeline, three
   // workgroups per CU (the fused one spills under that register cap)
-  constexpr bool FUSE_ = WAVES == 8 || MT >= 9;
-  constexpr int OCC_ = WAVES == 8 ? 1 : (FUSE_ ? 2 : 3);
+  // 8 waves: the lean pipeline in its ping-pong form (one workgroup per CU = two waves per SIMD: OCC_ counts waves per SIMD)
+  constexpr bool FUSE_ = WAVES == 8 ? false : MT >= 9;
+  constexpr int OCC_ = WAVES == 8 ? 2 : (FUSE_ ? 2 : 3);
   const size_t dyn = (size_t)((((a.Kd >> 4) + 4) & ~1) * 8) + (act ? (size_t)2 * ((a.Cb + 15) / 16 * 16) * sizeof(float) : 0);
 #define SLV_K3(PRO_, EPI_) \
   hipLaunchKernelGGL((igemm3_kernel<MT, NT, PRO_, EPI_, WAVES, OCC_, FUSE_>), grid, dim3(64 * WAVES), dyn, st, a)
