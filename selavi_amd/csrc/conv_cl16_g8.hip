@@ -10,18 +10,18 @@
 //   * tile = 256 positions x BM = 2 x MTW x 16 output channels (256 or 288 or 128); wave (h, q) owns channel half h and
 //     position quarter q: MTW x 4 accumulator tiles, MTW + 4 fragment reads for 4 MTW MFMAs per 32-channel chunk;
 //   * group G0 = waves 0-3, G1 = waves 4-7: one wave of each group on every SIMD.  A wave alternates two slots,
-//       R(c): write the activation pieces of chunk c + 1 to LDS (BatchNorm + ReLU on the way), read the fragments of chunk c
-//       M(c): the 4 MTW MFMAs of chunk c back to back (s_setprio 1), with the requests of later chunks riding between them:
-//             the weights of chunk c + 2 by LDS-DMA (buffer_load_dwordx4 ... lds, inline asm), the activation pieces of
-//             chunk c + 3 into registers
+//       R(c): request the weights of chunk c + 2 (LDS-DMA: buffer_load_dwordx4 ... lds, inline asm) and the activation pieces
+//             of chunk c + 3 (registers), write the pieces of chunk c + 1 to LDS (BatchNorm + ReLU on the way), read the
+//             fragments of chunk c
+//       M(c): the 4 MTW MFMAs of chunk c back to back (s_setprio 1), nothing else
 //     and every slot ends in s_barrier; G1 runs ONE barrier behind G0, so while G0's waves hold the matrix pipes G1's waves
 //     do everything else, and vice versa: the pipe of a SIMD sees MFMA slots back to back.
 //   * three chunk buffers in LDS ({weights [BM][64 B], activations [256][64 B]}, XOR-swizzled rows as in cl16.hpp: the
 //     swizzle of a DMA'd image sits on the SOURCE address).  Hazards, with slot numbers (G0: R(c) = 2c, M(c) = 2c + 1; G1 one
-//     later): chunk X's activations are written in R(X - 1) (slots 2X - 2 / 2X - 1), its weights are requested in M(X - 2)
-//     (2X - 3 / 2X - 2) and waited for at the end of R(X - 1); both are read from slot 2X on.  The buffer's previous tenant,
-//     chunk X - 3, was last read in slot 2X - 5.  One s_waitcnt vmcnt(0) per R slot, placed at its END: everything it waits
-//     for was requested a whole slot earlier.  (LDS-DMA requests and register loads do not complete in order with respect to
+//     later): chunk X's activations are written in R(X - 1) (slots 2X - 2 / 2X - 1), its weights are requested in R(X - 2)
+//     (2X - 4 / 2X - 3) and waited for at the start of R(X - 1); both are read from slot 2X on.  The buffer's previous tenant,
+//     chunk X - 3, was last read in slot 2X - 5.  One s_waitcnt vmcnt(0) per R slot, at its START, in front of the slot's own
+//     requests: everything it waits for was requested a whole period earlier.  (LDS-DMA requests and register loads do not complete in order with respect to
 //     each other -- profiles/r04_notes.md -- so the wait is never a counted one.)
 // Epilogues: EPI 0 (affine / residual / ReLU -> bf16: eval-mode BatchNorm, backward data + addend) and EPI 1 (raw bf16 +
 // BatchNorm statistics of the rounded tile on the matrix cores), per channel half through a transposed LDS tile, 16-byte
@@ -125,19 +125,29 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
   u32x4 rb[2][2];
   unsigned okl = 0;                    // bit set * 2 + i: that piece lies inside the tensor
   int kcw[2] = {0, 0};                 // the channel chunk of the pieces in set s (prologue table index)
+  // (the tap's part of a request -- validity of the two rows, offset of the shifted row -- is formed when the tap CHANGES, every
+  //  Cin_p / 32 chunks, not per chunk: ~30 VALU instructions of every R slot otherwise)
+  unsigned okT = 0, toffT = 0;
   auto issue_loads = [&](auto set_tag) __attribute__((always_inline)) {
     constexpr int S = decltype(set_tag)::value;
     if (cL < nch) {
-      const int tp = tpL;
-      const int dt = (tp & 15) - 8, dh = ((tp >> 4) & 15) - 8, dw = ((tp >> 8) & 15) - 8;
-      const unsigned toff = (unsigned)(((dt * g.Hi + dh) * g.Wi + dw) * g.Cin_p * 2 + kcL * 64);
+      if (kcL == 0) {
+        const int tp = tpL;
+        const int dt = (tp & 15) - 8, dh = ((tp >> 4) & 15) - 8, dw = ((tp >> 8) & 15) - 8;
+        toffT = (unsigned)(((dt * g.Hi + dh) * g.Wi + dw) * g.Cin_p * 2);
+        okT = 0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const bool ok = (unsigned)(bt[i] + dt) < (unsigned)g.Ti && (unsigned)(bh[i] + dh) < (unsigned)g.Hi &&
-                        (unsigned)(bw[i] + dw) < (unsigned)g.Wi;
-        okl = (okl & ~(1u << (S * 2 + i))) | ((unsigned)ok << (S * 2 + i));
-        rb[S][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? bbase[i] + toff : 0xFFFFFFF0u, 0, 0));
+        for (int i = 0; i < 2; ++i) {
+          const bool ok = (unsigned)(bt[i] + dt) < (unsigned)g.Ti && (unsigned)(bh[i] + dh) < (unsigned)g.Hi &&
+                          (unsigned)(bw[i] + dw) < (unsigned)g.Wi;
+          okT |= (unsigned)ok << i;
+        }
       }
+      const unsigned toff = toffT + (unsigned)(kcL * 64);
+      okl = (okl & ~(3u << (S * 2))) | (okT << (S * 2));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        rb[S][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ((okT >> i) & 1u) ? bbase[i] + toff : 0xFFFFFFF0u, 0, 0));
       kcw[S] = kcL;
       ++cL;
       if (++kcL == kcs) {
@@ -219,33 +229,53 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
 
   int bufR = 0;                                     // buffer of the chunk being multiplied; chunk c + 1 lives in the next one
   auto iter = [&](auto set_tag) __attribute__((always_inline)) {      // set_tag: parity of chunk c + 1 (= of chunk c + 3)
+    constexpr int S = decltype(set_tag)::value;
     const int bufW = bufR == G8_NB - 1 ? 0 : bufR + 1;
-    // ---- R(c).  (With the prologue the staging arithmetic comes first: its ~25 temporaries on top of the 52 fragment
-    // registers and the 144 accumulators spill at MTW = 9.)
+    // ---- R(c): everything that is not an MFMA.  FIRST the wait for last slot's requests (a whole period old) and the new
+    // requests -- chunk c + 2's weights (its buffer was last read in R(c - 1)), chunk c + 3's pieces into the set whose
+    // tenant, chunk c + 1, is written to LDS below -- so that every request has a full period to land; an LDS-DMA
+    // instruction costs the issuing wave 60-180 cycles of issue (MI355X_MICROARCH.md): inside the M slot each one idled the
+    // matrix pipe for that long (first version: 740 instead of 860 TFLOP/s on layer 2.1).
     const unsigned char* A = lds_raw + bufR * STAGE + (wh * BMH + fr) * 64 + fsw;
     const unsigned char* B = lds_raw + bufR * STAGE + ABYTES + (wq * 64 + fr) * 64 + fsw;
     bf16x8 a[MTW], b[4];
+    g8_wait_vm();
+    u32x4 keep[2] = {rb[S][0], rb[S][1]};           // chunk c + 1's pieces leave the request registers
+    const unsigned keep_ok = (okl >> (S * 2)) & 3u;
+    const int keep_kc = kcw[S];
+    issue_dma();
+    issue_loads(set_tag);
     fetch_taps();
-    if constexpr (PRO == 1) {
-      write_b(set_tag, bufW);
-      __builtin_amdgcn_sched_barrier(0);
+    {
+      unsigned char* Bw = lds_raw + bufW * STAGE + ABYTES;
+      if constexpr (PRO == 1) {                                       // the producer's BatchNorm + ReLU, zero padding AFTER it
+        float sc[8], sh[8];
+        const float* sp = pro + keep_kc * 32 + piece * 8;
+        *(f32x4*)sc = *(const f32x4*)sp;
+        *(f32x4*)(sc + 4) = *(const f32x4*)(sp + 4);
+        *(f32x4*)sh = *(const f32x4*)(sp + g.Cin_p);
+        *(f32x4*)(sh + 4) = *(const f32x4*)(sp + g.Cin_p + 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x4 t = affine_relu8(keep[i], sc, sh);
+          keep[i] = ((keep_ok >> i) & 1u) ? t : (u32x4){0u, 0u, 0u, 0u};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *(u32x4*)(Bw + (brow + 128 * i) * 64 + bsw) = keep[i];
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(B + j * 1024);
 #pragma unroll
     for (int i = 0; i < MTW; ++i) a[i] = *(const bf16x8*)(A + i * 1024);
-    if constexpr (PRO == 0) write_b(set_tag, bufW);
-    g8_wait_vm();                                   // the requests of M(c - 1): chunk c + 1's weights, chunk c + 2's pieces
     g8_barrier();
-    // ---- M(c)
+    // ---- M(c): the MFMAs of chunk c, nothing else
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      if (i == 0) issue_dma();                      // chunk c + 2's weights (its buffer was last read in R(c - 1))
-      if (i == 1) issue_loads(set_tag);             // chunk c + 3's pieces (the set R(c) just emptied)
-    }
     __builtin_amdgcn_s_setprio(0);
     g8_barrier();
     bufR = bufW;

@@ -82,7 +82,7 @@ constexpr int X3_MAXC = 1152;     // widest gathered tensor of the two trunks (p
 // FUSE: B two chunks deep with the split between the MFMAs (above); false: one chunk deep, the split behind the chunk's
 // MFMAs -- ~90 registers fewer (no second operand set, none of the rematerialisation the long live ranges cause: 140
 // instead of 290 VALU instructions per chunk), which buys a third workgroup per CU for the tiles whose LDS admits it (MT <= 8).
-// PING-PONG (WAVES == 8 with the lean pipeline): what the counters said of the 4-wave forms -- MFMA busy 50 %, two waves per
+// PING-PONG (WAVES == 8 with the lean pipeline; an experiment kept behind -DSLV_X3_PP=1, see launch_igemm3): what the counters said of the 4-wave forms -- MFMA busy 50 %, two waves per
 // SIMD that run in phase, each stalled while the other holds the pipe it wants (profiles/r04_notes.md 2) -- is a scheduling
 // problem between the two waves of a SIMD, not a resource limit.  One 8-wave workgroup owns the CU; an iteration is cut into
 // an M slot (the A-stage DMA and the raw B loads of chunk c + 1 requested, then the 6 MT NT MFMAs of chunk c back to back at
@@ -590,9 +590,15 @@ inline void launch_igemm3(IgemmArgs a, int splits, hipStream_t st) {
   // workgroups per CU the register budget is cut for: the LDS (two A stages) admits 2 at MT = 9, 3 at MT = 8, 6 at MT = 4
   // MT = 9 (two A stages = 55 KB: two workgroups per CU at most): fused two-deep pipeline; MT <= 8: the lean pipeline, three
   // workgroups per CU (the fused one spills under that register cap)
-  // 8 waves: the lean pipeline in its ping-pong form (one workgroup per CU = two waves per SIMD: OCC_ counts waves per SIMD)
-  constexpr bool FUSE_ = WAVES == 8 ? false : MT >= 9;
-  constexpr int OCC_ = WAVES == 8 ? 2 : (FUSE_ ? 2 : 3);
+  // (-DSLV_X3_PP=1: the 8-wave tiles on the lean pipeline in its ping-pong form, one workgroup per CU = two waves per SIMD.
+  //  Measured (tools/x3_pp_ab.py, profiles/r05_notes.md): SLOWER than the free-running 4-wave forms on every layer -- 159 vs 192
+  //  TFLOP/s on the layer-1 spatial forward: with the slots fenced by barriers nothing may fill the matrix pipe while the wave
+  //  that owns the M slot waits for its next A fragments, one LDS round trip per row-tile step.  Off.)
+#ifndef SLV_X3_PP
+#define SLV_X3_PP 0
+#endif
+  constexpr bool FUSE_ = (WAVES == 8 && !SLV_X3_PP) || (WAVES != 8 && MT >= 9);
+  constexpr int OCC_ = WAVES == 8 ? (SLV_X3_PP ? 2 : 1) : (FUSE_ ? 2 : 3);
   const size_t dyn = (size_t)((((a.Kd >> 4) + 4) & ~1) * 8) + (act ? (size_t)2 * ((a.Cb + 15) / 16 * 16) * sizeof(float) : 0);
 #define SLV_K3(PRO_, EPI_) \
   hipLaunchKernelGGL((igemm3_kernel<MT, NT, PRO_, EPI_, WAVES, OCC_, FUSE_>), grid, dim3(64 * WAVES), dyn, st, a)
