@@ -342,9 +342,9 @@ int slv_avgpool_cl16(const void* x_bf16, float* y, int64_t N, int64_t S, int C, 
  *
  * slv_cl16_conv: the general launch of the bf16 implicit-GEMM kernel.  clconv: slv_cl16_conv_words() int32 =
  *   {N, Ti, Hi, Wi, Cin_p, Cin, Lt, Lh, Lw, bmt, bmh, bmw, bot, boh, bow, To, Ho, Wo, Cout, Cout_p, omt, omh, omw, oot,
- *    ooh, oow, Mrows, ntaps, tap[64]}: the block enumerates the lattice Lt x Lh x Lw per clip; activation rows are read
+ *    ooh, oow, Mrows, ntaps, tap[64], flags}: the block enumerates the lattice Lt x Lh x Lw per clip; activation rows are read
  *   at lattice*bm + bo + tap offset, the output row is lattice*om + oo; tap = (dt+8) | (dh+8) << 4 | (dw+8) << 8 |
- *   weight slab << 12.  Forward conv: lattice = output, bm = stride, bo = -pad; backward data: one launch per
+ *   weight slab << 12; flags bit 0 = a forward launch (kernel choice only).  Forward conv: lattice = output, bm = stride, bo = -pad; backward data: one launch per
  *   stride-parity class of the input positions (selavi_amd/ops16.py builds the tables).
  *   in_scale_shift [2][Cin] (nullable): rows are read as relu(x*s + h), zero padding after the affine (train-mode
  *     BatchNorm + ReLU of the producing layer applied on load);

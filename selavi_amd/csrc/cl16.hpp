@@ -71,6 +71,7 @@ struct ClConv {
   int Mrows;                         // rows of the weight layout [slab][Cin_p/32][Mrows][32]
   int ntaps;
   int tap[64];                       // (dt + 8) | (dh + 8) << 4 | (dw + 8) << 8 | weight slab << 12
+  int flags;                         // bit 0: a FORWARD launch (the dispatcher's heuristics tell the forward from the backward data)
 };
 constexpr int CLC_WORDS = sizeof(ClConv) / 4;
 

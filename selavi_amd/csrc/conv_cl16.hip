@@ -471,6 +471,7 @@ int slv_conv_cl16_fwd(const int32_t* geom, int mt, const void* x_bf16, const voi
   g.To = To; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.Cout_p = Cout_p;
   g.omt = g.omh = g.omw = 1;
   g.Mrows = Mrows;
+  g.flags = 1;
   for (int a = 0; a < kt; ++a)
     for (int b = 0; b < kh; ++b)
       for (int c = 0; c < kw; ++c) g.tap[g.ntaps] = (a + 8) | (b + 8) << 4 | (c + 8) << 8 | g.ntaps << 12, ++g.ntaps;

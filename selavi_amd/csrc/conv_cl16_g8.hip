@@ -1,28 +1,32 @@
-// 16-bit MFMA path: the WIDE layers (layers 2-4 of R(2+1)D-18, 128..1152 channels: 45 % of the forward's time at 10 % of its
-// bytes) -- forward and backward data of any kernel / stride / padding the lattice description of cl16.hpp expresses, as
-// an implicit GEMM  D[cout][pos] = sum_{tap, c} W[cout][tap][c] * act(X)[pos * stride + tap - pad][c]  whose matrix pipes do
-// not wait for the rest of the kernel.
+// 16-bit MFMA path: the WIDE layers (layers 2-4 of R(2+1)D-18, 128..1152 channels) -- forward and backward data of any
+// kernel / stride / padding the lattice description of cl16.hpp expresses, as an implicit GEMM
+// D[cout][pos] = sum_{tap, c} W[cout][tap][c] * act(X)[pos * stride + tap - pad][c]  in PING-PONG form.
 //
 // What bounded the tile kernels on these layers (csrc/conv_cl16.hip, conv_cl16_s3.hip: 450-950 TFLOP/s of 2 500): a stage
 // is [issue loads | fragment reads | MFMAs | LDS writes | barrier] and the two workgroups of a CU run it in lockstep -- the
 // phases of a stage follow each other, the matrix cores idle through all but one (profiles/r02_notes.md: no single resource
-// binds).  Here ONE workgroup of 8 waves owns the CU and its two halves run the stage half a period apart ("ping-pong"):
+// binds).  Here ONE workgroup of 8 waves owns the CU and its two halves run the stage half a period apart:
 //   * tile = 256 positions x BM = 2 x MTW x 16 output channels (256 or 288 or 128); wave (h, q) owns channel half h and
 //     position quarter q: MTW x 4 accumulator tiles, MTW + 4 fragment reads for 4 MTW MFMAs per 32-channel chunk;
 //   * group G0 = waves 0-3, G1 = waves 4-7: one wave of each group on every SIMD.  A wave alternates two slots,
-//       R(c): request the weights of chunk c + 2 (LDS-DMA: buffer_load_dwordx4 ... lds, inline asm) and the activation pieces
-//             of chunk c + 3 (registers), write the pieces of chunk c + 1 to LDS (BatchNorm + ReLU on the way), read the
-//             fragments of chunk c
-//       M(c): the 4 MTW MFMAs of chunk c back to back (s_setprio 1), nothing else
+//       R(c): write the activation pieces of chunk c + 1 to LDS, read the fragments of chunk c, wait for the requests in flight
+//       M(c): the 4 MTW MFMAs of chunk c back to back (s_setprio 1), every operand already in registers
 //     and every slot ends in s_barrier; G1 runs ONE barrier behind G0, so while G0's waves hold the matrix pipes G1's waves
-//     do everything else, and vice versa: the pipe of a SIMD sees MFMA slots back to back.
+//     do everything else, and vice versa.  The requests of later chunks -- the weights of chunk c + 2 by LDS-DMA
+//     (buffer_load_dwordx4 ... lds, inline asm: 1 KiB per wave instruction), the activation pieces of chunk c + 3 into
+//     registers -- and the BatchNorm + ReLU of the landed pieces sit where the measurements put them per form (below):
+//     between the MFMAs of the M slot or at the end of the R slot behind its vmcnt wait.
 //   * three chunk buffers in LDS ({weights [BM][64 B], activations [256][64 B]}, XOR-swizzled rows as in cl16.hpp: the
 //     swizzle of a DMA'd image sits on the SOURCE address).  Hazards, with slot numbers (G0: R(c) = 2c, M(c) = 2c + 1; G1 one
-//     later): chunk X's activations are written in R(X - 1) (slots 2X - 2 / 2X - 1), its weights are requested in R(X - 2)
-//     (2X - 4 / 2X - 3) and waited for at the start of R(X - 1); both are read from slot 2X on.  The buffer's previous tenant,
-//     chunk X - 3, was last read in slot 2X - 5.  One s_waitcnt vmcnt(0) per R slot, at its START, in front of the slot's own
-//     requests: everything it waits for was requested a whole period earlier.  (LDS-DMA requests and register loads do not complete in order with respect to
-//     each other -- profiles/r04_notes.md -- so the wait is never a counted one.)
+//     later): chunk X's activations are written in R(X - 1) (slots 2X - 2 / 2X - 1), its weights are requested in R(X - 2) or
+//     M(X - 2) (2X - 4 .. 2X - 2) and waited for at the end of R(X - 1); both are read from slot 2X on.  The buffer's previous
+//     tenant, chunk X - 3, was last read in slot 2X - 5.  One s_waitcnt vmcnt(0) per R slot (LDS-DMA requests and register
+//     loads do not complete in order with respect to each other -- profiles/r04_notes.md -- so the wait is never a counted one).
+// Where it stands (profiles/r05_notes.md 4: ablations with tools/g8_ablate.py): the K loop runs at 0.94-0.97 PFLOP/s (the tile
+// kernels: 0.5-0.86) but the epilogue -- 147 KB per workgroup through a transposed LDS tile, nothing on the CU to overlap it
+// -- is a quarter of the launch at K = 1 152 and 40 % at K = 864: the kernel wins where the tile kernel ran (temporal, strided,
+// pointwise convs with >= 256 output rows: layer 3 temporal forward 0.106 -> 0.063 ms at 64 clips) and loses to the patch kernel
+// on the stride-1 spatial convs; cl16_g8_applies() dispatches accordingly.
 // Epilogues: EPI 0 (affine / residual / ReLU -> bf16: eval-mode BatchNorm, backward data + addend) and EPI 1 (raw bf16 +
 // BatchNorm statistics of the rounded tile on the matrix cores), per channel half through a transposed LDS tile, 16-byte
 // stores along the channels.  Reference semantics: torchvision Conv3d / Conv2d forward and backward data as reached from
@@ -35,6 +39,26 @@
 namespace slv {
 
 constexpr int G8_BN = 256, G8_THREADS = 512, G8_NB = 3;
+// Where the non-MFMA work of a chunk goes (tools/g8_ablate.py, profiles/r05_notes.md 4: every placement measured per shape):
+//   weight DMA / activation requests: between the MFMAs of the M slot, or at the END of the R slot behind its vmcnt wait;
+//   BatchNorm + ReLU of the landed pieces (PRO 1): at the LDS-write point in the R slot, or between the MFMAs (VALU in the
+//   matrix pipe's shadow) -- the latter only where an M slot is long enough to cover ~70 VALU instructions (MTW >= 8).
+// -1 = the per-instantiation choice below; 0 / 1 force one (ablation builds).
+#ifndef SLV_G8_DMA_R_END
+#define SLV_G8_DMA_R_END -1
+#endif
+#ifndef SLV_G8_LOADS_R_END
+#define SLV_G8_LOADS_R_END -1
+#endif
+#ifndef SLV_G8_PRO_IN_M
+#define SLV_G8_PRO_IN_M -1
+#endif
+#ifndef SLV_G8_OCC4
+#define SLV_G8_OCC4 1          // the 128-row form (MTW = 4) at two workgroups per CU (128 registers): one's epilogue under the other's loop
+#endif
+#ifndef SLV_G8_ABL
+#define SLV_G8_ABL 0           // timing ablations (wrong results; tools/g8_ablate.sh): 1 no weight DMA, 2 no activation loads, 3 no LDS
+#endif                         // writes, 4 no fragment reads, 5 no MFMAs, 6 no barrier behind the M slot, 7 no vmcnt wait, 8 no epilogue, 9 no K loop, 10 no output stores, 11 no LDS transposition writes, 12 no row-store phase
 
 // one LDS-DMA piece: 64 lanes x 16 bytes, memory (voff + soff) -> LDS at lds_addr + 16 * lane
 __device__ __forceinline__ void g8_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
@@ -48,7 +72,9 @@ __device__ __forceinline__ void g8_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ void g8_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void g8_wait_vm() {
+  if (SLV_G8_ABL != 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 constexpr int g8_orow(int mtw) { return mtw * 32 + 16; }      // bytes per position row of the transposed half tile
 constexpr size_t g8_lds_bytes(int mtw, int cin_p, bool pro) {
@@ -58,7 +84,7 @@ constexpr size_t g8_lds_bytes(int mtw, int cin_p, bool pro) {
 }
 
 template <int MTW, int PRO, int EPI>
-__global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsigned short* __restrict__ x,
+__global__ __launch_bounds__(G8_THREADS, (SLV_G8_OCC4 && MTW == 4) ? 4 : 2) void conv_cl16_g8_kernel(const unsigned short* __restrict__ x,
                                                                       const unsigned short* __restrict__ wl,
                                                                       unsigned short* __restrict__ y,
                                                                       const float* __restrict__ in_ss,
@@ -69,6 +95,13 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
                                                                       FastDiv dLh, FastDiv dLt, FastDiv dGx) {
   constexpr int BMH = MTW * 16, BM = 2 * BMH;
   constexpr int ABYTES = BM * 64, STAGE = ABYTES + G8_BN * 64;
+  // measured best per form (64 clips x 16 frames, ms of the train-mode forward / plain forward): layer 2.1 spatial 0.356 with the
+  // prologue in the M slot and both requests at the end of R (0.396 with the first arrangement), layer 3.1 spatial 0.166 (0.191),
+  // layer 3.1 temporal 0.063 (0.074); plain launches 0.391 -> 0.359 with the DMA at the end of R; the 128-row form keeps the
+  // first arrangement (its M slot is 16 MFMAs: nothing to hide 70 VALU instructions behind: 0.197 vs 0.243)
+  constexpr bool PRO_IN_M = SLV_G8_PRO_IN_M >= 0 ? SLV_G8_PRO_IN_M != 0 : (PRO == 1 && MTW >= 8);
+  constexpr bool DMA_R_END = SLV_G8_DMA_R_END >= 0 ? SLV_G8_DMA_R_END != 0 : (PRO == 0 || MTW >= 8);
+  constexpr bool LOADS_R_END = SLV_G8_LOADS_R_END >= 0 ? SLV_G8_LOADS_R_END != 0 : (PRO == 1 && MTW >= 8);
   constexpr int NDMA = BM / 16;                           // 1 KiB pieces of a chunk's weight image (16 rows each)
   constexpr int OROW = g8_orow(MTW);
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
@@ -146,8 +179,10 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
       const unsigned toff = toffT + (unsigned)(kcL * 64);
       okl = (okl & ~(3u << (S * 2))) | (okT << (S * 2));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        rb[S][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ((okT >> i) & 1u) ? bbase[i] + toff : 0xFFFFFFF0u, 0, 0));
+      for (int i = 0; i < 2; ++i) {
+        if (SLV_G8_ABL == 2) rb[S][i] = (u32x4){toff, bbase[i], 1u, 2u};
+        else rb[S][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ((okT >> i) & 1u) ? bbase[i] + toff : 0xFFFFFFF0u, 0, 0));
+      }
       kcw[S] = kcL;
       ++cL;
       if (++kcL == kcs) {
@@ -164,7 +199,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
 #pragma unroll
       for (int t = 0; t < (NDMA + 7) / 8; ++t) {
         const int i = wave + 8 * t;
-        if (i < NDMA)
+        if (i < NDMA && SLV_G8_ABL != 1)
           g8_dma16(__builtin_amdgcn_readfirstlane(dst + (unsigned)(i * 1024)), voffA, rwl,
                    __builtin_amdgcn_readfirstlane(soff + (unsigned)(i * 1024)));
       }
@@ -180,7 +215,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
     constexpr int S = decltype(set_tag)::value;
     unsigned char* B = lds_raw + buf * STAGE + ABYTES;
     u32x4 v[2] = {rb[S][0], rb[S][1]};
-    if constexpr (PRO == 1) {                                       // the producer's BatchNorm + ReLU, zero padding AFTER it
+    if constexpr (PRO == 1 && !PRO_IN_M) {                   // the producer's BatchNorm + ReLU, zero padding AFTER it
       float s[8], h[8];
       const float* sp = pro + kcw[S] * 32 + piece * 8;
       *(f32x4*)s = *(const f32x4*)sp;
@@ -195,6 +230,24 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) *(u32x4*)(B + (brow + 128 * i) * 64 + bsw) = v[i];
+  };
+
+  // PRO 1, PRO_IN_M: the pieces of set S (landed) -> relu(x s + h) in place, zero where the tap left the tensor
+  auto transform = [&](auto set_tag) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_tag)::value;
+    if constexpr (PRO == 1) {
+      float sc[8], sh[8];
+      const float* sp = pro + kcw[S] * 32 + piece * 8;
+      *(f32x4*)sc = *(const f32x4*)sp;
+      *(f32x4*)(sc + 4) = *(const f32x4*)(sp + 4);
+      *(f32x4*)sh = *(const f32x4*)(sp + g.Cin_p);
+      *(f32x4*)(sh + 4) = *(const f32x4*)(sp + g.Cin_p + 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x4 t = affine_relu8(rb[S][i], sc, sh);
+        rb[S][i] = ((okl >> (S * 2 + i)) & 1u) ? t : (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
   };
 
   f32x4 acc[MTW][4];
@@ -221,34 +274,33 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
     g8_barrier();
   }
   g8_wait_vm();
+  if (PRO_IN_M) {
+    transform(S0);
+    transform(S1);
+  }
   write_b(S0, 0);
   issue_loads(S0);
   fetch_taps();
   g8_barrier();
-  if (grp == 1) g8_barrier();                       // G1 runs one slot behind G0 from here on
+  if (grp == 1 && SLV_G8_ABL != 6) g8_barrier();    // G1 runs one slot behind G0 from here on
 
   int bufR = 0;                                     // buffer of the chunk being multiplied; chunk c + 1 lives in the next one
   auto iter = [&](auto set_tag) __attribute__((always_inline)) {      // set_tag: parity of chunk c + 1 (= of chunk c + 3)
     constexpr int S = decltype(set_tag)::value;
     const int bufW = bufR == G8_NB - 1 ? 0 : bufR + 1;
-    // ---- R(c): everything that is not an MFMA.  FIRST the wait for last slot's requests (a whole period old) and the new
-    // requests -- chunk c + 2's weights (its buffer was last read in R(c - 1)), chunk c + 3's pieces into the set whose
-    // tenant, chunk c + 1, is written to LDS below -- so that every request has a full period to land; an LDS-DMA
-    // instruction costs the issuing wave 60-180 cycles of issue (MI355X_MICROARCH.md): inside the M slot each one idled the
-    // matrix pipe for that long (first version: 740 instead of 860 TFLOP/s on layer 2.1).
+    // ---- R(c): the pieces of chunk c + 1 (requested two chunks ago) go to LDS, the fragments of chunk c come out, then the
+    // wait for everything requested a period ago and -- in the forms that have them here -- the new requests.  (All requests at
+    // the TOP of the slot measured worse, 0.42 against 0.36 ms on layer 2.1: the slot's own work waits behind the DMA issue.)
     const unsigned char* A = lds_raw + bufR * STAGE + (wh * BMH + fr) * 64 + fsw;
     const unsigned char* B = lds_raw + bufR * STAGE + ABYTES + (wq * 64 + fr) * 64 + fsw;
     bf16x8 a[MTW], b[4];
-    g8_wait_vm();
     u32x4 keep[2] = {rb[S][0], rb[S][1]};           // chunk c + 1's pieces leave the request registers
     const unsigned keep_ok = (okl >> (S * 2)) & 3u;
     const int keep_kc = kcw[S];
-    issue_dma();
-    issue_loads(set_tag);
     fetch_taps();
     {
       unsigned char* Bw = lds_raw + bufW * STAGE + ABYTES;
-      if constexpr (PRO == 1) {                                       // the producer's BatchNorm + ReLU, zero padding AFTER it
+      if constexpr (PRO == 1 && !PRO_IN_M) {                   // the producer's BatchNorm + ReLU, zero padding AFTER it
         float sc[8], sh[8];
         const float* sp = pro + keep_kc * 32 + piece * 8;
         *(f32x4*)sc = *(const f32x4*)sp;
@@ -261,33 +313,56 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
           keep[i] = ((keep_ok >> i) & 1u) ? t : (u32x4){0u, 0u, 0u, 0u};
         }
       }
+      if (SLV_G8_ABL != 3) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) *(u32x4*)(Bw + (brow + 128 * i) * 64 + bsw) = keep[i];
+        for (int i = 0; i < 2; ++i) *(u32x4*)(Bw + (brow + 128 * i) * 64 + bsw) = keep[i];
+      } else {
+        asm volatile("" ::"v"(keep[0]), "v"(keep[1]));
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(B + j * 1024);
+    for (int j = 0; j < 4; ++j) b[j] = SLV_G8_ABL == 4 ? __builtin_bit_cast(bf16x8, (u32x4){(unsigned)(size_t)B, (unsigned)j, 1u, 2u}) : *(const bf16x8*)(B + j * 1024);
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) a[i] = *(const bf16x8*)(A + i * 1024);
+    for (int i = 0; i < MTW; ++i) a[i] = SLV_G8_ABL == 4 ? __builtin_bit_cast(bf16x8, (u32x4){(unsigned)(size_t)A, (unsigned)i, 3u, 4u}) : *(const bf16x8*)(A + i * 1024);
+    {
+      g8_wait_vm();                                 // the requests of M(c - 1) / the end of R(c - 1): chunk c + 1's weights, chunk c + 2's pieces
+      if (DMA_R_END) issue_dma();
+      if (LOADS_R_END) issue_loads(set_tag);
+    }
     g8_barrier();
-    // ---- M(c): the MFMAs of chunk c, nothing else
+    // ---- M(c): the MFMAs of chunk c (and whatever of the requests / the prologue this form places between them)
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
+    for (int i = 0; i < MTW; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        if (SLV_G8_ABL == 5) acc[i][j][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, a[i])[0] ^ __builtin_bit_cast(u32x4, b[j])[0]);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (!DMA_R_END && i == 0) issue_dma();                // chunk c + 2's weights (its buffer was last read in R(c - 1))
+      if (!LOADS_R_END && i == 1) issue_loads(set_tag);     // chunk c + 3's pieces (the set R(c) just emptied)
+      if (PRO_IN_M && i == 2) transform(std::integral_constant<int, S ^ 1>{});   // chunk c + 2's pieces (landed: waited for in R(c))
+    }
     __builtin_amdgcn_s_setprio(0);
-    g8_barrier();
+    if (SLV_G8_ABL != 6) g8_barrier();
     bufR = bufW;
   };
-  for (int c = 0; c < nch; c += 2) {
+  for (int c = 0; c < (SLV_G8_ABL == 9 ? 0 : nch); c += 2) {
     iter(S1);
     if (c + 1 < nch) iter(S0);
   }
-  if (grp == 0) g8_barrier();
+  if (grp == 0 && SLV_G8_ABL != 6) g8_barrier();
   g8_wait_vm();
   g8_barrier();
 
+  if (SLV_G8_ABL == 8) {                            // (every accumulator stays alive: an ablation must not delete the MFMAs)
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   // ---- epilogue, one channel half at a time: the half's tiles transposed through LDS ([position][cout] rows), statistics
   // of the rounded tile on the matrix cores (8 waves x 32 rows), 16-byte stores along a position's channels
   unsigned char* ot = lds_raw;                                    // [256][OROW]
@@ -350,7 +425,8 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];      // rows >= Cout: zero weights -> 0
           }
-          *(uint2*)(ot + pl * OROW + (i * 16 + fk * 4) * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+          if (SLV_G8_ABL == 11) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+          else *(uint2*)(ot + pl * OROW + (i * 16 + fk * 4) * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
         }
       }
     }
@@ -373,7 +449,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
     const int c_hi = min(c0 + BMH, g.Cout_p);
     const int c_end = (by == gridDim.y - 1 && hh == 1) ? g.Cout_p : c_hi;
     const int pieces = (c_end - c0) >> 3;                 // 16-byte pieces per position
-    if (pieces > 0) {
+    if (pieces > 0 && SLV_G8_ABL != 12) {
       const int rpp = G8_THREADS / pieces, pl0 = tid / pieces, pc = tid - pl0 * pieces;
       if (pl0 < rpp) {
         const bool cval = c0 + pc * 8 < c_hi;
@@ -385,7 +461,8 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_cl16_g8_kernel(const unsig
           if (op == 0xFFFFFFFFu) continue;
           u32x4 val = {0u, 0u, 0u, 0u};
           if (cval) val = *(const u32x4*)src;
-          *(u32x4*)(yb + op * rowb + coff) = val;
+          if (SLV_G8_ABL == 10) { if (val[0] == 0x12345678u) *(u32x4*)(yb + op * rowb + coff) = val; }
+          else *(u32x4*)(yb + op * rowb + coff) = val;
         }
       }
     }
@@ -423,14 +500,14 @@ bool cl16_g8_applies(const ClConv& g) {
   const long long P = (long long)g.N * g.Lt * g.Lh * g.Lw;
   const long long blocks = ((P + G8_BN - 1) / G8_BN) * (g.Mrows / (32 * mtw));
   if (mode == 1) {
-    // one workgroup per CU: a launch of fewer than ~a round of 256 leaves CUs idle that the 128-position tiles would fill;
-    // narrow contractions (the stems) have nothing for the pipeline to overlap
-    if (blocks < 160 || g.Cin_p * g.ntaps < 256) return false;
-    static const bool over_s3 = []() {
-      const char* e = getenv("SELAVI_CL16_G8_S3");
-      return !(e && e[0] == '0');
-    }();
-    if (!over_s3 && cl16_s3_applies(g)) return false;
+    // What the A/B of the layer shapes says (tools/g8_ab.py, 64 clips x 16 frames and cfg5's 128 x 32; profiles/r05_notes.md 4):
+    // this kernel wins the FORWARD launches the tile kernel (csrc/conv_cl16.hip) had -- temporal, strided and pointwise convs
+    // with >= 256 output rows: layer 3 temporal 0.106 -> 0.063 ms, layer 4.0 spatial 0.136 -> 0.085 -- and loses to the patch
+    // kernel on the stride-1 spatial convs (activations read once for nine taps there), on the 128-row launches and on the
+    // backward data.  One workgroup per CU: a launch of fewer than ~a round of 256 leaves CUs idle that the 128-position
+    // tiles would fill; narrow contractions (the stems) have nothing for the pipeline to overlap.
+    if (!(g.flags & 1) || mtw < 8 || blocks < 160 || g.Cin_p * g.ntaps < 256) return false;
+    if (cl16_s3_applies(g)) return false;
   }
   return true;
 }

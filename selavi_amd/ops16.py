@@ -151,7 +151,7 @@ CL_BUF_LIMIT = int(os.environ.get("SELAVI_CL16_BUF_LIMIT", str(0xFFFFFFF0)))
 _CLC_WORDS = None
 
 
-def _clconv(N, Bdims, Cin_p, Cin, L, bm, bo, Odims, Cout, Cout_p, om, oo, Mrows, taps):
+def _clconv(N, Bdims, Cin_p, Cin, L, bm, bo, Odims, Cout, Cout_p, om, oo, Mrows, taps, forward=False):
     """int32 image of csrc/conv_cl16.hip:ClConv.  taps: [(dt, dh, dw, slab)]."""
     global _CLC_WORDS
     if _CLC_WORDS is None:
@@ -161,6 +161,7 @@ def _clconv(N, Bdims, Cin_p, Cin, L, bm, bo, Odims, Cout, Cout_p, om, oo, Mrows,
     g[:28] = [N, *Bdims, Cin_p, Cin, *L, *bm, *bo, *Odims, Cout, Cout_p, *om, *oo, Mrows, len(taps)]
     for i, (dt, dh, dw, slab) in enumerate(taps):
         g[28 + i] = (dt + 8) | (dh + 8) << 4 | (dw + 8) << 8 | slab << 12
+    g[28 + 64] = 1 if forward else 0          # flags: bit 0 = forward launch (the library's kernel choice)
     return g
 
 
@@ -230,7 +231,7 @@ class Plan16:
         # ---- forward
         taps = [(a, b, c, (a * kh + b) * kw + c) for a in range(kt) for b in range(kh) for c in range(kw)]
         self.g_fwd = _clconv(N, (Ti, Hi, Wi), self.Cin_p, self.Cin, (To, Ho, Wo), stride, (-pt, -ph, -pw), (To, Ho, Wo),
-                             Cout, self.Cout_p, (1, 1, 1), (0, 0, 0), self.mrows_f, taps)
+                             Cout, self.Cout_p, (1, 1, 1), (0, 0, 0), self.mrows_f, taps, forward=True)
         self.nblk = C.slv_cl16_conv_nblk(self.g_fwd.ctypes.data)
         # ---- backward data: per dimension, class c of the input coordinate and its taps (offset, j)
         def classes(X, kk, s, p):
