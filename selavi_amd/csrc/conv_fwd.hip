@@ -76,11 +76,9 @@ struct SplitDesc {
 struct SplitArgs {
   SplitDesc d[9];              // the forward image + up to 8 stride-parity classes of the backward data: ONE launch per layer
 };
-__global__ __launch_bounds__(256) void w_split_kernel(const float* __restrict__ w, unsigned* __restrict__ wf_img,
-                                                      unsigned* __restrict__ wt_img, const SplitArgs args, int Cin, int taps_all) {
-  const SplitDesc& d = args.d[blockIdx.y];
+__device__ __forceinline__ void w_split_body(const float* __restrict__ w, unsigned* __restrict__ img, const SplitDesc& d, int Cin,
+                                             int taps_all) {
   const int M = d.M, Cg = d.Cg, Kd = d.Kd, ntaps = d.ntaps, transposed = d.transposed;
-  unsigned* img = (transposed ? wt_img : wf_img) + d.off;
   const int Mp = (M + 15) / 16 * 16, nch = (Kd + 31) / 32;
   const size_t total = (size_t)nch * Mp * 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -110,6 +108,25 @@ __global__ __launch_bounds__(256) void w_split_kernel(const float* __restrict__ 
       img[base + (size_t)Mp * 32 + e] = (l[2 * e] >> 16) | (l[2 * e + 1] & 0xffff0000u);
     }
   }
+}
+__global__ __launch_bounds__(256) void w_split_kernel(const float* __restrict__ w, unsigned* __restrict__ wf_img,
+                                                      unsigned* __restrict__ wt_img, const SplitArgs args, int Cin, int taps_all) {
+  const SplitDesc& d = args.d[blockIdx.y];
+  w_split_body(w, (d.transposed ? wt_img : wf_img) + d.off, d, Cin, taps_all);
+}
+// The weight images of MANY layers in one launch (slv_conv_w_transform_jobs): a job = one image (a layer's forward image or
+// one stride-parity class of its backward data); the table lives in device memory, built once per model and input shape
+// (pointers to the parameters and to the persistent image buffers are stable), blockIdx.y = job.  ~70 launches of a
+// training step become 2 (one per trunk).
+struct SplitJob {
+  const float* w;
+  unsigned* img;              // the image's first dword (offset inside the layer's buffer already added)
+  int Cin, taps_all;
+  SplitDesc d;
+};
+__global__ __launch_bounds__(256) void w_split_jobs_kernel(const SplitJob* __restrict__ jobs) {
+  const SplitJob& j = jobs[blockIdx.y];
+  w_split_body(j.w, j.img, j.d, j.Cin, j.taps_all);
 }
 static bool split_desc(SplitDesc& o, const Desc& d, size_t off_floats, int transposed) {
   if (d.ntaps == 0 || d.Kd == 0 || d.ntaps > 27) return false;      // a parity class no tap reaches: no weights, no K steps
@@ -384,6 +401,50 @@ int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf, float* 
   const size_t nel = (size_t)g.Cout * g.Cin * taps;
   hipLaunchKernelGGL(w_transform_kernel, dim3((unsigned)((nel + 255) / 256 < 4096 ? (nel + 255) / 256 : 4096)),
                      dim3(256), 0, st, w, wf, wt, g.Cout, g.Cin, taps, tm, df.Cp, cp_out);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- batched weight images: see SplitJob.  slv_conv_w_jobs writes the jobs of ONE layer (host memory, slv_conv_w_job_words()
+// int32 words each; returns their number, 0 when the layer does not use split-operand images: the caller keeps
+// slv_conv_w_transform for it); the caller concatenates the jobs of its layers, copies the table to the device once and
+// launches slv_conv_w_transform_jobs every step.
+int32_t slv_conv_w_job_words(void) { return (int32_t)(sizeof(SplitJob) / 4); }
+
+int32_t slv_conv_w_jobs(const int32_t* geom, const float* w, float* wf, float* wt, int32_t* out, int32_t max_jobs) {
+  Geom g;
+  if (read_geom(geom, g) != 0 || !w || !out || max_jobs < 9) return -1;
+  const Desc df = fwd_desc(g);
+  Desc ds[8];
+  const int n = dgrad_descs(g, ds);
+  if (!(wf && df.x3) && !(wt && n > 0 && ds[0].x3)) return 0;
+  if ((wf && df.kord == KORD_TAP && !df.x3) || (wt && n > 0 && !ds[0].x3)) return 0;      // mixed layouts: the per-layer entry point
+  SplitJob* jobs = (SplitJob*)out;
+  int nj = 0;
+  const int taps_all = g.kt * g.kh * g.kw;
+  if (wf && df.x3) {
+    if (df.ntaps > 27) return -1;
+    SplitJob j;
+    memset(&j, 0, sizeof(j));
+    if (split_desc(j.d, df, 0, 0)) { j.w = w; j.img = (unsigned*)wf; j.Cin = g.Cin; j.taps_all = taps_all; j.d.off = 0; jobs[nj++] = j; }
+  }
+  if (wt && n > 0 && ds[0].x3)
+    for (int i = 0; i < n; ++i) {
+      if (ds[i].ntaps > 27) return -1;
+      SplitJob j;
+      memset(&j, 0, sizeof(j));
+      if (split_desc(j.d, ds[i], ds[i].wt_off, 1)) {
+        j.w = w; j.img = (unsigned*)wt + ds[i].wt_off; j.Cin = g.Cin; j.taps_all = taps_all; j.d.off = 0;
+        jobs[nj++] = j;
+      }
+    }
+  return nj;
+}
+
+int slv_conv_w_transform_jobs(const int32_t* jobs_dev, int32_t njobs, int32_t blocks_per_job, slv_stream_t stream) {
+  SLV_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535 && blocks_per_job > 0 && blocks_per_job <= 1024, "bad argument");
+  hipLaunchKernelGGL(w_split_jobs_kernel, dim3((unsigned)blocks_per_job, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream,
+                     (const SplitJob*)jobs_dev);
   SLV_LAUNCH_CHECK();
   return 0;
 }

@@ -48,6 +48,44 @@ __global__ __launch_bounds__(256) void cl16_w_transform_kernel(const float* __re
   }
 }
 
+// The same for MANY layers in one launch (slv_cl16_w_transform_jobs): a job = the arguments of one layer's launch, the table in
+// device memory (built once per model and input shape by selavi_amd/ops16.py: parameter and layout buffers are persistent),
+// blockIdx.y = job, grid-stride over the job's elements.
+struct ClWJob {
+  const float* w;
+  unsigned short* wf;
+  unsigned short* wt;
+  int Cout, Cin, taps, Cin_p, Cout_p, MrowsF, MrowsD, patch_kw;
+  unsigned nf, nt;
+};
+static_assert(sizeof(ClWJob) == 64, "16 int32 words: mirrored by selavi_amd/ops16.py");
+__global__ __launch_bounds__(256) void cl16_w_transform_jobs_kernel(const ClWJob* __restrict__ jobs) {
+  const ClWJob j = jobs[blockIdx.y];
+  const unsigned total = j.nf + j.nt;
+  for (unsigned idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    if (idx < j.nf) {
+      const unsigned jj = idx & 31, m = (idx >> 5) % j.MrowsF, r = (idx >> 5) / j.MrowsF;
+      float v = 0.f;
+      if (j.patch_kw > 0) {
+        const unsigned a = r;
+        const unsigned dw = jj / j.Cin, c = jj - dw * j.Cin;
+        if (m < (unsigned)j.Cout && dw < (unsigned)j.patch_kw) v = j.w[((size_t)(m * j.Cin + c) * j.taps + a) * j.patch_kw + dw];
+      } else {
+        const unsigned kcs = j.Cin_p >> 5, kc = r % kcs, tap = r / kcs, c = kc * 32 + jj;
+        if (m < (unsigned)j.Cout && c < (unsigned)j.Cin) v = j.w[((size_t)m * j.Cin + c) * j.taps + tap];
+      }
+      j.wf[idx] = f2bf(v);
+    } else {
+      const unsigned i2 = idx - j.nf;
+      const unsigned jj = i2 & 31, m = (i2 >> 5) % j.MrowsD, r = (i2 >> 5) / j.MrowsD;
+      const unsigned kcs = j.Cout_p >> 5, kc = r % kcs, tap = r / kcs, co = kc * 32 + jj;
+      float v = 0.f;
+      if (co < (unsigned)j.Cout && m < (unsigned)j.Cin) v = j.w[((size_t)co * j.Cin + m) * j.taps + tap];
+      j.wt[i2] = f2bf(v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ weight gradient
 struct ClWgrad {                      // int32 x CLW_WORDS, mirrored by selavi_amd/ops16.py
   int N;
@@ -590,6 +628,15 @@ int slv_cl16_w_transform(const float* w, void* wf_bf16, void* wt_bf16, int Cout,
   hipLaunchKernelGGL(cl16_w_transform_kernel, dim3((unsigned)((nf + nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                      (unsigned short*)wf_bf16, (unsigned short*)wt_bf16, Cout, Cin, taps, Cin_p, Cout_p, mrows_fwd,
                      mrows_dgrad, patch_kw, (unsigned)nf, (unsigned)nt);
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
+int slv_cl16_w_transform_jobs(const int32_t* jobs_dev, int32_t njobs, int32_t blocks_per_job, slv_stream_t stream) {
+  using namespace slv;
+  SLV_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535 && blocks_per_job > 0 && blocks_per_job <= 4096, "bad argument");
+  hipLaunchKernelGGL(cl16_w_transform_jobs_kernel, dim3((unsigned)blocks_per_job, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream,
+                     (const ClWJob*)jobs_dev);
   SLV_LAUNCH_CHECK();
   return 0;
 }

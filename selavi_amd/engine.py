@@ -59,6 +59,7 @@ class Ctx:
         self.sync = sync            # (process_group, world_size) for SyncBN or None
         self.grads = {}             # id(param) -> grad tensor
         self.grad_out = None        # id(param) -> preallocated gradient view (parallel.GradSink), or None
+        self.wimg = None            # ops.WeightImages of this trunk pass (all weight re-layouts in one launch), if any
         self.side = None            # HIP stream carrying this pass' weight-gradient launches, if any
         self.wgrad_side = WGRAD_SIDE_STREAM      # (off for a trunk that itself runs on a side stream: nn.TrunkFunction)
 
@@ -83,7 +84,14 @@ def conv_bn(ctx, x, conv, bn, need_dx=True, defer=False):
     plan = ctx.ops.plan_for(xin, conv)
     # one pass over the weights makes the forward (tap-major) and backward-data layouts of this step
     # (issuing these small kernels on the side stream was measured: no gain)
-    wf, wt = ctx.ops.conv_w_transform(plan, conv.weight, need_wt=ctx.training and need_dx)
+    need_wt = ctx.training and need_dx
+    got = ctx.wimg.get(plan, conv.weight, need_wt) if (ctx.wimg is not None and ctx.wimg.ready) else None
+    if got is not None:
+        wf, wt = got                                  # made by the trunk's one launch (ops.WeightImages.run)
+    else:
+        wf, wt = ctx.ops.conv_w_transform(plan, conv.weight, need_wt=need_wt)
+        if ctx.wimg is not None and not ctx.wimg.ready:
+            ctx.wimg.note(plan, conv.weight, need_wt)
     patch = None
     if getattr(plan, "stem", False):      # (1.64 GB at 128 clips x 32 frames; making it twice cost 0.95 ms of the step)
         patch = ctx.ops.stem_patch(plan, xin)

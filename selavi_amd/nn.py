@@ -237,6 +237,34 @@ def _take_fork_event(trunk, dfeat):
     return ev
 
 
+def _weight_images(trunk, x, training, first, last_done=False):
+    """ops.WeightImages of this trunk for this input shape and mode (fp32 backend only): created at the first stage of a
+    pass (``first``: the images are made there, one launch), handed to the later stages of the same pass, built from what the
+    first pass recorded once its last stage is through (``last_done``)."""
+    from . import ops as _o
+    be = _backend(trunk)
+    if not _o.BATCH_W_IMAGES or not x.is_cuda:
+        return None
+    if last_done:
+        w = trunk.__dict__.get("_wimg_cur")
+        if w is not None and not w.ready:
+            w.build(x.device)
+        return w
+    if first:
+        cache = trunk.__dict__.setdefault("_wimg_cache", {})
+        key = (tuple(x.shape), bool(training), be.__name__, _o.conv_arithmetic(), _o.benchmark)
+        w = cache.get(key)
+        if w is None:
+            if len(cache) >= 8:
+                cache.clear()
+            w = cache[key] = be.WeightImages()
+        trunk.__dict__["_wimg_cur"] = w
+        if w.ready:
+            w.run()
+        return w
+    return trunk.__dict__.get("_wimg_cur")
+
+
 class TrunkFunction(torch.autograd.Function):
     """One autograd node per trunk: forward = engine schedule, backward = hand-written schedule.
 
@@ -260,14 +288,18 @@ class TrunkFunction(torch.autograd.Function):
             main = torch.cuda.current_stream(x.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                ectx.wimg = _weight_images(trunk, x, training, first=True)
                 feat, saved = fwd(ectx, trunk, x)
+                _weight_images(trunk, x, training, first=False, last_done=True)
             x.record_stream(side)
             feat.record_stream(main)
             # the join the consumer of ``feat`` owes: model.forward waits for it in front of the heads (a caller that sets
             # ``side_stream`` itself must do the same; model.forward resets the attribute when it returns)
             trunk._join_event = side.record_event()
         else:
+            ectx.wimg = _weight_images(trunk, x, training, first=True)
             feat, saved = fwd(ectx, trunk, x)
+            _weight_images(trunk, x, training, first=False, last_done=True)
         fctx.need, fctx.side = need_grad, side
         if need_grad:
             fctx.saved_rec, fctx.trunk, fctx.kind, fctx.sync, fctx.ops = saved, trunk, kind, ectx.sync, ectx.ops
@@ -326,7 +358,10 @@ class VideoStageFunction(torch.autograd.Function):
         training = trunk.training
         need_grad = training and any(fctx.needs_input_grad)
         ectx = engine.Ctx(training, sync=_sync_of(trunk) if training else None, ops=_backend(trunk))
+        ectx.wimg = _weight_images(trunk, x, training, first=(stage == "stem"))
         out, saved = engine.video_stage_forward(ectx, trunk, stage, x)
+        if stage == "layer4":
+            _weight_images(trunk, x, training, first=False, last_done=True)
         fctx.need = need_grad
         if need_grad:
             fctx.saved_rec, fctx.trunk, fctx.stage, fctx.sync, fctx.ops = saved, trunk, stage, ectx.sync, ectx.ops

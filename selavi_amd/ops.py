@@ -311,6 +311,67 @@ def conv_wt_transform(plan, w):
     return conv_w_transform(plan, w, need_wf=False)[1]
 
 
+BATCH_W_IMAGES = os.environ.get("SELAVI_BATCH_W_IMAGES", "1") == "1"
+
+
+class WeightImages:
+    """The per-step weight re-layouts of a whole trunk in ONE launch (slv_conv_w_transform_jobs) instead of one per conv layer
+    (~70 launches of the fp32 step).  Life cycle, per (trunk, input shape, mode): the first pass runs the per-layer entry
+    point and RECORDS (plan, weight, need_wt) of every conv it meets (``note``); ``build`` then allocates persistent image
+    buffers, asks the library for the job descriptors (slv_conv_w_jobs) and copies the table to the device once; from the
+    next pass on ``run`` makes every image with one launch at the head of the trunk and ``get`` hands them out.  Layers
+    without split-operand images (the 3 / 1-channel stems, the native arithmetic) stay on the per-layer path.
+    The images are rewritten by every pass that calls ``run`` (weights change at every optimizer step); a backward pass
+    reads the backward-data images its own forward made."""
+
+    def __init__(self):
+        self.rec, self.seen = [], set()
+        self.ent = None                   # id(weight) -> (plan, wf, wt)
+        self.table, self.njobs, self.blocks = None, 0, 0
+
+    def note(self, plan, w, need_wt):
+        if id(w) not in self.seen and plan.chunks is None:
+            self.seen.add(id(w))
+            self.rec.append((plan, w, need_wt))
+
+    def build(self, device):
+        words = C.slv_conv_w_job_words()
+        jobs, ent = [], {}
+        for plan, w, need_wt in self.rec:
+            wf = _f32(plan.wf_elems, device=device) if plan.wf_elems else None
+            wt = _f32(plan.wt_elems, device=device) if need_wt else None
+            if wf is None and wt is None:
+                continue
+            buf = np.zeros(9 * words, dtype=np.int32)
+            n = C.slv_conv_w_jobs(plan.gp, ptr(w), ptr(wf), ptr(wt), buf.ctypes.data, 9)
+            if n <= 0:
+                continue                  # (this layer keeps slv_conv_w_transform)
+            jobs.append(buf[:n * words])
+            ent[id(w)] = (plan, wf, wt, w)
+        self.rec = None
+        self.ent = ent
+        if jobs:
+            tab = np.concatenate(jobs)
+            self.table = torch.from_numpy(tab).to(device)
+            self.njobs = tab.size // words
+            self.blocks = 48              # grid-stride per job: the largest image (layer 4: 21 MB) is 48 x 256 x ~450 slots
+        return self
+
+    @property
+    def ready(self):
+        return self.ent is not None
+
+    def run(self):
+        if self.table is not None:
+            C.slv_conv_w_transform_jobs(ptr(self.table), self.njobs, self.blocks, stream())
+
+    def get(self, plan, w, need_wt):
+        e = self.ent.get(id(w)) if self.ent is not None else None
+        if e is None or e[0] is not plan or e[3] is not w or (need_wt and e[2] is None):
+            return None
+        return e[1], (e[2] if need_wt else None)
+
+
 def conv_dgrad(plan, dy, wt, x_out=None, bwd5=None, relu=False, addend=None, out=None, bnr=None):
     """dx = conv_transpose(dy) (+ addend).  bnr = (x, scale_shift, mean_invstd) of the layer that produced
     this conv's input: the kernel epilogue then also emits that BatchNorm's backward partial sums and

@@ -308,6 +308,57 @@ def conv_wt_transform(plan, w):
     return conv_w_transform(plan, w, need_wf=False)[1]
 
 
+class WeightImages:
+    """ops.WeightImages for this backend: the bf16 weight layouts of a whole trunk in ONE launch
+    (slv_cl16_w_transform_jobs) instead of one per conv layer."""
+
+    def __init__(self):
+        self.rec, self.seen = [], set()
+        self.ent = None
+        self.table, self.njobs, self.blocks = None, 0, 0
+
+    def note(self, plan, w, need_wt):
+        if id(w) not in self.seen:
+            self.seen.add(id(w))
+            self.rec.append((plan, w, need_wt))
+
+    def build(self, device):
+        jobs, ent = [], {}
+        for plan, w, need_wt in self.rec:
+            need_wt = need_wt and not plan.stem
+            wf = _bf16(plan.wf_elems, device=device)
+            wt = _bf16(plan.wt_elems, device=device) if need_wt else None
+            job = np.zeros(16, dtype=np.int32)
+            job[0:6] = np.array([ptr(w), ptr(wf), ptr(wt)], dtype=np.uint64).view(np.int32)
+            job[6:14] = [plan.Cout, plan.Cin_w, plan.w_shape_taps if not plan.stem else plan.taps, plan.Cin_p, plan.Cout_p,
+                         plan.mrows_f, plan.mrows_d, plan.patch_kw]
+            job[14:16] = np.array([wf.numel(), wt.numel() if wt is not None else 0], dtype=np.uint32).view(np.int32)
+            jobs.append(job)
+            ent[id(w)] = (plan, wf, wt, w)
+        self.rec = None
+        self.ent = ent
+        if jobs:
+            self.table = torch.from_numpy(np.concatenate(jobs)).to(device)
+            self.njobs = len(jobs)
+            self.blocks = 96
+        return self
+
+    @property
+    def ready(self):
+        return self.ent is not None
+
+    def run(self):
+        if self.table is not None:
+            C.slv_cl16_w_transform_jobs(ptr(self.table), self.njobs, self.blocks, stream())
+
+    def get(self, plan, w, need_wt):
+        e = self.ent.get(id(w)) if self.ent is not None else None
+        need_wt = need_wt and not plan.stem
+        if e is None or e[0] is not plan or e[3] is not w or (need_wt and e[2] is None):
+            return None
+        return e[1], (e[2] if need_wt else None)
+
+
 def stem_patch(plan, x):
     """The W-patch image of the fp32 clip / spectrogram a stem conv reads (made once per step: the forward and the weight
     gradient both take it through ``patch=``)."""

@@ -190,6 +190,14 @@ class DataParallel(torch.nn.Module):
         self._last_batch = b
 
     def forward(self, *args, **kwargs):
-        if args and hasattr(args[0], "shape"):
+        # (under HIP-graph capture -- train.GraphedStep -- the check is issued by replay(): it reads a result on the host)
+        if args and hasattr(args[0], "shape") and not torch.cuda.is_current_stream_capturing():
             self.check_equal_batches(int(args[0].shape[0]), args[0].device)
         return self.module(*args, **kwargs)
+
+    def capturable(self):
+        """Can a step through this wrapper be captured into a HIP graph?  Only when EVERY exchange of the step is a library
+        call on a HIP stream (comm.NativeComm: the RCCL launches are captured like any kernel); torch.distributed's
+        collectives (gloo, or the fall-back after a failed preflight) are host-driven."""
+        from .comm import NativeComm
+        return self.sink.native is not None and NativeComm._disabled is None

@@ -79,12 +79,22 @@ class GraphedStep:
     is capturable as is (no allocation, synchronisation or host copy inside libselavi_hip.so; pointer tables travel in
     kernel arguments; the trunk / weight-gradient side streams fork from and join the capturing stream with events).
     Inputs are static buffers: copy the next batch into ``video / audio / selected`` (and update ``selflabels`` in
-    place) before ``replay()``.  Single process only (collectives are not captured); BatchNorm's
-    ``num_batches_tracked`` advances per replay."""
+    place) before ``replay()``.  BatchNorm's ``num_batches_tracked`` advances per replay.
+    Data parallel: ``model`` may be a ``parallel.DataParallel`` whose exchanges run on the library's own RCCL communicators
+    (comm.NativeComm: SyncBN = slv_bn_sync_finalize on the compute streams, the gradient buckets = slv_comm_allreduce_f32 on
+    their own stream, forked from and joined to the capturing stream with events) -- the collectives are graph nodes like
+    the kernels around them, every rank replays the same graph.  The per-step equal-batch check (a host read) moves from
+    ``forward`` to ``replay()``.  A wrapper on torch.distributed collectives (gloo, torch DDP) is refused."""
 
     def __init__(self, model, optimizer, video, audio, selflabels, selected, headcount, warmup=3):
         import torch
         self.model, self.video, self.audio, self.selflabels, self.selected = model, video, audio, selflabels, selected
+        self._dp = model if hasattr(model, "check_equal_batches") else None
+        if self._dp is not None and not self._dp.capturable():
+            raise RuntimeError("train.GraphedStep: this DataParallel's exchanges go through torch.distributed (host-driven): "
+                               "only the library's RCCL communicators (backend nccl / SELAVI_NATIVE_COMM) can be captured")
+        if self._dp is None and type(model).__name__ == "DistributedDataParallel":
+            raise RuntimeError("train.GraphedStep: torch DDP's bucket hooks are not capturable; use train.data_parallel(kind='native')")
         self._bns = [m for m in model.modules() if hasattr(m, "note_batch")]
         # (the audio trunk keeps its own stream under capture: its node forks and joins with events, nn.TrunkFunction)
         side = torch.cuda.Stream()
@@ -105,6 +115,8 @@ class GraphedStep:
             b._pending -= 1
 
     def replay(self):
+        if self._dp is not None:
+            self._dp.check_equal_batches(int(self.video.shape[0]), self.video.device)
         self.graph.replay()
         for b in self._bns:
             b.note_batch()

@@ -448,3 +448,84 @@ def test_native_rccl_communicator_world1():
     ret = mp.Manager().dict()
     mp.spawn(_native_comm_worker, args=(29810 + os.getpid() % 80, ret), nprocs=1, join=True)
     assert ret.get("ok") and "rccl" in ret["lib"]
+
+
+def _graphed_dp_worker(rank, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from selavi_amd import model as smodel, optim, train
+        from selavi_amd.comm import NativeComm
+        hc, K = 2, 7
+        video = portable_fill_(torch.empty(4, 3, 4, 32, 32), 5).cuda()
+        audio = portable_fill_(torch.empty(4, 1, 40, 36), 6).cuda()
+        sl = torch.from_numpy((np.arange(64 * hc).reshape(64, hc) * 7919 % K).astype(np.int64)).cuda()
+        sel = torch.tensor([3, 17, 42, 63]).cuda()
+
+        def make():
+            m = smodel.load_model(use_mlp=True, num_classes=K, norm_feat=False, headcount=hc)
+            portable_init_(m, seed=31)
+            step_ref.set_dropout_p(m, 0.0)
+            m = m.cuda().train()
+            net = train.data_parallel(m, [0], kind="native")
+            return m, net, optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+        m0, n0, o0 = make()
+        for _ in range(5):
+            l0 = train.train_step(n0, o0, video, audio, sl, sel, hc)
+        m1, n1, o1 = make()
+        assert n1.capturable() and len(NativeComm._cache) >= 3          # bn, bn_audio, grad: RCCL behind the C ABI
+        gs = train.GraphedStep(n1, o1, video, audio, sl, sel, hc, warmup=3)
+        for _ in range(2):
+            l1 = gs.replay()
+        torch.cuda.synchronize()
+        same = all(torch.equal(a, b) for a, b in zip(m0.state_dict().values(), m1.state_dict().values()))
+        ret["out"] = (float(l0), float(l1), same, int(m1.state_dict()["video_network.base.stem.1.num_batches_tracked"]))
+        NativeComm.destroy_all()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_graphed_step_under_native_data_parallel_captures_the_rccl_collectives():
+    """train.GraphedStep around parallel.DataParallel on REAL RCCL (a world of one rank: the boxes have one GPU and RCCL
+    refuses two ranks per device): the 88 SyncBN exchanges (slv_bn_sync_finalize on the main and the audio stream) and the 7
+    gradient-bucket all-reduces (slv_comm_allreduce_f32 on the buckets' stream) are captured as graph nodes between the
+    kernels; two replays leave bit for bit the weights, buffers and loss of five eager data-parallel steps (3 warm-up + 2)."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_graphed_dp_worker, args=(29900 + os.getpid() % 90, ret), nprocs=1, join=True)
+    l0, l1, same, nbt = ret["out"]
+    assert l0 == l1 and same and nbt == 5, ret["out"]
+
+
+def test_graphed_step_refuses_host_driven_collectives():
+    """... and over torch.distributed (gloo here) the capture is refused up front, not left to fail inside the graph."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_graphed_refuse_worker, args=(29800 + os.getpid() % 90, ret), nprocs=1, join=True)
+    assert "torch.distributed" in ret["err"]
+
+
+def _graphed_refuse_worker(rank, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["SELAVI_NATIVE_COMM"] = "0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from selavi_amd import model as smodel, optim, train
+        m = smodel.load_model(use_mlp=True, num_classes=7, norm_feat=False, headcount=2).cuda().train()
+        net = train.data_parallel(m, [0], kind="native")
+        opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+        video = torch.randn(2, 3, 4, 32, 32).cuda()
+        audio = torch.randn(2, 1, 40, 36).cuda()
+        sl = torch.zeros(64, 2, dtype=torch.int64).cuda()
+        sel = torch.tensor([3, 17]).cuda()
+        try:
+            train.GraphedStep(net, opt, video, audio, sl, sel, 2)
+            ret["err"] = "no error"
+        except RuntimeError as e:
+            ret["err"] = str(e)
+    finally:
+        dist.destroy_process_group()

@@ -771,3 +771,38 @@ def test_gradients_against_the_fp64_oracle_on_a_well_conditioned_network():
     assert not badp, badp[:8]
     assert np.median(rel) <= 1e-5 and np.median(np.abs(proj - 1)) <= 1e-6, (np.median(rel), np.median(np.abs(proj - 1)))
     assert dd.max() <= max(1e-4, 3 * dd32.max()), (dd, dd32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_batched_weight_images_leave_the_step_bit_identical(monkeypatch, precision):
+    """ops.WeightImages: from the second pass on every split-operand weight image of a trunk is made by ONE launch at the head
+    of the trunk (slv_conv_w_transform_jobs) instead of one launch per conv layer -- same kernels' arithmetic, same images:
+    four training steps and an eval pass with the batching on and off end in bit-identical weights, buffers and features."""
+    from selavi_amd import ops, optim, train
+
+    def run(flag):
+        monkeypatch.setattr(ops, "BATCH_W_IMAGES", flag)
+        m = _build(2, 12, True).train()
+        m.set_precision(precision)
+        opt = optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-5)
+        video = portable_fill_(torch.empty(4, 3, 4, 32, 32), 5).cuda()
+        audio = portable_fill_(torch.empty(4, 1, 40, 36), 6).cuda()
+        sl = torch.from_numpy((np.arange(64 * 2).reshape(64, 2) * 7919 % 12).astype(np.int64)).cuda()
+        sel = torch.tensor([3, 17, 42, 63]).cuda()
+        losses = [float(train.train_step(m, opt, video, audio, sl, sel, 2)) for _ in range(4)]
+        m.eval()
+        m.return_features = True
+        with torch.no_grad():
+            f1 = m(video, audio)
+            f2 = m(video, audio)            # (the second eval pass runs on the batched images)
+        assert torch.equal(f1[0], f2[0]) and torch.equal(f1[1], f2[1])
+        w = m.video_network.base.__dict__.get("_wimg_cur")
+        return losses, {k: v.clone() for k, v in m.state_dict().items()}, f2, w
+    l1, s1, f1, w1 = run(True)
+    l0, s0, f0, w0 = run(False)
+    assert w0 is None and w1 is not None and w1.ready and w1.njobs >= 20, (w1 and w1.njobs)
+    assert l0 == l1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    assert torch.equal(f0[0], f1[0]) and torch.equal(f0[1], f1[1])
