@@ -165,9 +165,10 @@ size_t slv_conv_wt_elems(const int32_t* geom);
 int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf /* nullable */, float* wt /* nullable */,
                          slv_stream_t stream);
 /* The split-operand weight images of MANY layers in one launch.  slv_conv_w_jobs writes the job descriptors of one layer
- * (host memory: slv_conv_w_job_words() int32 each, at most 9; w / wf / wt as slv_conv_w_transform -- they must stay where they
- * are for the table's lifetime) and returns their number; 0 = this layer does not use split-operand images (stems, native
- * arithmetic): keep slv_conv_w_transform for it.  The caller concatenates the jobs of its layers into ONE device buffer (once)
+ * (host memory: slv_conv_w_job_words() int32 each -- an image is cut into jobs of 16 384 slots, so a layer-4 conv has ~80 --; w / wf /
+ * wt as slv_conv_w_transform: they must stay where they are for the table's lifetime) and returns their number (-1: max_jobs
+ * too small or a bad argument); 0 = this layer does not use split-operand images (stems, native arithmetic): keep
+ * slv_conv_w_transform for it.  blocks_per_job = 0: the library's choice.  The caller concatenates the jobs of its layers into ONE device buffer (once)
  * and calls slv_conv_w_transform_jobs on it every step. */
 int32_t slv_conv_w_job_words(void);
 int32_t slv_conv_w_jobs(const int32_t* geom, const float* w, float* wf, float* wt, int32_t* out_jobs, int32_t max_jobs);
@@ -395,9 +396,11 @@ int slv_cl16_conv_dgrad_bn_apply(const int32_t* clconv, const void* dy_bf16, con
                                  const void* src_x_bf16, const float* bwd5, slv_stream_t stream);
 int slv_cl16_w_transform(const float* w, void* wf_bf16, void* wt_bf16, int Cout, int Cin, int taps, int Cin_p,
                          int Cout_p, int mrows_fwd, int mrows_dgrad, int patch_kw, slv_stream_t stream);
-/* slv_cl16_w_transform for MANY layers in one launch: jobs_dev = njobs x 16 int32 in device memory, one job =
+/* slv_cl16_w_transform for MANY layers in one launch: jobs_dev = njobs x 18 int32 in device memory, one job =
  * {w, wf, wt (three 64-bit pointers, wf / wt nullable), Cout, Cin, taps, Cin_p, Cout_p, mrows_fwd, mrows_dgrad, patch_kw,
- * nf, nt} with nf / nt = the element counts of the two layouts (0 for a null one) -- the arguments of slv_cl16_w_transform. */
+ * nf, nt, first, count} with nf / nt = the element counts of the two layouts (0 for a null one) -- the arguments of
+ * slv_cl16_w_transform -- and [first, first + count) the elements of the nf + nt this job makes (equal jobs: the caller cuts
+ * a large layer into several). */
 int slv_cl16_w_transform_jobs(const int32_t* jobs_dev, int32_t njobs, int32_t blocks_per_job, slv_stream_t stream);
 int32_t slv_cl16_wgrad_words(void);
 size_t slv_cl16_wgrad_ws_bytes(const int32_t* clw, int wm, int wn);

@@ -77,11 +77,12 @@ struct SplitArgs {
   SplitDesc d[9];              // the forward image + up to 8 stride-parity classes of the backward data: ONE launch per layer
 };
 __device__ __forceinline__ void w_split_body(const float* __restrict__ w, unsigned* __restrict__ img, const SplitDesc& d, int Cin,
-                                             int taps_all) {
+                                             int taps_all, size_t first = 0, size_t count = ~(size_t)0) {
   const int M = d.M, Cg = d.Cg, Kd = d.Kd, ntaps = d.ntaps, transposed = d.transposed;
   const int Mp = (M + 15) / 16 * 16, nch = (Kd + 31) / 32;
-  const size_t total = (size_t)nch * Mp * 4;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  size_t total = (size_t)nch * Mp * 4;
+  if (count < total - first) total = first + count;        // (a job of the batched launch covers a RANGE of the image's slots)
+  for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int slot = (int)(i & 3);
     const size_t rr = i >> 2;
     const int row = (int)(rr % Mp), ch = (int)(rr / Mp);
@@ -122,11 +123,13 @@ struct SplitJob {
   const float* w;
   unsigned* img;              // the image's first dword (offset inside the layer's buffer already added)
   int Cin, taps_all;
-  SplitDesc d;
+  unsigned long long first, count;      // the 16-byte slots of the image this job makes (W_JOB_SLOTS at most: the images of
+  SplitDesc d;                          // layer 4 are 30 x a layer-1 image -- equal jobs keep every CU busy to the end)
 };
+constexpr unsigned W_JOB_SLOTS = 16384, W_JOB_BLOCKS = 16;
 __global__ __launch_bounds__(256) void w_split_jobs_kernel(const SplitJob* __restrict__ jobs) {
   const SplitJob& j = jobs[blockIdx.y];
-  w_split_body(j.w, j.img, j.d, j.Cin, j.taps_all);
+  w_split_body(j.w, j.img, j.d, j.Cin, j.taps_all, (size_t)j.first, (size_t)j.count);
 }
 static bool split_desc(SplitDesc& o, const Desc& d, size_t off_floats, int transposed) {
   if (d.ntaps == 0 || d.Kd == 0 || d.ntaps > 27) return false;      // a parity class no tap reaches: no weights, no K steps
@@ -422,27 +425,32 @@ int32_t slv_conv_w_jobs(const int32_t* geom, const float* w, float* wf, float* w
   SplitJob* jobs = (SplitJob*)out;
   int nj = 0;
   const int taps_all = g.kt * g.kh * g.kw;
-  if (wf && df.x3) {
-    if (df.ntaps > 27) return -1;
+  auto emit = [&](const Desc& d, unsigned* img, int transposed) -> bool {      // the image in jobs of W_JOB_SLOTS slots
     SplitJob j;
     memset(&j, 0, sizeof(j));
-    if (split_desc(j.d, df, 0, 0)) { j.w = w; j.img = (unsigned*)wf; j.Cin = g.Cin; j.taps_all = taps_all; j.d.off = 0; jobs[nj++] = j; }
+    if (!split_desc(j.d, d, 0, transposed)) return true;
+    j.w = w; j.img = img; j.Cin = g.Cin; j.taps_all = taps_all; j.d.off = 0;
+    const unsigned long long total = (unsigned long long)((d.Kd + 31) / 32) * ((d.M + 15) / 16 * 16) * 4;
+    for (unsigned long long f = 0; f < total; f += W_JOB_SLOTS) {
+      if (nj >= max_jobs) return false;
+      j.first = f;
+      j.count = total - f < W_JOB_SLOTS ? total - f : W_JOB_SLOTS;
+      jobs[nj++] = j;
+    }
+    return true;
+  };
+  if (wf && df.x3) {
+    if (df.ntaps > 27 || !emit(df, (unsigned*)wf, 0)) return -1;
   }
   if (wt && n > 0 && ds[0].x3)
-    for (int i = 0; i < n; ++i) {
-      if (ds[i].ntaps > 27) return -1;
-      SplitJob j;
-      memset(&j, 0, sizeof(j));
-      if (split_desc(j.d, ds[i], ds[i].wt_off, 1)) {
-        j.w = w; j.img = (unsigned*)wt + ds[i].wt_off; j.Cin = g.Cin; j.taps_all = taps_all; j.d.off = 0;
-        jobs[nj++] = j;
-      }
-    }
+    for (int i = 0; i < n; ++i)
+      if (ds[i].ntaps > 27 || !emit(ds[i], (unsigned*)wt + ds[i].wt_off, 1)) return -1;
   return nj;
 }
 
 int slv_conv_w_transform_jobs(const int32_t* jobs_dev, int32_t njobs, int32_t blocks_per_job, slv_stream_t stream) {
-  SLV_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535 && blocks_per_job > 0 && blocks_per_job <= 1024, "bad argument");
+  SLV_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535 && blocks_per_job >= 0 && blocks_per_job <= 1024, "bad argument");
+  if (blocks_per_job == 0) blocks_per_job = W_JOB_BLOCKS;      // (16 x 256 threads for <= 16 384 slots)
   hipLaunchKernelGGL(w_split_jobs_kernel, dim3((unsigned)blocks_per_job, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream,
                      (const SplitJob*)jobs_dev);
   SLV_LAUNCH_CHECK();

@@ -57,12 +57,13 @@ struct ClWJob {
   unsigned short* wt;
   int Cout, Cin, taps, Cin_p, Cout_p, MrowsF, MrowsD, patch_kw;
   unsigned nf, nt;
+  unsigned first, count;      // the elements (of the nf + nt) this job makes: equal jobs, whatever the layer's size
 };
-static_assert(sizeof(ClWJob) == 64, "16 int32 words: mirrored by selavi_amd/ops16.py");
+static_assert(sizeof(ClWJob) == 72, "18 int32 words: mirrored by selavi_amd/ops16.py");
 __global__ __launch_bounds__(256) void cl16_w_transform_jobs_kernel(const ClWJob* __restrict__ jobs) {
   const ClWJob j = jobs[blockIdx.y];
-  const unsigned total = j.nf + j.nt;
-  for (unsigned idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+  const unsigned total = j.first + j.count;
+  for (unsigned idx = j.first + blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     if (idx < j.nf) {
       const unsigned jj = idx & 31, m = (idx >> 5) % j.MrowsF, r = (idx >> 5) / j.MrowsF;
       float v = 0.f;

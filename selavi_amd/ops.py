@@ -342,8 +342,8 @@ class WeightImages:
             wt = _f32(plan.wt_elems, device=device) if need_wt else None
             if wf is None and wt is None:
                 continue
-            buf = np.zeros(9 * words, dtype=np.int32)
-            n = C.slv_conv_w_jobs(plan.gp, ptr(w), ptr(wf), ptr(wt), buf.ctypes.data, 9)
+            buf = np.zeros(1024 * words, dtype=np.int32)
+            n = C.slv_conv_w_jobs(plan.gp, ptr(w), ptr(wf), ptr(wt), buf.ctypes.data, 1024)
             if n <= 0:
                 continue                  # (this layer keeps slv_conv_w_transform)
             jobs.append(buf[:n * words])
@@ -354,7 +354,7 @@ class WeightImages:
             tab = np.concatenate(jobs)
             self.table = torch.from_numpy(tab).to(device)
             self.njobs = tab.size // words
-            self.blocks = 48              # grid-stride per job: the largest image (layer 4: 21 MB) is 48 x 256 x ~450 slots
+            self.blocks = 0               # the library's choice (jobs are equal: 16 384 slots each)
         return self
 
     @property

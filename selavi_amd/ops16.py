@@ -312,6 +312,8 @@ class WeightImages:
     """ops.WeightImages for this backend: the bf16 weight layouts of a whole trunk in ONE launch
     (slv_cl16_w_transform_jobs) instead of one per conv layer."""
 
+    JOB_ELEMS = 131072
+
     def __init__(self):
         self.rec, self.seen = [], set()
         self.ent = None
@@ -328,19 +330,23 @@ class WeightImages:
             need_wt = need_wt and not plan.stem
             wf = _bf16(plan.wf_elems, device=device)
             wt = _bf16(plan.wt_elems, device=device) if need_wt else None
-            job = np.zeros(16, dtype=np.int32)
+            job = np.zeros(18, dtype=np.int32)
             job[0:6] = np.array([ptr(w), ptr(wf), ptr(wt)], dtype=np.uint64).view(np.int32)
             job[6:14] = [plan.Cout, plan.Cin_w, plan.w_shape_taps if not plan.stem else plan.taps, plan.Cin_p, plan.Cout_p,
                          plan.mrows_f, plan.mrows_d, plan.patch_kw]
-            job[14:16] = np.array([wf.numel(), wt.numel() if wt is not None else 0], dtype=np.uint32).view(np.int32)
-            jobs.append(job)
+            total = wf.numel() + (wt.numel() if wt is not None else 0)
+            job[14:16] = np.array([wf.numel(), total - wf.numel()], dtype=np.uint32).view(np.int32)
+            for first in range(0, total, self.JOB_ELEMS):      # equal jobs: layer 4's layouts are 30 x layer 1's
+                jb = job.copy()
+                jb[16:18] = np.array([first, min(self.JOB_ELEMS, total - first)], dtype=np.uint32).view(np.int32)
+                jobs.append(jb)
             ent[id(w)] = (plan, wf, wt, w)
         self.rec = None
         self.ent = ent
         if jobs:
             self.table = torch.from_numpy(np.concatenate(jobs)).to(device)
             self.njobs = len(jobs)
-            self.blocks = 96
+            self.blocks = 32
         return self
 
     @property

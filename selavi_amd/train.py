@@ -108,7 +108,10 @@ class GraphedStep:
         snn.dropout_device_state(video.device, create=True)     # Dropout(0.3) draws fresh masks on every replay
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        # (under torch.distributed's nccl backend a watchdog thread polls its work events with hipEventQuery: legal beside a
+        #  capture only in thread-local error mode -- the default "global" mode makes that query fail and takes the process down)
+        mode = {"capture_error_mode": "thread_local"} if self._dp is not None else {}
+        with torch.cuda.graph(self.graph, **mode):
             self.loss = train_step(model, optimizer, video, audio, selflabels, selected, headcount)
             _join_package_streams()                    # a capture may only end with every forked stream joined
         for b in self._bns:                            # the captured call counted one batch without running it
