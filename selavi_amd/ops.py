@@ -311,7 +311,11 @@ def conv_wt_transform(plan, w):
     return conv_w_transform(plan, w, need_wf=False)[1]
 
 
-BATCH_W_IMAGES = os.environ.get("SELAVI_BATCH_W_IMAGES", "1") == "1"
+# Off by default: measured in the step (tools/step16_bench.py, two interleaved pairs, one box) the one launch is 0.3 ms SLOWER
+# than the ~70 it replaces (fp32 30.16 / 30.22 ms against 29.82 / 29.95; bf16 12.34 against 12.23) although the forward alone
+# gains 0.1 ms: an image made right in front of its conv is still in the 256 MB Infinity Cache when the conv's workgroups stream
+# it, the images of the one launch at the head of the trunk (190 + 190 MB) are not.  SELAVI_BATCH_W_IMAGES=1 switches it on.
+BATCH_W_IMAGES = os.environ.get("SELAVI_BATCH_W_IMAGES", "0") == "1"
 
 
 class WeightImages:
