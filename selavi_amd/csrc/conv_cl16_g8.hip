@@ -506,8 +506,15 @@ bool cl16_g8_applies(const ClConv& g) {
     // kernel on the stride-1 spatial convs (activations read once for nine taps there), on the 128-row launches and on the
     // backward data.  One workgroup per CU: a launch of fewer than ~a round of 256 leaves CUs idle that the 128-position
     // tiles would fill; narrow contractions (the stems) have nothing for the pipeline to overlap.
-    if (!(g.flags & 1) || mtw < 8 || blocks < 160 || g.Cin_p * g.ntaps < 256) return false;
-    if (cl16_s3_applies(g)) return false;
+    if (mtw < 8 || blocks < 160 || g.Cin_p * g.ntaps < 256) return false;
+    if (g.flags & 1) {
+      if (cl16_s3_applies(g)) return false;
+    } else {
+      // backward data: only on the 7 x 7 maps of layer 4, where the patch kernel's 128-position tiles are mostly halo and the
+      // tile kernel's launches are short (128 clips x 32 frames: layer 4.1 spatial 0.307 -> 0.239 ms, layer 4.0 strided spatial
+      // 0.449 -> 0.273; the layer-3 launches lose 10-20 %: profiles/r05_g8_ab_cfg5_l3_l4.txt)
+      if (g.Hi * g.Wi > 64) return false;
+    }
   }
   return true;
 }
