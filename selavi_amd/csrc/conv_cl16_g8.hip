@@ -56,6 +56,9 @@ constexpr int G8_BN = 256, G8_THREADS = 512, G8_NB = 3;
 #ifndef SLV_G8_OCC4
 #define SLV_G8_OCC4 1          // the 128-row form (MTW = 4) at two workgroups per CU (128 registers): one's epilogue under the other's loop
 #endif
+#ifndef SLV_G8_DIRECT_EPI
+#define SLV_G8_DIRECT_EPI 0    // 1: EPI 0 launches store their accumulators straight to memory (8-byte pieces, no LDS transposition, no barrier)
+#endif
 #ifndef SLV_G8_ABL
 #define SLV_G8_ABL 0           // timing ablations (wrong results; tools/g8_ablate.sh): 1 no weight DMA, 2 no activation loads, 3 no LDS
 #endif                         // writes, 4 no fragment reads, 5 no MFMAs, 6 no barrier behind the M slot, 7 no vmcnt wait, 8 no epilogue, 9 no K loop, 10 no output stores, 11 no LDS transposition writes, 12 no row-store phase
@@ -361,6 +364,60 @@ __global__ __launch_bounds__(G8_THREADS, (SLV_G8_OCC4 && MTW == 4) ? 4 : 2) void
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+  if constexpr (EPI == 0 && SLV_G8_DIRECT_EPI) {
+    // ---- direct epilogue: every wave stores ITS tiles as they are -- a lane holds 4 consecutive channels of one position
+    // (8 bytes), the 4 k-groups of a position 32 contiguous bytes -- no LDS, no barrier: with one workgroup per CU nothing
+    // overlaps an epilogue, so its phases (transpose, barrier, row stores) cost their full latency each
+    unsigned opj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned p = bx * G8_BN + wq * 64 + j * 16 + fr;
+      unsigned o = 0xFFFFFFFFu;
+      if (p < P) {
+        const unsigned q1 = fdiv(p, dLw), q2 = fdiv(q1, dLh), q = fdiv(q2, dLt);
+        const int lw = p - q1 * g.Lw, lh = q1 - q2 * g.Lh, lt = q2 - q * g.Lt;
+        o = ((q * g.To + lt * g.omt + g.oot) * g.Ho + lh * g.omh + g.ooh) * g.Wo + lw * g.omw + g.oow;
+      }
+      opj[j] = o;
+    }
+    const int c0 = m0 + wh * BMH;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      const int co = c0 + i * 16 + fk * 4;
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (scale_shift) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sc[r] = co + r < g.Cout ? scale_shift[co + r] : 0.f;
+          sh[r] = co + r < g.Cout ? scale_shift[g.Cout + co + r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned op = opj[j];
+        if (op == 0xFFFFFFFFu || co >= g.Cout_p) continue;
+        uint2 rr = make_uint2(0u, 0u);
+        if (res) rr = *(const uint2*)(res + (size_t)op * g.Cout_p + co);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = acc[i][j][r];
+          if (scale_shift) t = __builtin_fmaf(t, sc[r], sh[r]);
+          if (res) t += bf2f((unsigned short)((r < 2 ? rr.x : rr.y) >> ((r & 1) * 16)));
+          if (relu) t = fmaxf(t, 0.f);
+          v[r] = t;
+        }
+        *(uint2*)(y + (size_t)op * g.Cout_p + co) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      }
+    }
+    if (by == gridDim.y - 1 && g.Mrows < g.Cout_p && wh == 1) {      // padding channels no tile covers: zeros
+      for (int c = g.Mrows + fk * 4; c < g.Cout_p; c += 16)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (opj[j] != 0xFFFFFFFFu) *(uint2*)(y + (size_t)opj[j] * g.Cout_p + c) = make_uint2(0u, 0u);
+    }
     return;
   }
   // ---- epilogue, one channel half at a time: the half's tiles transposed through LDS ([position][cout] rows), statistics

@@ -53,6 +53,9 @@ for name, Cin, T, H, W, Cout, k, st, pd in (("l2.1.spatial", 128, 8, 28, 28, 288
     wf, wt = ops16.conv_w_transform(plan, w)
     t_plain = timeit(lambda: ops16.conv_fwd(plan, x, w, want_stats=False, wf=wf))
     t_full = timeit(lambda: ops16.conv_fwd(plan, x, w, in_ss=ss, in_relu=True, wf=wf))
+    dy = torch.randn(plan.out_shape, device=dev, generator=g).to(torch.bfloat16)
+    dy[..., Cout:] = 0
+    t_dg = timeit(lambda: ops16.conv_dgrad(plan, dy, wt))
     flop = 2.0 * B * plan.out_dims[0] * plan.out_dims[1] * plan.out_dims[2] * Cout * Cin * k[0] * k[1] * k[2]
-    out.append(f"{name}: plain {t_plain:.3f} ms ({flop / t_plain / 1e9:.0f} TF) train {t_full:.3f} ms")
+    out.append(f"{name}: plain {t_plain:.3f} ms ({flop / t_plain / 1e9:.0f} TF) train {t_full:.3f} dgrad {t_dg:.3f} ms")
 print(" | ".join(out))
