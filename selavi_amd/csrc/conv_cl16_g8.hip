@@ -54,8 +54,8 @@ constexpr int G8_BN = 256, G8_THREADS = 512, G8_NB = 3;
 #define SLV_G8_PRO_IN_M -1
 #endif
 #ifndef SLV_G8_OCC4
-#define SLV_G8_OCC4 1          // the 128-row form (MTW = 4) at two workgroups per CU (128 registers): one's epilogue under the other's loop
-#endif
+#define SLV_G8_OCC4 1          // the 128-row form (MTW = 4) without prologue at two workgroups per CU (128 registers): one's epilogue under
+#endif                         // the other's loop (with the prologue the 128-register cap spills 24-32 bytes and buys 1.5 %)
 #ifndef SLV_G8_DIRECT_EPI
 #define SLV_G8_DIRECT_EPI 0    // 1: EPI 0 launches store their accumulators straight to memory (8-byte pieces, no LDS transposition, no barrier)
 #endif
@@ -87,7 +87,7 @@ constexpr size_t g8_lds_bytes(int mtw, int cin_p, bool pro) {
 }
 
 template <int MTW, int PRO, int EPI>
-__global__ __launch_bounds__(G8_THREADS, (SLV_G8_OCC4 && MTW == 4) ? 4 : 2) void conv_cl16_g8_kernel(const unsigned short* __restrict__ x,
+__global__ __launch_bounds__(G8_THREADS, (SLV_G8_OCC4 && MTW == 4 && PRO == 0) ? 4 : 2) void conv_cl16_g8_kernel(const unsigned short* __restrict__ x,
                                                                       const unsigned short* __restrict__ wl,
                                                                       unsigned short* __restrict__ y,
                                                                       const float* __restrict__ in_ss,
