@@ -9,15 +9,18 @@
 //   * waves 0-2 are MFMA waves: wave w owns output channels 48 w .. 48 w + 47 and holds their whole weight slice --
 //     9 taps x 2 chunks x 3 tiles = 54 A fragments = 216 registers, in the accumulator half of the register file
 //     (asm MFMAs with an "a" operand) -- for the kernel's lifetime.  Per tile: 72 ds_read_b128 of the input patch
-//     (one base register, every tap / chunk / fragment an immediate offset), 216 MFMAs, the bf16 tile into LDS;
-//     the tile's epilogue rides BETWEEN the MFMAs of the next tile (two accumulator sets): round to bf16 through a
-//     private LDS stage, BatchNorm statistics of the rounded values as per-lane running sums, the 96-byte segment of
-//     every pixel's channel row to memory (wave 2: 128 bytes, with the 16 padding channels);
-//   * wave 3 is the data-movement wave: it fetches the 10 x 10-pixel patch of the NEXT tile (16-byte pieces, each lane
-//     a fixed channel piece, so BatchNorm + ReLU coefficients stay in registers; border handling from four precomputed
-//     bit masks), applies BatchNorm + ReLU once per element and writes zeros for the halo outside the image (no per-tap
-//     masks anywhere);
-//   * the patch is double buffered in LDS (one workgroup per CU: 79 KB of the 160), ONE barrier per tile.
+//     (one base register, every tap / chunk / fragment an immediate offset), 216 MFMAs;
+//     the tile's epilogue rides BETWEEN the MFMAs of the next tile (two accumulator sets): 12 items = round one
+//     accumulator tile to bf16 into the workgroup's OUTPUT TILE in LDS (64 pixels x 160 channels, double buffered) and
+//     add the rounded values to the per-lane running sums of the BatchNorm statistics;
+//   * wave 3 is the data-movement wave, BOTH directions: it fetches the 10 x 10-pixel patch of the NEXT tile (16-byte
+//     pieces, each lane a fixed channel piece, so BatchNorm + ReLU coefficients stay in registers; border handling from
+//     four precomputed bit masks), applies BatchNorm + ReLU once per element and writes zeros for the halo outside the
+//     image (no per-tap masks anywhere); and it moves the output tile finished two tiles ago to memory -- a tile row is 8
+//     pixels x 320 bytes CONTIGUOUS, every store instruction writes 1 KB of whole cache lines (round 5; before, each MFMA
+//     wave stored its own 96-byte segment of every pixel row -- partial lines from three waves at three times -- with the
+//     LDS reads and the address arithmetic of 8 stores riding between its MFMAs: 0.58 -> 0.48 ms without those stores);
+//   * patch and output tile are double buffered in LDS (one workgroup per CU: 92 KB of the 160), ONE barrier per tile.
 // LDS patch: pixel (py, px) of the 10 x 10 patch at ((py * 16 + px) * 160) bytes -- pitch 16, rows of 128 + 32 bytes:
 // found by enumeration to be conflict-free for ds_read_b128 fragments whose 16 positions are 2 tile rows x 8 columns,
 // for every tap shift, without any XOR (so taps stay immediates).
@@ -31,11 +34,17 @@ constexpr int SR_PW = SR_T + 2;                       // patch edge
 constexpr int SR_PITCH = 16, SR_ROWB = 160;           // LDS patch geometry (see above)
 constexpr int SR_PATCH = SR_PW * SR_PITCH * SR_ROWB;  // 25 600 B
 constexpr int SR_CIN = 64, SR_COUT = 144, SR_COUTP = 160;
-constexpr int SR_OROW = 128 + 16;                     // bytes per pixel row of a wave's output stage (<= 64 channels)
-constexpr int SR_OST = SR_T * SR_T * SR_OROW;         // 9 216 B per MFMA wave
-constexpr int SR_LDS = 2 * SR_PATCH + 3 * SR_OST;
+constexpr int SR_OROW = SR_COUTP * 2 + 16;            // bytes per pixel row of the output tile (pitch 84 dwords: the 8-byte
+                                                      // writes of a half wave -- 16 pixels x 2 k-groups -- hit 64 distinct banks)
+constexpr int SR_OUT = SR_T * SR_T * SR_OROW;         // 21 504 B per output tile
+constexpr int SR_LDS = 2 * SR_PATCH + 2 * SR_OUT;
 constexpr int SR_NIT = (SR_PW * SR_PW + 7) / 8;       // 13 load instructions cover the patch (8 rows of 8 pieces each)
+constexpr int SR_OPIECES = SR_T * SR_T * (SR_COUTP * 2 / 16);   // 1 280 16-byte pieces of an output tile
+constexpr int SR_ONIT = SR_OPIECES / 64;              // = 20 store instructions of one wave
 
+#ifndef SLV_SR_EVERY
+#define SLV_SR_EVERY 7    // one epilogue item behind every SLV_SR_EVERY-th MFMA of the next tile
+#endif
 #ifndef SLV_SR_ABL
 #define SLV_SR_ABL 0      // timing ablations (results wrong): 1 no MFMAs (a VALU xor keeps the operands alive), 2 no global
 #endif                    // patch loads, 3 no output stores, 4 no epilogue at all, 5 no sched_barrier between MFMA groups
@@ -101,19 +110,13 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
 #pragma unroll
         for (int i = 0; i < 3; ++i)
           A[t][c][i] = *(const bf16x8*)(wl + ((size_t)((t * 2 + c) * SR_COUT + (wave * 3 + i) * 16 + fr) * 32 + fk * 8));
-    const unsigned Ptot = (unsigned)g.N * g.Ti * H * W;
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)(Ptot * (SR_COUTP * 2u)), 0x00020000);
-    // the wave's own output stage: 64 pixels x its channel segment (wave 2: its 48 channels + the 16 padding channels
-    // 144..159, which stay zero), written and read by this wave only
-    unsigned char* const ost = lds + 2 * SR_PATCH + wave * SR_OST;
-    for (int i = lane * 16; i < SR_OST; i += 64 * 16) *(u32x4*)(ost + i) = (u32x4){0u, 0u, 0u, 0u};
-    const int npc = wave == 2 ? 8 : 6;                // 16-byte pieces of the segment per pixel
-    const int ppi = 64 / npc;                         // pixels one store instruction covers (10 or 8)
-    const int spiece = lane % npc, spx = lane / npc;
-    const bool sact = lane < ppi * npc;
+    // the workgroup's output tiles [2][64 pixels][SR_OROW]: zeroed once (the 16 padding channels 144..159 are never
+    // written again and reach memory as zeros), filled by the MFMA waves, moved to memory by the data-movement wave
+    unsigned char* const outb = lds + 2 * SR_PATCH;
+    for (int i = (wave * 64 + lane) * 16; i < 2 * SR_OUT; i += 3 * 64 * 16) *(u32x4*)(outb + i) = (u32x4){0u, 0u, 0u, 0u};
     // lane part of a fragment read: position fr of fragment nn is tile pixel (2 nn + (fr >> 3), fr & 7)
     const int lbase = (((fr >> 3) * SR_PITCH + (fr & 7)) * SR_ROWB) + fk * 16;
-    const int obase = fr * SR_OROW + fk * 8;
+    const int obase = fr * SR_OROW + wave * 96 + fk * 8;
     // BatchNorm statistics: per-lane running sums of the ROUNDED outputs and their squares (channel (3 wave + i) * 16 +
     // 4 fk + r, over this lane's pixel column fr), reduced over the 16 lanes of a DPP row once, at the end of the kernel
     float stS[3][4], stQ[3][4];
@@ -121,45 +124,26 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) stS[i][r] = stQ[i][r] = 0.f;
-    // The epilogue of tile n - 1 (round to bf16 through the wave's LDS stage, statistics, 7-8 stores) is cut into 30
-    // ITEMS that ride between the MFMAs of tile n, one item after every 7th MFMA (two accumulator sets, the loop
-    // unrolled by two).  An in-order wave cannot issue past a waiting MFMA: work placed BEHIND a block of MFMAs runs with
-    // the matrix pipe idle (measured: the epilogue behind the block, or in 18 slices behind the 18 MFMA groups, cost a
-    // quarter of the tile time either way), work placed BETWEEN MFMAs rides in the 12 idle issue cycles of each.
-    u32x4 carry = {0u, 0u, 0u, 0u};
-    unsigned carry_off = 0xFFFFFFF0u;
-    constexpr int SR_ITEMS = 28, SR_EVERY = 7;
-    auto drain_item = [&](int it, f32x4 (&pv)[3][4], const SrTile& tl) __attribute__((always_inline)) {
-      if (it < 12) {                                  // items 0-11: one accumulator tile -> bf16 -> LDS stage
-        const int i = it >> 2, nn = it & 3;
-        const unsigned lo = pack_bf2(pv[i][nn][0], pv[i][nn][1]), hi = pack_bf2(pv[i][nn][2], pv[i][nn][3]);
-        *(uint2*)(ost + obase + nn * 16 * SR_OROW + i * 32) = make_uint2(lo, hi);
-        if constexpr (EPI == 1) {
-          float v[4] = {bf_lo(lo), bf_hi(lo), bf_lo(hi), bf_hi(hi)};
-          if (tl.y0 + SR_T > H || tl.x0 + SR_T > W) { // ragged tile (rare): pixels outside the image count as zero
-            const int pp = nn * 16 + fr;
-            if (tl.y0 + (pp >> 3) >= H || tl.x0 + (pp & 7) >= W) v[0] = v[1] = v[2] = v[3] = 0.f;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            stS[i][r] += v[r];
-            stQ[i][r] = __builtin_fmaf(v[r], v[r], stQ[i][r]);
-          }
+    // The epilogue of tile n - 1 (round to bf16 into the output tile, statistics) is cut into 12 ITEMS -- one per
+    // accumulator tile -- that ride between the MFMAs of tile n, one item after every SR_EVERY-th MFMA (two accumulator
+    // sets, the loop unrolled by two).  An in-order wave cannot issue past a waiting MFMA: work placed BEHIND a block of
+    // MFMAs runs with the matrix pipe idle (measured: the epilogue behind the block, or in 18 slices behind the 18 MFMA
+    // groups, cost a quarter of the tile time either way), work placed BETWEEN MFMAs rides in the 12 idle issue cycles of each.
+    constexpr int SR_ITEMS = 12, SR_EVERY = SLV_SR_EVERY;
+    auto drain_item = [&](int it, f32x4 (&pv)[3][4], const SrTile& tl, unsigned char* ost) __attribute__((always_inline)) {
+      const int i = it >> 2, nn = it & 3;
+      const unsigned lo = pack_bf2(pv[i][nn][0], pv[i][nn][1]), hi = pack_bf2(pv[i][nn][2], pv[i][nn][3]);
+      *(uint2*)(ost + obase + nn * 16 * SR_OROW + i * 32) = make_uint2(lo, hi);
+      if constexpr (EPI == 1) {
+        float v[4] = {bf_lo(lo), bf_hi(lo), bf_lo(hi), bf_hi(hi)};
+        if (tl.y0 + SR_T > H || tl.x0 + SR_T > W) {   // ragged tile (rare): pixels outside the image count as zero
+          const int pp = nn * 16 + fr;
+          if (tl.y0 + (pp >> 3) >= H || tl.x0 + (pp & 7) >= W) v[0] = v[1] = v[2] = v[3] = 0.f;
         }
-      } else if (it < SR_ITEMS) {                     // items 12-27: store k = read its pieces, then issue it
-        const int k = (it - 12) >> 1;
-        if (k * ppi < SR_T * SR_T) {                  // (out-of-range offsets drop the store: no branches per lane)
-          if (((it - 12) & 1) == 0) {
-            const int p = k * ppi + spx;
-            const int yy = tl.y0 + (p >> 3), xx = tl.x0 + (p & 7);
-            const bool ok = sact && p < SR_T * SR_T && yy < H && xx < W;
-            carry = *(const u32x4*)(ost + (p < SR_T * SR_T ? p : 0) * SR_OROW + spiece * 16);
-            carry_off = (ok && SLV_SR_ABL != 3)
-                            ? (tl.fpos + (unsigned)(yy * W + xx)) * (SR_COUTP * 2u) + (unsigned)(wave * 96 + spiece * 16)
-                            : 0xFFFFFFF0u;
-          } else {
-            __builtin_amdgcn_raw_buffer_store_b128(carry, ry, carry_off, 0, 0);
-          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          stS[i][r] += v[r];
+          stQ[i][r] = __builtin_fmaf(v[r], v[r], stQ[i][r]);
         }
       }
     };
@@ -167,6 +151,7 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
       const unsigned char* src = patch + (n & 1) * SR_PATCH + lbase;
       const bool drain = n > 0 && SLV_SR_ABL != 4;
       const SrTile tl = tile_of(n > 0 ? n - 1 : 0);
+      unsigned char* const ost = outb + ((n & 1) ^ 1) * SR_OUT;   // tile n - 1's output tile
       // 18 MFMA groups (tap, chunk); the fragments of group g + 1 are requested before the MFMAs of group g (two
       // register sets), so that no MFMA waits for an LDS read
       bf16x8 b[2][4];
@@ -188,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
             else sr_mfma(acc[i][nn], A[gi >> 1][gi & 1][i], b[gi & 1][nn]);
             const int m = gi * 12 + i * 4 + nn;       // MFMA index within the tile
             if (m % SR_EVERY == SR_EVERY - 1 && m / SR_EVERY < SR_ITEMS) {
-              if (drain) drain_item(m / SR_EVERY, pv, tl);
+              if (drain) drain_item(m / SR_EVERY, pv, tl, ost);
               if (SLV_SR_ABL != 5) __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -204,14 +189,16 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
     if (nt > 0) {                                     // the last tile's epilogue
       asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // 8-pass XDL result -> VALU read
       const SrTile tl = tile_of(nt - 1);
+      unsigned char* const ost = outb + ((nt - 1) & 1) * SR_OUT;
       if ((nt - 1) & 1) {
 #pragma unroll
-        for (int it = 0; it < SR_ITEMS; ++it) drain_item(it, accB, tl);
+        for (int it = 0; it < SR_ITEMS; ++it) drain_item(it, accB, tl, ost);
       } else {
 #pragma unroll
-        for (int it = 0; it < SR_ITEMS; ++it) drain_item(it, accA, tl);
+        for (int it = 0; it < SR_ITEMS; ++it) drain_item(it, accA, tl, ost);
       }
     }
+    sr_barrier();                                     // the last output tile is in LDS
     if constexpr (EPI == 1) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -299,6 +286,34 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
       *(u32x4*)(dst + loff[i]) = v;
     }
   };
+  // ---- the way out: output tile k (finished by the MFMA waves one barrier ago) -> memory.  Piece q = 64 it + lane of
+  // the tile's 1 280: tile row q / 160 (8 pixels x 320 B, contiguous in memory), then pixel, then 16-byte piece
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)(Ptot * (SR_COUTP * 2u)), 0x00020000);
+  const unsigned char* const outb = lds + 2 * SR_PATCH;
+  unsigned oglo[SR_ONIT], opk[SR_ONIT];
+#pragma unroll
+  for (int it = 0; it < SR_ONIT; ++it) {
+    const int q = it * 64 + lane, row = q / 160, rem = q - row * 160, px = rem / 20, pc = rem - px * 20;
+    oglo[it] = (unsigned)((row * W + px) * (SR_COUTP * 2) + pc * 16);
+    opk[it] = (unsigned)((row * SR_T + px) * SR_OROW + pc * 16) | (unsigned)row << 16 | (unsigned)px << 24;
+  }
+  auto store_out = [&](int k) __attribute__((always_inline)) {
+    const SrTile t = tile_of(k > 0 ? k : 0);
+    const unsigned char* src = outb + (k & 1) * SR_OUT;
+    const unsigned base = (t.fpos + (unsigned)(t.y0 * W + t.x0)) * (SR_COUTP * 2u);
+    const int hy = k >= 0 && SLV_SR_ABL != 3 ? H - t.y0 : 0, hx = W - t.x0;      // rows / columns of the tile inside the image
+#pragma unroll
+    for (int h = 0; h < SR_ONIT; h += SR_ONIT / 2) {
+      u32x4 v[SR_ONIT / 2];
+#pragma unroll
+      for (int it = 0; it < SR_ONIT / 2; ++it) v[it] = *(const u32x4*)(src + (opk[h + it] & 0xFFFFu));
+#pragma unroll
+      for (int it = 0; it < SR_ONIT / 2; ++it) {
+        const bool ok = (int)((opk[h + it] >> 16) & 0xFFu) < hy && (int)(opk[h + it] >> 24) < hx;
+        __builtin_amdgcn_raw_buffer_store_b128(v[it], ry, ok ? base + oglo[h + it] : 0xFFFFFFF0u, 0, 0);
+      }
+    }
+  };
   // ---- pipeline head: patch 0 into buffer 0, patch 1 requested
   load_patch(0);
   store_patch(0);
@@ -307,8 +322,12 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
   for (int n = 0; n < nt; ++n) {
     store_patch((n + 1) & 1);                         // patch n + 1 (requested a step ago) -> the buffer tile n - 1 used
     load_patch(n + 2);                                // patch n + 2: in flight across the barrier
+    store_out(n - 2);                                 // output tile n - 2: complete since the last barrier
     sr_barrier();
   }
+  store_out(nt - 2);
+  sr_barrier();                                       // the MFMA waves have written the last output tile
+  store_out(nt - 1);
 }
 
 static bool sr_enabled() {
