@@ -42,9 +42,6 @@ constexpr int SR_NIT = (SR_PW * SR_PW + 7) / 8;       // 13 load instructions co
 constexpr int SR_OPIECES = SR_T * SR_T * (SR_COUTP * 2 / 16);   // 1 280 16-byte pieces of an output tile
 constexpr int SR_ONIT = SR_OPIECES / 64;              // = 20 store instructions of one wave
 
-#ifndef SLV_SR_EVERY
-#define SLV_SR_EVERY 7    // one epilogue item behind every SLV_SR_EVERY-th MFMA of the next tile
-#endif
 #ifndef SLV_SR_ABL
 #define SLV_SR_ABL 0      // timing ablations (results wrong): 1 no MFMAs (a VALU xor keeps the operands alive), 2 no global
 #endif                    // patch loads, 3 no output stores, 4 no epilogue at all, 5 no sched_barrier between MFMA groups
@@ -64,10 +61,24 @@ __device__ __forceinline__ void sr_mfma0(f32x4& acc, const bf16x8& a, const bf16
   asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(a), "v"(b));
 #endif
 }
+__device__ __forceinline__ void sr_add(float& a, float v) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(a) : "v"(v)); }
+__device__ __forceinline__ void sr_sq(float& q, float v) { asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(q) : "v"(v)); }
 __device__ __forceinline__ void sr_barrier() {        // LDS traffic of this wave complete, then the workgroup barrier;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // global loads / stores stay in flight across it
   __builtin_amdgcn_s_barrier();
 }
+
+#ifdef SLV_SR_TRACE       // timing only (tools/sr_trace.py): per wave, s_memtime ticks summed over the tiles per section, written
+#define SR_STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); trc[i] += t_ - tlast; tlast = t_; } while (0)
+#define SR_TRACE_DECL unsigned long long trc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter()
+#define SR_TRACE_RESET tlast = __builtin_readcyclecounter()
+#define SR_TRACE_OUT do { if (lane == 0) { unsigned long long* o_ = (unsigned long long*)y + (blockIdx.x * 4 + wave) * 8; for (int i_ = 0; i_ < 8; ++i_) o_[i_] = trc[i_]; } } while (0)
+#else                     // over the head of y at the end of the kernel (the first output rows are garbage afterwards)
+#define SR_STAMP(i) do { } while (0)
+#define SR_TRACE_DECL do { } while (0)
+#define SR_TRACE_RESET do { } while (0)
+#define SR_TRACE_OUT do { } while (0)
+#endif
 
 struct SrTile {
   int y0, x0;
@@ -124,34 +135,55 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) stS[i][r] = stQ[i][r] = 0.f;
-    // The epilogue of tile n - 1 (round to bf16 into the output tile, statistics) is cut into 12 ITEMS -- one per
-    // accumulator tile -- that ride between the MFMAs of tile n, one item after every SR_EVERY-th MFMA (two accumulator
-    // sets, the loop unrolled by two).  An in-order wave cannot issue past a waiting MFMA: work placed BEHIND a block of
-    // MFMAs runs with the matrix pipe idle (measured: the epilogue behind the block, or in 18 slices behind the 18 MFMA
-    // groups, cost a quarter of the tile time either way), work placed BETWEEN MFMAs rides in the 12 idle issue cycles of each.
-    constexpr int SR_ITEMS = 12, SR_EVERY = SLV_SR_EVERY;
-    auto drain_item = [&](int it, f32x4 (&pv)[3][4], const SrTile& tl, unsigned char* ost) __attribute__((always_inline)) {
-      const int i = it >> 2, nn = it & 3;
-      const unsigned lo = pack_bf2(pv[i][nn][0], pv[i][nn][1]), hi = pack_bf2(pv[i][nn][2], pv[i][nn][3]);
-      *(uint2*)(ost + obase + nn * 16 * SR_OROW + i * 32) = make_uint2(lo, hi);
-      if constexpr (EPI == 1) {
-        float v[4] = {bf_lo(lo), bf_hi(lo), bf_lo(hi), bf_hi(hi)};
-        if (tl.y0 + SR_T > H || tl.x0 + SR_T > W) {   // ragged tile (rare): pixels outside the image count as zero
-          const int pp = nn * 16 + fr;
-          if (tl.y0 + (pp >> 3) >= H || tl.x0 + (pp & 7) >= W) v[0] = v[1] = v[2] = v[3] = 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          stS[i][r] += v[r];
-          stQ[i][r] = __builtin_fmaf(v[r], v[r], stQ[i][r]);
+    // The epilogue of tile n - 1 (round to bf16 into the output tile, statistics) is cut into 72 STEPS of <= 3 VALU
+    // instructions -- 6 per accumulator tile -- and ONE step rides behind every third MFMA of tile n (two accumulator
+    // sets, the loop unrolled by two).  An in-order wave cannot issue past a waiting MFMA, and the matrix pipe holds one
+    // 16-cycle MFMA: a 25-instruction item behind every 7th MFMA (rounds 3-4) left the pipe idle for ~85 cycles per item =
+    // 1 000 of a tile's 5 100 cycles (tools/sr_trace.py); three VALU instructions fit the 12 issue cycles an MFMA leaves.
+    constexpr int SR_STEPS = 72, SR_EVERY = 3;
+    unsigned dlo = 0, dhi = 0;
+    float dv0 = 0.f, dv1 = 0.f;
+    unsigned keep[4] = {~0u, ~0u, ~0u, ~0u};          // ragged tiles: pixels outside the image count as zero in the statistics
+    auto drain_step = [&](int st, f32x4 (&pv)[3][4], unsigned char* ost) __attribute__((always_inline)) {
+      const int a = st / 6, sub = st - a * 6, i = a >> 2, nn = a & 3;
+      if (sub == 0) {
+        dlo = pack_bf2(pv[i][nn][0], pv[i][nn][1]);
+        dhi = pack_bf2(pv[i][nn][2], pv[i][nn][3]);
+      } else if (sub == 1) {
+        if constexpr (EPI == 1) dlo &= keep[nn], dhi &= keep[nn];   // (no branch: a taken branch idles the matrix pipe ~30 cycles)
+        *(uint2*)(ost + obase + nn * 16 * SR_OROW + i * 32) = make_uint2(dlo, dhi);
+      } else if constexpr (EPI == 1) {                // (asm: left to itself hipcc SLP-packs adjacent sums into v_pk_add_f32 /
+        if (sub == 2) {                               // v_pk_fma_f32, and ONE packed f32 instruction beside MFMAs costs 22-26
+          dv0 = bf_lo(dlo), dv1 = bf_hi(dlo);         // cycles of matrix-pipe time: 24 of them per tile were the 1 000 cycles
+          sr_add(stS[i][0], dv0);                     // the statistics used to cost)
+        } else if (sub == 3) {
+          sr_add(stS[i][1], dv1);
+          sr_sq(stQ[i][0], dv0);
+          sr_sq(stQ[i][1], dv1);
+        } else if (sub == 4) {
+          dv0 = bf_lo(dhi), dv1 = bf_hi(dhi);
+          sr_add(stS[i][2], dv0);
+        } else {
+          sr_add(stS[i][3], dv1);
+          sr_sq(stQ[i][2], dv0);
+          sr_sq(stQ[i][3], dv1);
         }
       }
     };
+    auto set_keep = [&](const SrTile& tl) __attribute__((always_inline)) {
+      if constexpr (EPI == 1) {
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)                // (position fr of fragment nn is tile pixel (2 nn + (fr >> 3), fr & 7))
+          keep[nn] = (tl.y0 + 2 * nn + (fr >> 3) < H && tl.x0 + (fr & 7) < W) ? ~0u : 0u;
+      }
+    };
+    SR_TRACE_DECL;
     auto tile_step = [&](int n, f32x4 (&acc)[3][4], f32x4 (&pv)[3][4]) __attribute__((always_inline)) {
       const unsigned char* src = patch + (n & 1) * SR_PATCH + lbase;
-      const bool drain = n > 0 && SLV_SR_ABL != 4;
+      // (at n = 0 the other accumulator set is all zeros: zeros into an output tile nobody stores, zeros to the statistics)
       const SrTile tl = tile_of(n > 0 ? n - 1 : 0);
       unsigned char* const ost = outb + ((n & 1) ^ 1) * SR_OUT;   // tile n - 1's output tile
+      set_keep(tl);
       // 18 MFMA groups (tap, chunk); the fragments of group g + 1 are requested before the MFMAs of group g (two
       // register sets), so that no MFMA waits for an LDS read
       bf16x8 b[2][4];
@@ -172,16 +204,23 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
             if (gi == 0) sr_mfma0(acc[i][nn], A[gi >> 1][gi & 1][i], b[gi & 1][nn]);
             else sr_mfma(acc[i][nn], A[gi >> 1][gi & 1][i], b[gi & 1][nn]);
             const int m = gi * 12 + i * 4 + nn;       // MFMA index within the tile
-            if (m % SR_EVERY == SR_EVERY - 1 && m / SR_EVERY < SR_ITEMS) {
-              if (drain) drain_item(m / SR_EVERY, pv, tl, ost);
+            if (m % SR_EVERY == SR_EVERY - 1 && m / SR_EVERY < SR_STEPS) {
+              if (SLV_SR_ABL != 4) drain_step(m / SR_EVERY, pv, ost);
               if (SLV_SR_ABL != 5) __builtin_amdgcn_sched_barrier(0);
             }
           }
       }
+      SR_STAMP(0);                                    // the tile's MFMAs + the previous tile's epilogue items
       sr_barrier();                                   // the patch buffer is free: the data-movement wave may refill it
+      SR_STAMP(1);                                    // waiting for the other waves
     };
     f32x4 accA[3][4], accB[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) accB[i][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
     sr_barrier();                                     // patch 0 is in LDS
+    SR_TRACE_RESET;
     for (int n = 0; n < nt; n += 2) {
       tile_step(n, accA, accB);
       if (n + 1 < nt) tile_step(n + 1, accB, accA);
@@ -190,15 +229,17 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
       asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // 8-pass XDL result -> VALU read
       const SrTile tl = tile_of(nt - 1);
       unsigned char* const ost = outb + ((nt - 1) & 1) * SR_OUT;
+      set_keep(tl);
       if ((nt - 1) & 1) {
 #pragma unroll
-        for (int it = 0; it < SR_ITEMS; ++it) drain_item(it, accB, tl, ost);
+        for (int it = 0; it < SR_STEPS; ++it) drain_step(it, accB, ost);
       } else {
 #pragma unroll
-        for (int it = 0; it < SR_ITEMS; ++it) drain_item(it, accA, tl, ost);
+        for (int it = 0; it < SR_STEPS; ++it) drain_step(it, accA, ost);
       }
     }
     sr_barrier();                                     // the last output tile is in LDS
+    SR_STAMP(2);
     if constexpr (EPI == 1) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -212,6 +253,7 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
           }
         }
     }
+    SR_TRACE_OUT;
     return;
   }
 
@@ -245,9 +287,12 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
     mleft |= (unsigned)(px == 0) << i;
     mright |= (unsigned)(px == SR_PW - 1) << i;
   }
-  u32x4 st[SR_NIT];
-  unsigned stv = 0;
-  auto load_patch = [&](int k) __attribute__((always_inline)) {
+  // two register sets: patch k + 2 AND patch k + 3 are in flight while tile k is computed -- with one set the request
+  // had less than one tile time (~2.5 us) to come back, and a late one put store_patch (BatchNorm + ReLU, 13 LDS writes)
+  // on the workgroup's critical path (the prologue cost 0.09 ms of 0.6)
+  u32x4 stA[SR_NIT], stB[SR_NIT];
+  unsigned svA = 0, svB = 0;
+  auto load_patch = [&](int k, u32x4 (&st)[SR_NIT], unsigned& stv) __attribute__((always_inline)) {
     const SrTile t = tile_of(k);
     // pieces inside the image.  Whole tiles (the common case): a piece is outside iff it lies on a patch border that
     // coincides with an image border -- four precomputed bit masks; ragged tiles and steps past the last tile: per piece
@@ -274,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
     for (int i = 0; i < SR_NIT; ++i)
       st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (((valid >> i) & 1) && SLV_SR_ABL != 2) ? base + goff[i] : 0xFFFFFFF0u, 0, 0));
   };
-  auto store_patch = [&](int buf) __attribute__((always_inline)) {
+  auto store_patch = [&](int buf, const u32x4 (&st)[SR_NIT], const unsigned& stv) __attribute__((always_inline)) {
     unsigned char* dst = patch + buf * SR_PATCH;
 #pragma unroll
     for (int i = 0; i < SR_NIT; ++i) {
@@ -302,32 +347,58 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
     const unsigned char* src = outb + (k & 1) * SR_OUT;
     const unsigned base = (t.fpos + (unsigned)(t.y0 * W + t.x0)) * (SR_COUTP * 2u);
     const int hy = k >= 0 && SLV_SR_ABL != 3 ? H - t.y0 : 0, hx = W - t.x0;      // rows / columns of the tile inside the image
+    const bool whole = hy >= SR_T && hx >= SR_T;      // (the common case: the tile's base as the scalar offset, no VALU per store)
 #pragma unroll
     for (int h = 0; h < SR_ONIT; h += SR_ONIT / 2) {
       u32x4 v[SR_ONIT / 2];
 #pragma unroll
       for (int it = 0; it < SR_ONIT / 2; ++it) v[it] = *(const u32x4*)(src + (opk[h + it] & 0xFFFFu));
+      if (whole) {
 #pragma unroll
-      for (int it = 0; it < SR_ONIT / 2; ++it) {
-        const bool ok = (int)((opk[h + it] >> 16) & 0xFFu) < hy && (int)(opk[h + it] >> 24) < hx;
-        __builtin_amdgcn_raw_buffer_store_b128(v[it], ry, ok ? base + oglo[h + it] : 0xFFFFFFF0u, 0, 0);
+        for (int it = 0; it < SR_ONIT / 2; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], ry, oglo[h + it], base, 0);
+      } else {
+#pragma unroll
+        for (int it = 0; it < SR_ONIT / 2; ++it) {
+          const bool ok = (int)((opk[h + it] >> 16) & 0xFFu) < hy && (int)(opk[h + it] >> 24) < hx;
+          __builtin_amdgcn_raw_buffer_store_b128(v[it], ry, ok ? base + oglo[h + it] : 0xFFFFFFF0u, 0, 0);
+        }
       }
     }
   };
-  // ---- pipeline head: patch 0 into buffer 0, patch 1 requested
-  load_patch(0);
-  store_patch(0);
-  load_patch(1);
+  // ---- pipeline head: patch 0 into buffer 0, patches 1 and 2 requested
+  load_patch(0, stA, svA);
+  load_patch(1, stB, svB);
+  store_patch(0, stA, svA);
+  load_patch(2, stA, svA);
   sr_barrier();
-  for (int n = 0; n < nt; ++n) {
-    store_patch((n + 1) & 1);                         // patch n + 1 (requested a step ago) -> the buffer tile n - 1 used
-    load_patch(n + 2);                                // patch n + 2: in flight across the barrier
+  SR_TRACE_DECL;
+  auto phase = [&](int n, u32x4 (&st)[SR_NIT], unsigned& stv) __attribute__((always_inline)) {
+#ifdef SLV_SR_TRACE
+    asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    SR_STAMP(0);                                      // waiting for patch n + 1
+#endif
+    store_patch((n + 1) & 1, st, stv);                // patch n + 1 (requested two steps ago) -> the buffer tile n - 1 used
+    SR_STAMP(1);
     store_out(n - 2);                                 // output tile n - 2: complete since the last barrier
+    SR_STAMP(2);
+    // (stores BEFORE the loads: vmcnt counts both, the compiler's counted waits for patch n + 2 in the next step assume only
+    // the 13 loads of patch n + 3 are younger -- with the 20 stores behind them the wait would reach into patch n + 3)
+    load_patch(n + 3, st, stv);                       // patch n + 3: in flight across two barriers
+    SR_STAMP(3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SR_STAMP(4);
     sr_barrier();
+    SR_STAMP(5);
+  };
+  for (int n = 0; n < nt; n += 2) {
+    phase(n, stB, svB);
+    if (n + 1 < nt) phase(n + 1, stA, svA);
   }
   store_out(nt - 2);
   sr_barrier();                                       // the MFMA waves have written the last output tile
   store_out(nt - 1);
+  SR_STAMP(6);
+  SR_TRACE_OUT;
 }
 
 static bool sr_enabled() {
