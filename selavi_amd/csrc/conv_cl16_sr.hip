@@ -135,38 +135,31 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) stS[i][r] = stQ[i][r] = 0.f;
-    // The epilogue of tile n - 1 (round to bf16 into the output tile, statistics) is cut into 72 STEPS of <= 3 VALU
-    // instructions -- 6 per accumulator tile -- and ONE step rides behind every third MFMA of tile n (two accumulator
-    // sets, the loop unrolled by two).  An in-order wave cannot issue past a waiting MFMA, and the matrix pipe holds one
-    // 16-cycle MFMA: a 25-instruction item behind every 7th MFMA (rounds 3-4) left the pipe idle for ~85 cycles per item =
-    // 1 000 of a tile's 5 100 cycles (tools/sr_trace.py); three VALU instructions fit the 12 issue cycles an MFMA leaves.
-    constexpr int SR_STEPS = 72, SR_EVERY = 3;
+    // The epilogue of tile n - 1 (round to bf16 into the output tile, statistics) is cut into single instructions and ONE
+    // rides behind each MFMA of tile n (two accumulator sets, the loop unrolled by two).  Measured on this chip
+    // (tools/proto/mfma_fill_bench.hip, one wave per SIMD): back-to-back v_mfma_f32_16x16x32_bf16 issue every 18.0 cycles;
+    // one independent VALU instruction behind each costs +0.7 cycles, two +1.0, THREE +5, four +13 -- and a taken branch
+    // ~30.  Rounds 3-4 placed a 25-instruction item behind every 7th MFMA: 1 000 of the tile's 5 100 cycles
+    // (tools/sr_trace.py); three-instruction steps behind every third MFMA still cost 630.
+    constexpr int SR_SUB = EPI == 1 ? 17 : 3, SR_STEPS = 12 * SR_SUB;       // 204 (36) of the tile's 216 MFMA slots
     unsigned dlo = 0, dhi = 0;
-    float dv0 = 0.f, dv1 = 0.f;
+    float dv = 0.f;
     unsigned keep[4] = {~0u, ~0u, ~0u, ~0u};          // ragged tiles: pixels outside the image count as zero in the statistics
     auto drain_step = [&](int st, f32x4 (&pv)[3][4], unsigned char* ost) __attribute__((always_inline)) {
-      const int a = st / 6, sub = st - a * 6, i = a >> 2, nn = a & 3;
-      if (sub == 0) {
-        dlo = pack_bf2(pv[i][nn][0], pv[i][nn][1]);
-        dhi = pack_bf2(pv[i][nn][2], pv[i][nn][3]);
-      } else if (sub == 1) {
-        if constexpr (EPI == 1) dlo &= keep[nn], dhi &= keep[nn];   // (no branch: a taken branch idles the matrix pipe ~30 cycles)
+      const int a = st / SR_SUB, sub = st - a * SR_SUB, i = a >> 2, nn = a & 3;
+      if (sub == 0) dlo = pack_bf2(pv[i][nn][0], pv[i][nn][1]);
+      else if (sub == 1) dhi = pack_bf2(pv[i][nn][2], pv[i][nn][3]);
+      else if constexpr (EPI == 0) {
         *(uint2*)(ost + obase + nn * 16 * SR_OROW + i * 32) = make_uint2(dlo, dhi);
-      } else if constexpr (EPI == 1) {                // (asm: left to itself hipcc SLP-packs adjacent sums into v_pk_add_f32 /
-        if (sub == 2) {                               // v_pk_fma_f32, and ONE packed f32 instruction beside MFMAs costs 22-26
-          dv0 = bf_lo(dlo), dv1 = bf_hi(dlo);         // cycles of matrix-pipe time: 24 of them per tile were the 1 000 cycles
-          sr_add(stS[i][0], dv0);                     // the statistics used to cost)
-        } else if (sub == 3) {
-          sr_add(stS[i][1], dv1);
-          sr_sq(stQ[i][0], dv0);
-          sr_sq(stQ[i][1], dv1);
-        } else if (sub == 4) {
-          dv0 = bf_lo(dhi), dv1 = bf_hi(dhi);
-          sr_add(stS[i][2], dv0);
-        } else {
-          sr_add(stS[i][3], dv1);
-          sr_sq(stQ[i][2], dv0);
-          sr_sq(stQ[i][3], dv1);
+      } else {                                        // (asm: left to itself hipcc SLP-packs adjacent sums into v_pk_add_f32 /
+        if (sub == 2) dlo &= keep[nn];                // v_pk_fma_f32: an anti-lever beside MFMAs)
+        else if (sub == 3) dhi &= keep[nn];
+        else if (sub == 4) *(uint2*)(ost + obase + nn * 16 * SR_OROW + i * 32) = make_uint2(dlo, dhi);
+        else {
+          const int e = (sub - 5) / 3, w = (sub - 5) % 3;      // element e of the tile's four, instruction w of its three
+          if (w == 0) dv = e == 0 ? bf_lo(dlo) : e == 1 ? bf_hi(dlo) : e == 2 ? bf_lo(dhi) : bf_hi(dhi);
+          else if (w == 1) sr_add(stS[i][e], dv);
+          else sr_sq(stQ[i][e], dv);
         }
       }
     };
@@ -184,30 +177,31 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
       const SrTile tl = tile_of(n > 0 ? n - 1 : 0);
       unsigned char* const ost = outb + ((n & 1) ^ 1) * SR_OUT;   // tile n - 1's output tile
       set_keep(tl);
-      // 18 MFMA groups (tap, chunk); the fragments of group g + 1 are requested before the MFMAs of group g (two
-      // register sets), so that no MFMA waits for an LDS read
+      // 18 MFMA groups (tap, chunk) of 12; the four fragments of group g + 1 are requested behind MFMAs 0, 2, 4, 6 of
+      // group g (two register sets): no MFMA waits for an LDS read, no slot carries more than two instructions
       bf16x8 b[2][4];
-      auto read_b = [&](int gi, bf16x8* to) __attribute__((always_inline)) {
+      auto read_b1 = [&](int gi, int nn, bf16x8* to) __attribute__((always_inline)) {
         const int t = gi >> 1, c = gi & 1;
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
-          to[nn] = *(const bf16x8*)(src + ((2 * nn + t / 3) * SR_PITCH + (t % 3)) * SR_ROWB + c * 64);
+        to[nn] = *(const bf16x8*)(src + ((2 * nn + t / 3) * SR_PITCH + (t % 3)) * SR_ROWB + c * 64);
       };
-      read_b(0, b[0]);
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) read_b1(0, nn, b[0]);
 #pragma unroll
       for (int gi = 0; gi < 18; ++gi) {
-        if (gi + 1 < 18) read_b(gi + 1, b[(gi + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int nn = 0; nn < 4; ++nn) {
             if (gi == 0) sr_mfma0(acc[i][nn], A[gi >> 1][gi & 1][i], b[gi & 1][nn]);
             else sr_mfma(acc[i][nn], A[gi >> 1][gi & 1][i], b[gi & 1][nn]);
-            const int m = gi * 12 + i * 4 + nn;       // MFMA index within the tile
-            if (m % SR_EVERY == SR_EVERY - 1 && m / SR_EVERY < SR_STEPS) {
-              if (SLV_SR_ABL != 4) drain_step(m / SR_EVERY, pv, ost);
-              if (SLV_SR_ABL != 5) __builtin_amdgcn_sched_barrier(0);
-            }
+            const int q = i * 4 + nn;                 // MFMA index within the group
+            if (gi + 1 < 18 && q < 8 && (q & 1) == 0) read_b1(gi + 1, q >> 1, b[(gi + 1) & 1]);
+            // (tried: no epilogue instruction in the slots that also carry a fragment read and an s_waitcnt, two in the
+            // slots 5 / 7 instead -- 4 635 -> 4 760 cycles per tile: the statistics cost ~4.5 cycles per VALU instruction
+            // wherever they sit once the stream also carries the fragment reads)
+            const int m = gi * 12 + q;
+            if (m < SR_STEPS && SLV_SR_ABL != 4) drain_step(m, pv, ost);
+            if (SLV_SR_ABL != 5) __builtin_amdgcn_sched_barrier(0);
           }
       }
       SR_STAMP(0);                                    // the tile's MFMAs + the previous tile's epilogue items

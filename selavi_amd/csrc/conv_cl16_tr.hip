@@ -59,6 +59,12 @@ __device__ __forceinline__ void tr_mfma_settle() {
 #endif
 }
 
+#ifdef SLV_TR_TRACE      // timing only (tools/tr_trace.py): s_memtime ticks per section of a step, summed over the wave's steps, written
+#define TR_STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); trc[i] += t_ - tlast; tlast = t_; } while (0)
+#else                    // over the head of y at the end of the kernel
+#define TR_STAMP(i) do { } while (0)
+#endif
+
 // MT: 16-row tiles of output channels (all of them: Mrows == 16 MT); KC: 32-channel chunks of the input (Cin_p / 32).
 // PRO 1: rows are read as relu(x * s + h).  EPI 0: y = acc -> bf16.  EPI 1: + per-channel sum / sum of squares of the
 // rounded outputs, one partial per column: stat_sum / stat_sq [Cout][ncol].  EPI 3 (backward data whose BatchNorm-backward
@@ -224,6 +230,9 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
 #pragma unroll
   for (int i = 0; i < MT; ++i) accS[i] = accQ[i] = 0.f;
   // one step: `cur` = register set holding step s + 2 (requested one step ago), `nxt` = the set step s + 3 goes to
+#ifdef SLV_TR_TRACE
+  unsigned long long trc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
   auto step = [&](u32x4* cur, unsigned& vcur, u32x4* nxt, unsigned& vnxt) __attribute__((always_inline)) {
     load_frame(pf, nxt, vnxt);                        // two frames in flight behind this step's MFMAs
     advance(pf);
@@ -242,6 +251,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
       }
     }
     const int sprev = slot == 0 ? 2 : slot - 1, snext = slot == 2 ? 0 : slot + 1;
+    TR_STAMP(0);                                      // requests issued
     f32x4 acc[MT][2];
     int pi = 0;                                       // next staged piece to get its BatchNorm + ReLU
 #pragma unroll
@@ -277,8 +287,10 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
 #endif
       }
     }
+    TR_STAMP(1);                                      // the MFMAs (and the fragment reads they wait for)
 #pragma unroll
     for (; pi < NIT; ++pi) affine_piece(cur, vcur, pi);
+    TR_STAMP(2);                                      // the wait for the staged frame + its BatchNorm + ReLU
     // ---- epilogue of the step: bf16 tile [pixel][cout] through LDS
     tr_mfma_settle();
 #pragma unroll
@@ -289,6 +301,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
         *(uint2*)(ost + (nn * 16 + fr) * orow + (i * 16 + fk * 4) * 2) = make_uint2(lo, hi);
       }
     store_frame(sprev, cur);                          // step s + 2 takes the slot of step s - 1: no longer read
+    TR_STAMP(3);                                      // output tile + staged frame into LDS
     if constexpr (EPI == 1) {                         // statistics of the 32 rounded rows on the matrix cores
       if (cc.px0 + TR_PX > HW) {                      // ragged last block of a frame: rows without a pixel count as zero
         const int valid = HW - cc.px0;
@@ -297,6 +310,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
       }
       wave_rows32_stats_acc<MT>(ost, orow, lane, accS, accQ);
     }
+    TR_STAMP(4);                                      // statistics
     {
       const unsigned obase = (cc.pos0 + (unsigned)cc.t * HW) * out_row + opiece * 16u;
       if constexpr (EPI == 3) {
@@ -346,11 +360,18 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
     }
     advance(cc);
     slot = snext;
+    TR_STAMP(5);                                      // output rows to memory (EPI 3: + the BatchNorm-backward apply)
   };
   for (int s = 0; s < S; s += 2) {
     step(ra, va, rb, vb);
     if (s + 1 < S) step(rb, vb, ra, va);
   }
+#ifdef SLV_TR_TRACE
+  if (lane == 0) {
+    unsigned long long* o_ = (unsigned long long*)y + blockIdx.x * 8;
+    for (int i_ = 0; i_ < 8; ++i_) o_[i_] = i_ == 7 ? (unsigned long long)S : trc[i_];
+  }
+#endif
 }
 
 static bool tr_enabled() {
