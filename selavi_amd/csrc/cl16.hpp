@@ -37,6 +37,14 @@ __device__ __forceinline__ unsigned relu_bf2(unsigned v) {
 // backward kernels must reproduce the forward's sign decision bit for bit.
 __device__ __forceinline__ float bn_affine(float x, float s, float h) { return __builtin_fmaf(x, s, h); }
 
+// Results of inline-asm MFMAs are invisible to the compiler's hazard recognizer: "s_nop 15; s_nop 7" between the last MFMA and
+// the first VALU read.  The asm's memory clobber orders MEMORY operations only -- a v_cvt_pk of an accumulator is free to be
+// scheduled in front of the nops (round 5: conv_cl16_tr's last accumulator tile of a step came out as garbage after an
+// unrelated change to the code behind it).  mfma_pin() makes the accumulator an output of an (empty) asm statement behind
+// the nops: every read of it stays behind.
+__device__ __forceinline__ void mfma_settle_nops() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+__device__ __forceinline__ void mfma_pin(f32x4& a) { asm volatile("" : "+v"(a)); }
+
 // relu(x*s + h) on the 8 bf16 of a 16-byte piece; s, h: the piece's 8 channels
 __device__ __forceinline__ u32x4 affine_relu8(u32x4 v, const float* s, const float* h) {
   u32x4 o;
@@ -196,6 +204,8 @@ __device__ __forceinline__ void wave_rows32_stats_acc_asm(const unsigned char* r
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=v"(q[i]) : "v"(yv[i]));
   }
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // 8-pass XDL result -> VALU read
+#pragma unroll
+  for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(sm[i]), "+v"(q[i]));
   const bool e1 = fr & 1, e2 = fr & 2;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {

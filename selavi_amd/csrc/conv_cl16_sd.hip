@@ -254,7 +254,11 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned sho
     if (n + 1 < nst) tile_step(n + 1, accB, accA, true);
   }
   if (nst > 0) {                                      // the last tile's epilogue
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    mfma_settle_nops();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) mfma_pin(accA[i][nn]), mfma_pin(accB[i][nn]);
     const SdTile tl = tile_of(nst - 1);
     if constexpr (RES == 1) {
 #pragma unroll

@@ -44,7 +44,7 @@ constexpr int SR_ONIT = SR_OPIECES / 64;              // = 20 store instructions
 
 #ifndef SLV_SR_ABL
 #define SLV_SR_ABL 0      // timing ablations (results wrong): 1 no MFMAs (a VALU xor keeps the operands alive), 2 no global
-#endif                    // patch loads, 3 no output stores, 4 no epilogue at all, 5 no sched_barrier between MFMA groups
+#endif                    // patch loads, 3 no output stores, 4 no epilogue at all, 5 no sched_barrier between MFMA groups, 6 two fragment sets per tile
 __device__ __forceinline__ void sr_mfma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
 #if SLV_SR_ABL == 1
   acc[0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, b)[0]);
@@ -186,6 +186,10 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
       };
 #pragma unroll
       for (int nn = 0; nn < 4; ++nn) read_b1(0, nn, b[0]);
+      if (SLV_SR_ABL == 6) {                          // (ablation: no fragment reads inside the tile)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) read_b1(1, nn, b[1]);
+      }
 #pragma unroll
       for (int gi = 0; gi < 18; ++gi) {
 #pragma unroll
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
             if (gi == 0) sr_mfma0(acc[i][nn], A[gi >> 1][gi & 1][i], b[gi & 1][nn]);
             else sr_mfma(acc[i][nn], A[gi >> 1][gi & 1][i], b[gi & 1][nn]);
             const int q = i * 4 + nn;                 // MFMA index within the group
-            if (gi + 1 < 18 && q < 8 && (q & 1) == 0) read_b1(gi + 1, q >> 1, b[(gi + 1) & 1]);
+            if (gi + 1 < 18 && q < 8 && (q & 1) == 0 && SLV_SR_ABL != 6) read_b1(gi + 1, q >> 1, b[(gi + 1) & 1]);
             // (tried: no epilogue instruction in the slots that also carry a fragment read and an s_waitcnt, two in the
             // slots 5 / 7 instead -- 4 635 -> 4 760 cycles per tile: the statistics cost ~4.5 cycles per VALU instruction
             // wherever they sit once the stream also carries the fragment reads)
@@ -220,7 +224,11 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
       if (n + 1 < nt) tile_step(n + 1, accB, accA);
     }
     if (nt > 0) {                                     // the last tile's epilogue
-      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // 8-pass XDL result -> VALU read
+      mfma_settle_nops();                             // 8-pass XDL result -> VALU read
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) mfma_pin(accA[i][nn]), mfma_pin(accB[i][nn]);
       const SrTile tl = tile_of(nt - 1);
       unsigned char* const ost = outb + ((nt - 1) & 1) * SR_OUT;
       set_keep(tl);

@@ -84,15 +84,16 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
   constexpr int PPR = KC * 4;                         // 16-byte pieces per input row
   constexpr int RPI = 64 / PPR;                       // input rows one load instruction covers
   constexpr int NIT = (TR_PX + RPI - 1) / RPI;
-  constexpr int SLOT = KC * TR_PX * 64;               // bytes of one frame in the ring: [chunk][pixel][64 B]
+  constexpr int SLOT = KC * TR_PX * 64 + 1024;        // bytes of one frame in the ring: [chunk][pixel][64 B] + 1 KiB where the
+                                                      // idle lanes' pieces go (no branches, one address form for every lane)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const ring = lds;                    // 3 x SLOT
   unsigned char* const ost = lds + 3 * SLOT;          // [TR_PX][orow]
-  unsigned char* const dump = ost + TR_PX * (g.Cout_p * 2 + 16);      // 1 KiB: where idle lanes' pieces go (no branches)
   const int lane = threadIdx.x;
   const int fr = lane & 15, fk = lane >> 4;
   const int T = g.Ti, HW = g.Hi * g.Wi;
-  const int orow = g.Cout_p * 2 + 16;                 // bytes per pixel row of the output stage (+16: banks)
+  constexpr int COUTP = ((MT * 16 + 31) / 32) * 32;   // (Cout_p == COUTP: cl16_tr_applies)
+  constexpr int orow = COUTP * 2 + 16;                // bytes per pixel row of the output stage (+16: banks)
   const unsigned in_row = (unsigned)g.Cin_p * 2u, out_row = (unsigned)g.Cout_p * 2u;
   const unsigned Ptot = (unsigned)g.N * T * HW;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(Ptot * in_row), 0x00020000);
@@ -132,9 +133,19 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
   // fragment reads: lane (fr, fk) reads row n * 16 + fr, slot fk ^ swz(fr)  (swz(n * 16 + fr) == swz(fr))
   const int boff = fr * 64 + ((fk ^ cl_swz(fr)) << 4);
   // output store: the same 16-byte piece of rows olr, olr + ORPI, ...
-  const int oppr = g.Cout_p >> 3, orpi = 64 / oppr;
+  constexpr int oppr = COUTP >> 3, orpi = 64 / oppr, ONIT = (TR_PX + orpi - 1) / orpi;
   const int opiece = lane % oppr, olr = lane / oppr;
   const bool oact = lane < orpi * oppr;
+  unsigned ooff[ONIT];                                // (per lane and store instruction, as loff / sto / lrow above)
+  int olds[ONIT], orw[ONIT];
+#pragma unroll
+  for (int q = 0; q < ONIT; ++q) {
+    const int r = q * orpi + olr;
+    const bool in = oact && r < TR_PX;
+    ooff[q] = (unsigned)r * (COUTP * 2u) + opiece * 16u;
+    orw[q] = in ? r : 0x7FFFFFFF;
+    olds[q] = (r < TR_PX ? r : 0) * (COUTP * 2 + 16) + opiece * 16;
+  }
   float e_s[8], e_h[8], e_a1[8], e_a2[8], e_a3[8];
   if constexpr (EPI == 3) {
 #pragma unroll
@@ -180,16 +191,29 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
       col_of(c);
     }
   };
+  // per lane and load instruction (loop invariants; round 5 -- the trace of tools/tr_trace.py showed 870 cycles per step in
+  // front of the MFMAs for 11 requests whose offsets were rebuilt from the position every time, 1 340 behind them for the LDS
+  // stores with their swizzle, 1 270 for four dependent read-then-store rounds of the output rows): the byte offset of the
+  // piece relative to the frame's first pixel of the column, its place in a ring slot, the row it belongs to
+  unsigned loff[NIT];
+  int sto[NIT], lrow[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int r = lr + RPI * i;
+    const bool in = lact && r < TR_PX;
+    loff[i] = (unsigned)r * in_row + piece * 16u;
+    lrow[i] = in ? r : 0x7FFFFFFF;                    // (idle lanes: a row no frame has)
+    sto[i] = in ? wchunk * (TR_PX * 64) + r * 64 + ((wq ^ cl_swz(r)) << 4) : KC * TR_PX * 64 + lane * 16;
+  }
   auto load_frame = [&](const Cur& c, u32x4* st, unsigned& stv) __attribute__((always_inline)) {
     stv = 0;
+    // (the out-of-range marker does not survive a scalar offset -- the sum wraps back into the buffer: the base goes into
+    // the vector offset, three VALU instructions per request instead of eight)
+    const unsigned base = (c.pos0 + (unsigned)c.t * HW) * in_row;
+    const int left = HW - c.px0;                      // pixels of the frame from the column's first one (<= 0: no such step)
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int r = lr + RPI * i;
-      const bool ok = lact && r < TR_PX && c.px0 + r < HW;
-      stv |= (unsigned)ok << i;
-      const unsigned off = (c.pos0 + (unsigned)c.t * HW + r) * in_row + piece * 16u;
-      st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : 0xFFFFFFF0u, 0, 0));
-    }
+    for (int i = 0; i < NIT; ++i)
+      st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, lrow[i] < left ? base + loff[i] : 0xFFFFFFF0u, 0, 0));
   };
   auto affine_piece = [&](u32x4* st, unsigned stv, int i) __attribute__((always_inline)) {
     // (rows beyond the frame's pixels -- the ragged last block -- become relu(h) instead of zero: their outputs are
@@ -198,12 +222,10 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
     (void)stv;
   };
   auto store_frame = [&](int slot, const u32x4* st) __attribute__((always_inline)) {
-    unsigned char* dst = ring + slot * SLOT + wchunk * (TR_PX * 64);
+    unsigned char* dst = ring + slot * SLOT;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int r = lr + RPI * i;
-      unsigned char* to = (lact && r < TR_PX) ? dst + r * 64 + ((wq ^ cl_swz(r)) << 4) : dump + lane * 16;
-      *(u32x4*)to = st[i];
+      *(u32x4*)(dst + sto[i]) = st[i];
     }
   };
   u32x4 ra[NIT], rb[NIT];
@@ -239,16 +261,14 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
     // EPI 3: the x pieces this step's epilogue needs (160 stored channels: 3 rows per instruction, 11 instructions) are
     // requested HERE, in front of the step's MFMAs (requested inside the store loop they cost one memory round trip each:
     // 3.83 ms per launch)
-    constexpr int E3_NOIT = (TR_PX + 2) / 3;
+    constexpr int E3_NOIT = ONIT;
     u32x4 yv[EPI == 3 ? E3_NOIT : 1];
+    const unsigned obase = (cc.pos0 + (unsigned)cc.t * HW) * out_row;   // the step's first output row
+    const int oleft = HW - cc.px0;
     if constexpr (EPI == 3) {
-      const unsigned ob3 = (cc.pos0 + (unsigned)cc.t * HW) * out_row + opiece * 16u;
 #pragma unroll
-      for (int q = 0; q < E3_NOIT; ++q) {
-        const int r = 3 * q + olr;
-        const bool ok = oact && r < TR_PX && cc.px0 + r < HW;
-        yv[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rax, ok ? ob3 + (unsigned)r * out_row : 0xFFFFFFF0u, 0, 0));
-      }
+      for (int q = 0; q < E3_NOIT; ++q)
+        yv[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rax, orw[q] < oleft ? obase + ooff[q] : 0xFFFFFFF0u, 0, 0));
     }
     const int sprev = slot == 0 ? 2 : slot - 1, snext = slot == 2 ? 0 : slot + 1;
     TR_STAMP(0);                                      // requests issued
@@ -293,6 +313,10 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
     TR_STAMP(2);                                      // the wait for the staged frame + its BatchNorm + ReLU
     // ---- epilogue of the step: bf16 tile [pixel][cout] through LDS
     tr_mfma_settle();
+#if SLV_TR_ASM_MFMA
+#pragma unroll
+    for (int i = 0; i < MT; ++i) mfma_pin(acc[i][0]), mfma_pin(acc[i][1]);
+#endif
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -312,13 +336,10 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
     }
     TR_STAMP(4);                                      // statistics
     {
-      const unsigned obase = (cc.pos0 + (unsigned)cc.t * HW) * out_row + opiece * 16u;
       if constexpr (EPI == 3) {
 #pragma unroll
         for (int q = 0; q < E3_NOIT; ++q) {
-          const int r = 3 * q + olr;
-          const bool ok = oact && r < TR_PX && cc.px0 + r < HW;
-          u32x4 v = *(const u32x4*)(ost + (r < TR_PX ? r : 0) * orow + opiece * 16);
+          u32x4 v = *(const u32x4*)(ost + olds[q]);
           const u32x4 xv = yv[q];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -333,15 +354,15 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
             }
             v[i] = pack_bf2(o2[0], o2[1]);
           }
-          __builtin_amdgcn_raw_buffer_store_b128(v, ry, ok ? obase + (unsigned)r * out_row : 0xFFFFFFF0u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v, ry, orw[q] < oleft ? obase + ooff[q] : 0xFFFFFFF0u, 0, 0);
         }
       } else {
-        for (int r0 = 0; r0 < TR_PX; r0 += orpi) {    // (out-of-range offsets drop the store: no branches)
-          const int r = r0 + olr;
-          const bool ok = oact && r < TR_PX && cc.px0 + r < HW;
-          const u32x4 v = *(const u32x4*)(ost + (r < TR_PX ? r : 0) * orow + opiece * 16);
-          __builtin_amdgcn_raw_buffer_store_b128(v, ry, ok ? obase + (unsigned)r * out_row : 0xFFFFFFF0u, 0, 0);
-        }
+        u32x4 v[ONIT];                                // all reads of the output tile, then all stores
+#pragma unroll
+        for (int q = 0; q < ONIT; ++q) v[q] = *(const u32x4*)(ost + olds[q]);
+#pragma unroll
+        for (int q = 0; q < ONIT; ++q)                // (out-of-range offsets drop the store: no branches)
+          __builtin_amdgcn_raw_buffer_store_b128(v[q], ry, orw[q] < oleft ? obase + ooff[q] : 0xFFFFFFF0u, 0, 0);
       }
     }
     if constexpr (EPI == 1) {
@@ -405,7 +426,7 @@ bool cl16_tr_applies(const ClConv& g) {
     }();
     if (only_kc && g.Cin_p / 32 != only_kc) return false;
   }
-  if ((g.Mrows & 15) || !tr_shape(g.Mrows / 16, g.Cin_p / 32) || g.Cout_p > 160) return false;
+  if ((g.Mrows & 15) || !tr_shape(g.Mrows / 16, g.Cin_p / 32) || g.Cout_p != ((g.Mrows + 31) / 32) * 32) return false;
   if ((long long)g.N * g.Ti * g.Hi * g.Wi * (g.Cin_p > g.Cout_p ? g.Cin_p : g.Cout_p) * 2 >= 0xFFFFFFF0LL) return false;
   return true;
 }
@@ -419,7 +440,7 @@ bool cl16_tr_forward(const ClConv& g) { return (g.tap[0] & 15) - 8 + g.bot < 0; 
 template <int MT, int KC, int PRO, int EPI>
 static int tr_launch_one(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, float* stat_sum,
                          float* stat_sq, hipStream_t st, const void* ax = nullptr, const float* ab5 = nullptr) {
-  const size_t lds = 3 * (size_t)KC * TR_PX * 64 + (size_t)TR_PX * (g.Cout_p * 2 + 16) + 1024;
+  const size_t lds = 3 * ((size_t)KC * TR_PX * 64 + 1024) + (size_t)TR_PX * (g.Cout_p * 2 + 16);
   static bool attr_set = false;
   if (!attr_set) {
     SLV_HIP(hipFuncSetAttribute((const void*)conv_cl16_tr_kernel<MT, KC, PRO, EPI>,
