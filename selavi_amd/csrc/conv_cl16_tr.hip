@@ -24,6 +24,9 @@
 namespace slv {
 
 constexpr int TR_PX = 32;                       // pixels per wave tile: two 16-position MFMA fragments
+constexpr int TR_CHS = TR_PX * 64 + 64;         // bytes from a chunk of a ring slot to the next: + 16 banks, so that the four
+                                                // chunks one quarter of a staging store touches do not share their banks
+                                                // (2 048-byte chunks: every ds_write_b128 of a frame was a 4-way conflict)
 
 // acc += A * B with the A fragment held in the ACCUMULATOR half of the register file.  Left to itself hipcc parks the
 // 216-240 registers of resident weights in AGPRs as a spill area and copies every fragment back with four
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
   constexpr int PPR = KC * 4;                         // 16-byte pieces per input row
   constexpr int RPI = 64 / PPR;                       // input rows one load instruction covers
   constexpr int NIT = (TR_PX + RPI - 1) / RPI;
-  constexpr int SLOT = KC * TR_PX * 64 + 1024;        // bytes of one frame in the ring: [chunk][pixel][64 B] + 1 KiB where the
+  constexpr int SLOT = KC * TR_CHS + 1024;             // bytes of one frame in the ring: [chunk][pixel][64 B] + 1 KiB where the
                                                       // idle lanes' pieces go (no branches, one address form for every lane)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const ring = lds;                    // 3 x SLOT
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
     const bool in = lact && r < TR_PX;
     loff[i] = (unsigned)r * in_row + piece * 16u;
     lrow[i] = in ? r : 0x7FFFFFFF;                    // (idle lanes: a row no frame has)
-    sto[i] = in ? wchunk * (TR_PX * 64) + r * 64 + ((wq ^ cl_swz(r)) << 4) : KC * TR_PX * 64 + lane * 16;
+    sto[i] = in ? wchunk * TR_CHS + r * 64 + ((wq ^ cl_swz(r)) << 4) : KC * TR_CHS + lane * 16;
   }
   auto load_frame = [&](const Cur& c, u32x4* st, unsigned& stv) __attribute__((always_inline)) {
     stv = 0;
@@ -283,8 +286,8 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         if (live) {
-          const bf16x8 b0 = *(const bf16x8*)(src + c * (TR_PX * 64));
-          const bf16x8 b1 = *(const bf16x8*)(src + c * (TR_PX * 64) + 16 * 64);
+          const bf16x8 b0 = *(const bf16x8*)(src + c * TR_CHS);
+          const bf16x8 b1 = *(const bf16x8*)(src + c * TR_CHS + 16 * 64);
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
             if (jj == 0 && c == 0) {
@@ -440,7 +443,7 @@ bool cl16_tr_forward(const ClConv& g) { return (g.tap[0] & 15) - 8 + g.bot < 0; 
 template <int MT, int KC, int PRO, int EPI>
 static int tr_launch_one(const ClConv& g, const void* x, const void* wl, void* y, const float* in_ss, float* stat_sum,
                          float* stat_sq, hipStream_t st, const void* ax = nullptr, const float* ab5 = nullptr) {
-  const size_t lds = 3 * ((size_t)KC * TR_PX * 64 + 1024) + (size_t)TR_PX * (g.Cout_p * 2 + 16);
+  const size_t lds = 3 * ((size_t)KC * TR_CHS + 1024) + (size_t)TR_PX * (g.Cout_p * 2 + 16);
   static bool attr_set = false;
   if (!attr_set) {
     SLV_HIP(hipFuncSetAttribute((const void*)conv_cl16_tr_kernel<MT, KC, PRO, EPI>,
