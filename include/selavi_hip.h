@@ -341,6 +341,22 @@ int slv_to_cl16(const float* x, void* y_bf16, int64_t N, int C, int Cp, int64_t 
  * outside): a (1,kh,kw) conv over C <= 4 channels becomes a (1,kh,1) conv over 32 channels (kw * C <= 32) */
 int slv_to_cl16_wpatch(const float* x, void* y_bf16, int64_t N, int C, int64_t TH, int W, int kw, int sw, int pw,
                        slv_stream_t stream);
+/* The stem convs DIRECTLY from the fp32 clip / spectrogram (csrc/conv_cl16_stem.hip; round 5): Conv3d(Cin <= 3 -> 32 < Cout <= 64,
+ * (1,7,7), stride (1,2,2), padding (0,3,3)) -- torchvision's R(2+1)D / ResNet stems, /root/reference/model.py:93-114 -- without
+ * the W-patch tensor of slv_to_cl16_wpatch.  x: fp32 [N][Cin][T][H][W] (W <= 112); w: the fp32 master weights
+ * [Cout][Cin][1][7][7]; y: bf16 [N][T][Ho][Wo][64]; stat_sum / stat_sq (both or neither): [Cout][slv_cl16_stem_nblk()] partial
+ * sums / sums of squares of the rounded outputs (BatchNorm statistics, as slv_cl16_conv's).  slv_cl16_stem_ok: 1 when the
+ * direct kernels take the geometry (SELAVI_CL16_STEM=0 switches them off: the W-patch path of rounds 1-4). */
+int32_t slv_cl16_stem_ok(int N, int Cin, int T, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw);
+int32_t slv_cl16_stem_nblk(int N, int Cin, int T, int H, int W, int Cout);
+int slv_cl16_stem_fwd(const float* x, const float* w, void* y_bf16, float* stat_sum, float* stat_sq, int N, int Cin, int T,
+                      int H, int W, int Cout, slv_stream_t stream);
+/* ... and its weight gradient: dy bf16 [N][T][Ho][Wo][64] (the gradient w.r.t. the conv's raw output), dw fp32
+ * [Cout][Cin][1][7][7] (the reference layout), ws: slv_cl16_stem_wgrad_ws_bytes() of scratch (per-workgroup partials,
+ * summed in a fixed order: deterministic). */
+size_t slv_cl16_stem_wgrad_ws_bytes(int N, int Cin, int T, int H, int W, int Cout);
+int slv_cl16_stem_wgrad(const float* x, const void* dy_bf16, float* dw, float* ws, size_t ws_bytes, int N, int Cin, int T, int H,
+                        int W, int Cout, slv_stream_t stream);
 /* MaxPool2d(3, 2, 1) on [N][H][W][Cp] bf16; AdaptiveAvgPool(1)+flatten: [N][S][Cp] bf16 -> fp32 [N][C] */
 int slv_maxpool_cl16(const void* x_bf16, void* y_bf16, int64_t N, int H, int W, int Cp, slv_stream_t stream);
 int slv_avgpool_cl16(const void* x_bf16, float* y, int64_t N, int64_t S, int C, int Cp, slv_stream_t stream);

@@ -122,6 +122,8 @@ from . import ops as _ops
 # layer-1 backward-data launches +300 us against the 45-110 us of the separate coalesced reduce pass it replaces
 # (profiles/r02_notes.md); SELAVI_CL16_FUSE_BNR=1 switches it on.
 FUSE_BNR = os.environ.get("SELAVI_CL16_FUSE_BNR", "0") == "1"
+# the stem's weight gradient on the direct kernel as well (then no W-patch tensor exists in the step)
+STEM_DIRECT_WGRAD = os.environ.get("SELAVI_CL16_STEM_WGRAD", "1") == "1"
 bn_train_finalize = _ops.bn_train_finalize
 bn_train_finalize_many = _ops.bn_train_finalize_many
 bn_eval_params = _ops.bn_eval_params
@@ -195,10 +197,14 @@ class Plan16:
         self.w_shape_taps = k[0] * k[1] * k[2]
         self.Cin_w, self.Cout = Cin, Cout                  # channel counts of the fp32 weight tensor
         self.patch_kw = 0
+        self.stem_direct = False
         if stem:                                           # (1,kh,kw) over Cin -> (1,kh,1) over the 32 patch channels
             assert k[0] == 1 and stride[0] == 1 and pad[0] == 0 and k[2] * Cin <= 32
             self.patch_kw, self.patch_sw, self.patch_pw = k[2], stride[2], pad[2]
             self.src_shape = (N, Cin, Ti, Hi, Wi)
+            # the direct kernels (csrc/conv_cl16_stem.hip): the fp32 clip staged in LDS band by band, no W-patch tensor
+            self.stem_direct = bool(C.slv_cl16_stem_ok(N, Cin, Ti, Hi, Wi, Cout, k[1], k[2], stride[1], stride[2], pad[1], pad[2]))
+            self.stem_nblk = C.slv_cl16_stem_nblk(N, Cin, Ti, Hi, Wi, Cout) if self.stem_direct else 0
             Wi = (Wi + 2 * pad[2] - k[2]) // stride[2] + 1
             Cin = k[2] * Cin
             k, stride, pad = (1, k[1], 1), (1, stride[1], 1), (0, pad[1], 0)
@@ -296,6 +302,8 @@ def _patch(plan, x):
 def conv_w_transform(plan, w, need_wf=True, need_wt=True):
     """fp32 master weights -> the bf16 layouts of this step (one launch): (wf, wt)."""
     need_wt = need_wt and not plan.stem
+    if plan.stem and plan.stem_direct and STEM_DIRECT_WGRAD:
+        return None, None                             # (the direct kernels read the fp32 master weights themselves)
     wf = _bf16(plan.wf_elems, device=w.device) if need_wf else None
     wt = _bf16(plan.wt_elems, device=w.device) if need_wt else None
     if wf is not None or wt is not None:
@@ -367,13 +375,24 @@ class WeightImages:
 
 def stem_patch(plan, x):
     """The W-patch image of the fp32 clip / spectrogram a stem conv reads (made once per step: the forward and the weight
-    gradient both take it through ``patch=``)."""
-    return _patch(plan, x) if plan.stem else None
+    gradient both take it through ``patch=``).  None on the direct kernels (Plan16.stem_direct), which read the clip itself."""
+    return _patch(plan, x) if plan.stem and not (plan.stem_direct and STEM_DIRECT_WGRAD) else None
 
 
 def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True, wf=None, out=None, patch=None):
     """y = conv(relu(x*s+h)) on the MFMA kernel; returns (y, stat_sum, stat_sq) with [Cout][nblk] partials."""
     assert (in_ss is not None) == bool(in_relu), "the load prologue is BatchNorm + ReLU"
+    if plan.stem and plan.stem_direct:
+        assert in_ss is None and plan.chunks is None
+        y = out if out is not None else _bf16(*plan.out_shape, device=x.device)
+        ssum = ssq = None
+        if want_stats:
+            ssum = torch.empty(plan.Cout, plan.stem_nblk, dtype=torch.float32, device=x.device)
+            ssq = torch.empty_like(ssum)
+        N, Cc, T, H, W = plan.src_shape
+        C.slv_cl16_stem_fwd(ptr(x.contiguous()), ptr(w.contiguous()), ptr(y), ptr(ssum), ptr(ssq), N, Cc, T, H, W, plan.Cout,
+                            stream())
+        return y, ssum, ssq
     if wf is None:
         wf, _ = conv_w_transform(plan, w, need_wt=False)
     if plan.stem:
@@ -483,6 +502,12 @@ def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, 
         C.slv_cl16_wgrad_bnr(plan.g_wgrad.ctypes.data, ptr(dy), ptr(x_in), ptr(in_ss), ptr(mi), ptr(w.contiguous()), ptr(dw),
                              ptr(part), plan.Cout, ptr(ws), plan.ws_wgrad_bnr, stream())
         return dw, part
+    if plan.stem and plan.stem_direct and STEM_DIRECT_WGRAD and patch is None:
+        N, Cc, T, H, W = plan.src_shape
+        nb = C.slv_cl16_stem_wgrad_ws_bytes(N, Cc, T, H, W, plan.Cout)
+        ws = _ops.workspace(nb, dy.device)
+        C.slv_cl16_stem_wgrad(ptr(x_in.contiguous()), ptr(dy), ptr(dw), ptr(ws), nb, N, Cc, T, H, W, plan.Cout, stream())
+        return dw
     if plan.stem:
         x_in = patch if patch is not None else _patch(plan, x_in)
     if plan.chunks is not None:

@@ -386,6 +386,44 @@ def test_stem_patch_conv_forward_and_weight_gradient():
     assert float((gotw - wantw).abs().max()) <= 2e-5 * float(wantw.abs().max())
 
 
+STEM_CASES = [  # N, Cin, T, H, W, Cout: 7 x 7, stride 2, padding 3 -> the direct kernels (csrc/conv_cl16_stem.hip)
+    (2, 3, 3, 40, 40, 45),        # three bands (8, 8, 4 rows), three column groups (8, 8, 4)
+    (1, 3, 2, 112, 112, 45),      # the video stem's frame: 7 bands x 7 column groups, the staged row used to its end
+    (2, 1, 1, 129, 100, 64),      # the audio stem: one channel, odd height (65 output rows: a band of one row), 64 channels
+    (6, 3, 24, 64, 24, 45),       # 576 bands on 512 persistent workgroups: the request pipeline across bands
+    (1, 2, 1, 7, 9, 40),          # smaller than one band, two channels
+]
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_stem_direct_forward_and_weight_gradient(case):
+    """The stem convs straight from the fp32 clip (no W-patch tensor): forward + BatchNorm statistics of the rounded outputs
+    against conv3d on the bf16-rounded operands; the weight gradient in the reference's [Cout][Cin][1][7][7] layout."""
+    from selavi_amd import ops16
+    N, Cin, T, H, W, Cout = case
+    k, st, pd = (1, 7, 7), (1, 2, 2), (0, 3, 3)
+    g = torch.Generator().manual_seed(17 + H)
+    x = torch.randn(N, Cin, T, H, W, generator=g)                      # NOT pre-rounded: the kernel rounds on the way in
+    w = torch.randn(Cout, Cin, *k, generator=g) * 0.1
+    plan = ops16.plan_for(x.cuda(), _Conv(Cin, Cout, k, st, pd))
+    assert plan.stem and plan.stem_direct
+    y, ssum, ssq = ops16.conv_fwd(plan, x.cuda(), w.cuda(), want_stats=True)
+    assert y.shape == plan.out_shape and (y[..., Cout:] == 0).all()
+    want = F.conv3d(_bf(x).double(), _bf(w).double(), stride=st, padding=pd)
+    got = _ncthw(y, Cout).double()
+    assert ((got - want).abs() <= want.abs() * 2.0 ** -8 + 1e-3 * want.abs().max()).all()
+    np.testing.assert_allclose(ssum.double().sum(1).cpu(), got.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(ssq.double().sum(1).cpu(), (got * got).sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
+    y2, _, _ = ops16.conv_fwd(plan, x.cuda(), w.cuda(), want_stats=False)
+    assert torch.equal(y, y2)
+    dy = _bf(torch.randn(want.shape, generator=g))
+    wv = torch.zeros(Cout, Cin, *k, dtype=torch.float64, requires_grad=True)
+    (wantw,) = torch.autograd.grad(F.conv3d(_bf(x).double(), wv, stride=st, padding=pd), wv, dy.double())
+    dw = ops16.conv_wgrad(plan, _cl(dy), x.cuda())
+    gotw = dw.view(Cout, Cin, *k).double().cpu()
+    assert float((gotw - wantw).abs().max()) <= 2e-5 * float(wantw.abs().max()) * max(1.0, (N * T * H * W / 2640.0) ** 0.5)
+
+
 @pytest.mark.parametrize("C,shape", [(144, (2, 3, 6, 5)), (45, (1, 2, 4, 4)), (921, (1, 2, 3, 3)), (64, (3, 4, 7, 9))])
 def test_batchnorm_kernels_channels_last(C, shape):
     """slv_cl16_bn_act / _bn_bwd_reduce / _bn_bwd_apply against their definitions (csrc/elementwise.hip semantics)."""
