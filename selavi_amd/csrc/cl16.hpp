@@ -37,6 +37,13 @@ __device__ __forceinline__ unsigned relu_bf2(unsigned v) {
 // backward kernels must reproduce the forward's sign decision bit for bit.
 __device__ __forceinline__ float bn_affine(float x, float s, float h) { return __builtin_fmaf(x, s, h); }
 
+// cache-policy operand of the buffer accesses that stream a tensor exactly once (outputs of the register-resident convs, the
+// temporal kernel's input rows): 2 = non-temporal
+#ifndef SLV_CL16_NT
+#define SLV_CL16_NT 1
+#endif
+constexpr int CL_NT = SLV_CL16_NT ? 2 : 0;
+
 // Results of inline-asm MFMAs are invisible to the compiler's hazard recognizer: "s_nop 15; s_nop 7" between the last MFMA and
 // the first VALU read.  The asm's memory clobber orders MEMORY operations only -- a v_cvt_pk of an accumulator is free to be
 // scheduled in front of the nops (round 5: conv_cl16_tr's last accumulator tile of a step came out as garbage after an

@@ -24,6 +24,15 @@
 #include "cl16.hpp"
 #include "../../include/selavi_hip.h"
 
+#ifndef SLV_DMA_NT
+#define SLV_DMA_NT 0      // 1: the LDS-DMA requests of the streamed operand carry the non-temporal hint (A/B: r05 notes)
+#endif
+#if SLV_DMA_NT
+#define SLV_DMA_NT_STR " nt"
+#else
+#define SLV_DMA_NT_STR ""
+#endif
+
 namespace slv {
 
 constexpr int SD_T = 8, SD_PW = 10;
@@ -49,7 +58,7 @@ __device__ __forceinline__ void sd_mfma0_a(f32x4& acc, const bf16x8& a, const bf
 // one LDS-DMA instruction: 64 lanes x 16 bytes from memory (per-lane byte offset voff into the buffer rsrc) to the
 // wave-uniform LDS address lds_addr + 16 lane.  Invisible to the compiler's wait-count bookkeeping (on purpose).
 __device__ __forceinline__ void sd_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" SLV_DMA_NT_STR " lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
 }
 
 struct SdTile {
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned sho
         carry = *(const u32x4*)(ost + (k * 16 + spx) * SD_OROW + spiece * 16);
       } else {
         const unsigned tb = (tl.fpos + (unsigned)(tl.y0 * W + tl.x0)) * (SD_COUT * 2u);
-        __builtin_amdgcn_raw_buffer_store_b128(carry, ry, tl.live ? tb + soff[k] : 0xFFFFFFF0u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(carry, ry, tl.live ? tb + soff[k] : 0xFFFFFFF0u, 0, CL_NT);
       }
     }
   };

@@ -357,12 +357,12 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
       for (int it = 0; it < SR_ONIT / 2; ++it) v[it] = *(const u32x4*)(src + (opk[h + it] & 0xFFFFu));
       if (whole) {
 #pragma unroll
-        for (int it = 0; it < SR_ONIT / 2; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], ry, oglo[h + it], base, 0);
+        for (int it = 0; it < SR_ONIT / 2; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], ry, oglo[h + it], base, CL_NT);
       } else {
 #pragma unroll
         for (int it = 0; it < SR_ONIT / 2; ++it) {
           const bool ok = (int)((opk[h + it] >> 16) & 0xFFu) < hy && (int)(opk[h + it] >> 24) < hx;
-          __builtin_amdgcn_raw_buffer_store_b128(v[it], ry, ok ? base + oglo[h + it] : 0xFFFFFFF0u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v[it], ry, ok ? base + oglo[h + it] : 0xFFFFFFF0u, 0, CL_NT);
         }
       }
     }

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, MT == 3 ? 2 : 1) void cl16_stem_fwd_kernel(con
         const int oy = oy0 + 2 * rp + (pos >> 3), ox = cg * 8 + (pos & 7);
         const bool ok = oy < g.Ho && ox < g.Wo;
         const unsigned off = ((unsigned)((fr * g.Ho + oy) * g.Wo + ox)) * 128u + pc8 * 16u;
-        __builtin_amdgcn_raw_buffer_store_b128(v, ry, ok ? off : 0xFFFFFFF0u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, ry, ok ? off : 0xFFFFFFF0u, 0, CL_NT);
       }
     }
     __syncthreads();                                  // every wave has read the image: the next band may overwrite it

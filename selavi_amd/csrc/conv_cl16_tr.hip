@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
     const int left = HW - c.px0;                      // pixels of the frame from the column's first one (<= 0: no such step)
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
-      st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, lrow[i] < left ? base + loff[i] : 0xFFFFFFF0u, 0, 0));
+      st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, lrow[i] < left ? base + loff[i] : 0xFFFFFFF0u, 0, CL_NT));
   };
   auto affine_piece = [&](u32x4* st, unsigned stv, int i) __attribute__((always_inline)) {
     // (rows beyond the frame's pixels -- the ragged last block -- become relu(h) instead of zero: their outputs are
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
             }
             v[i] = pack_bf2(o2[0], o2[1]);
           }
-          __builtin_amdgcn_raw_buffer_store_b128(v, ry, orw[q] < oleft ? obase + ooff[q] : 0xFFFFFFF0u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v, ry, orw[q] < oleft ? obase + ooff[q] : 0xFFFFFFF0u, 0, CL_NT);
         }
       } else {
         u32x4 v[ONIT];                                // all reads of the output tile, then all stores
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
         for (int q = 0; q < ONIT; ++q) v[q] = *(const u32x4*)(ost + olds[q]);
 #pragma unroll
         for (int q = 0; q < ONIT; ++q)                // (out-of-range offsets drop the store: no branches)
-          __builtin_amdgcn_raw_buffer_store_b128(v[q], ry, orw[q] < oleft ? obase + ooff[q] : 0xFFFFFFF0u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v[q], ry, orw[q] < oleft ? obase + ooff[q] : 0xFFFFFFF0u, 0, CL_NT);
       }
     }
     if constexpr (EPI == 1) {

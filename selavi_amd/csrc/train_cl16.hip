@@ -390,6 +390,23 @@ __global__ __launch_bounds__(256) void cl16_maxpool_bwd_kernel(const unsigned sh
 }
 
 
+#ifndef SLV_EW_NT
+#define SLV_EW_NT 1       // 1: the elementwise passes read / write their streams with the non-temporal hint (A/B: see r05 notes)
+#endif
+__device__ __forceinline__ u32x4 ew_ld(const unsigned short* p) {
+#if SLV_EW_NT
+  return __builtin_nontemporal_load((const u32x4*)p);
+#else
+  return *(const u32x4*)p;
+#endif
+}
+__device__ __forceinline__ void ew_st(unsigned short* p, u32x4 v) {
+#if SLV_EW_NT
+  __builtin_nontemporal_store(v, (u32x4*)p);
+#else
+  *(u32x4*)p = v;
+#endif
+}
 // ------------------------------------------------------------------------------------------ BatchNorm, channels last
 // Elementwise kernels on [P][Cp] bf16: one thread per 16-byte piece (8 channels).  The grid stride (gridDim.x * 256) is a
 // multiple of Cp/8 (cl16_ew_blocks), so a thread keeps ITS 8 channels for every position it visits and loads their
@@ -414,9 +431,9 @@ __global__ __launch_bounds__(256) void cl16_bn_act_kernel(const unsigned short* 
   }
   const bool tail = c0 + 8 > (unsigned)C;                        // this piece holds padding channels: keep them zero
   for (unsigned idx = first; idx < total; idx += gridDim.x * 256u) {
-    const u32x4 xv = *(const u32x4*)(x + (size_t)idx * 8);
+    const u32x4 xv = ew_ld(x + (size_t)idx * 8);
     u32x4 rv = {0u, 0u, 0u, 0u};
-    if (RES) rv = *(const u32x4*)(res + (size_t)idx * 8);
+    if (RES) rv = ew_ld(res + (size_t)idx * 8);
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -434,7 +451,7 @@ __global__ __launch_bounds__(256) void cl16_bn_act_kernel(const unsigned short* 
       }
       o[i] = pack_bf2(v[0], v[1]);
     }
-    *(u32x4*)(out + (size_t)idx * 8) = o;
+    ew_st(out + (size_t)idx * 8, o);
   }
 }
 
@@ -474,11 +491,11 @@ __global__ __launch_bounds__(256) void cl16_bn_bwd_reduce_kernel(const unsigned 
     }
     for (unsigned p = e0 + r; p < e1; p += rpb) {
       const size_t ad = ((size_t)p * pieces + pc) * 8;
-      u32x4 gv = *(const u32x4*)(gin + ad);
-      const u32x4 xv = *(const u32x4*)(x + ad);
+      u32x4 gv = ew_ld(gin + ad);
+      const u32x4 xv = ew_ld(x + ad);
       u32x4 vv = {0u, 0u, 0u, 0u}, x2v = {0u, 0u, 0u, 0u};
-      if (MASK == 2) vv = *(const u32x4*)(v + ad);
-      if (TWO) x2v = *(const u32x4*)(x2 + ad);
+      if (MASK == 2) vv = ew_ld(v + ad);
+      if (TWO) x2v = ew_ld(x2 + ad);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const unsigned wsel = i >> 1;
@@ -494,7 +511,7 @@ __global__ __launch_bounds__(256) void cl16_bn_bwd_reduce_kernel(const unsigned 
           if (!(((hi ? bf_hi(vv[wsel]) : bf_lo(vv[wsel])) > 0.f))) gv[wsel] &= hi ? 0x0000FFFFu : 0xFFFF0000u;
         }
       }
-      if (MASK == 2) *(u32x4*)(gout + ad) = gv;
+      if (MASK == 2) ew_st(gout + ad, gv);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -539,8 +556,8 @@ __global__ __launch_bounds__(256) void cl16_bn_bwd_apply_kernel(const unsigned s
     a3[i] = ok ? b5[4 * C + c0 + i] : 0.f;
   }
   for (unsigned idx = first; idx < total; idx += gridDim.x * 256u) {
-    const u32x4 gv = *(const u32x4*)(gin + (size_t)idx * 8);
-    const u32x4 xv = *(const u32x4*)(x + (size_t)idx * 8);
+    const u32x4 gv = ew_ld(gin + (size_t)idx * 8);
+    const u32x4 xv = ew_ld(x + (size_t)idx * 8);
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -555,7 +572,7 @@ __global__ __launch_bounds__(256) void cl16_bn_bwd_apply_kernel(const unsigned s
       }
       o[i] = pack_bf2(v[0], v[1]);
     }
-    *(u32x4*)(out + (size_t)idx * 8) = o;
+    ew_st(out + (size_t)idx * 8, o);
   }
 }
 
