@@ -52,6 +52,13 @@ constexpr int CL_NT = SLV_CL16_NT ? 2 : 0;
 __device__ __forceinline__ void mfma_settle_nops() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
 __device__ __forceinline__ void mfma_pin(f32x4& a) { asm volatile("" : "+v"(a)); }
 
+// The BatchNorm-backward apply A1 * (masked g) + A2 + A3 * x as EVERY kernel of this path evaluates it -- two fused
+// multiply-adds (the separate pass slv_cl16_bn_bwd_apply and the backward-data epilogue that replaces it must agree bit for bit;
+// as mul / add / mul / add it was 176 more VALU instructions per 32-pixel step of that epilogue)
+__device__ __forceinline__ float bn_bwd_apply1(float g, float x, float a1, float a2, float a3) {
+  return __builtin_fmaf(a3, x, __builtin_fmaf(a1, g, a2));
+}
+
 // relu(x*s + h) on the 8 bf16 of a 16-byte piece; s, h: the piece's 8 channels
 __device__ __forceinline__ u32x4 affine_relu8(u32x4 v, const float* s, const float* h) {
   u32x4 o;

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
               const float xx = e ? bf_hi(xv[i]) : bf_lo(xv[i]);
               float gg = e ? bf_hi(v[i]) : bf_lo(v[i]);
               if (!(bn_affine(xx, e_s[k], e_h[k]) > 0.f)) gg = 0.f;
-              o2[e] = e_a1[k] * gg + e_a2[k] + e_a3[k] * xx;     // (the expression of cl16_bn_bwd_apply_kernel)
+              o2[e] = bn_bwd_apply1(gg, xx, e_a1[k], e_a2[k], e_a3[k]);      // (cl16_bn_bwd_apply_kernel's)
             }
             v[i] = pack_bf2(o2[0], o2[1]);
           }

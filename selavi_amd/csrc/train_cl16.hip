@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void cl16_bn_bwd_apply_kernel(const unsigned s
         const float xx = e ? bf_hi(xv[i]) : bf_lo(xv[i]);
         float gg = e ? bf_hi(gv[i]) : bf_lo(gv[i]);
         if (relu && !(bn_affine(xx, s[k], h[k]) > 0.f)) gg = 0.f;
-        v[e] = a1[k] * gg + a2[k] + a3[k] * xx;                  // padding channels: all coefficients are zero
+        v[e] = bn_bwd_apply1(gg, xx, a1[k], a2[k], a3[k]);       // padding channels: all coefficients are zero
       }
       o[i] = pack_bf2(v[0], v[1]);
     }
