@@ -433,6 +433,9 @@ size_t slv_cl16_wgrad_bnr_ws_bytes(const int32_t* clw);
 int slv_cl16_wgrad_bnr(const int32_t* clw, const void* dy_bf16, const void* x_bf16, const float* in_scale_shift,
                        const float* in_mean_invstd, const float* w, float* dw, float* bn_part, int Cout, void* ws,
                        size_t ws_bytes, slv_stream_t stream);
+/* slv_cl16_bn_act: out = relu?(x*s + h + residual) on [P][Cp] bf16.  relu bit 0: the ReLU of the sum; bit 1 (with
+ * res_scale_shift): the residual is relu(res*rs + rh) ROUNDED TO bf16 -- the activated output of its BatchNorm exactly as a
+ * consumer's load prologue makes it from the raw tensor (the stem's un-materialised block output). */
 int slv_cl16_bn_act(const void* x_bf16, const float* scale_shift, const void* res_bf16, const float* res_scale_shift,
                     int relu, void* out_bf16, int64_t P, int C, int Cp, slv_stream_t stream);
 int32_t slv_cl16_bn_bwd_nsplit(int64_t P, int Cp);

@@ -442,10 +442,16 @@ __global__ __launch_bounds__(256) void cl16_bn_act_kernel(const unsigned short* 
       for (int e = 0; e < 2; ++e) {
         float t = bn_affine(e ? bf_hi(xv[i]) : bf_lo(xv[i]), s[2 * i + e], h[2 * i + e]);
         if (RES) {
-          const float r = e ? bf_hi(rv[i]) : bf_lo(rv[i]);
-          t += RSS ? bn_affine(r, rs[2 * i + e], rh[2 * i + e]) : r;
+          float r = e ? bf_hi(rv[i]) : bf_lo(rv[i]);
+          if (RSS) {
+            r = bn_affine(r, rs[2 * i + e], rh[2 * i + e]);
+            // relu bit 1: the residual is the ACTIVATED output of its BatchNorm as a consumer's load prologue makes it
+            // (ReLU, one rounding to bf16) -- the stem's un-materialised block output (engine.video_stage_forward)
+            if (relu & 2) r = bf_lo(pack_bf2(fmaxf(r, 0.f), 0.f));
+          }
+          t += r;
         }
-        if (relu) t = fmaxf(t, 0.f);
+        if (relu & 1) t = fmaxf(t, 0.f);
         if (tail && c0 + 2 * i + e >= (unsigned)C) t = 0.f;
         v[e] = t;
       }

@@ -236,7 +236,11 @@ def block_fwd(ctx, u, chain_mods, ds_mods):
         rec.chain.append(x)
     rec.ds = conv_bn(ctx, u, ds_mods[0], ds_mods[1], defer=True) if ds_mods is not None else None
     finalize_deferred(ctx, [rec.chain[-1], rec.ds])
-    rec.v = tail(ctx, rec.chain[-1], res=None if rec.ds is not None else u, res_raw=rec.ds)
+    if rec.ds is None and isinstance(u, Raw):              # (the un-materialised stem output as the shortcut)
+        last = rec.chain[-1]
+        rec.v = ctx.ops.bn_act(last.y, last.ss, res=u.y, res_ss=u.ss, relu=True, res_relu=True)
+    else:
+        rec.v = tail(ctx, rec.chain[-1], res=None if rec.ds is not None else u, res_raw=rec.ds)
     return rec
 
 
@@ -299,8 +303,19 @@ def video_stage_forward(ctx, base, stage, x):
         st = base.stem
         r0 = conv_bn(ctx, x, st[0], st[1], need_dx=False)
         r1 = conv_bn(ctx, r0, st[3], st[4])
+        if getattr(ctx.ops, "LAZY_STEM_TAIL", False):
+            # the stem's output relu(bn(.)) is NOT materialised: layer 1's first conv and its first block tail apply the
+            # BatchNorm + ReLU on load (one pass over a 64-channel tensor less: 0.7 ms of the cfg5 forward).  The stage hands
+            # the RAW tensor to the next autograd node and its scale / shift beside it (base._stem_ss); the gradient that
+            # comes back is, as before, the one w.r.t. the ACTIVATED output.
+            base._stem_ss = r1.ss
+            return r1.y, (r0, r1)
         return tail(ctx, r1), (r0, r1)
     u, recs = x, []
+    if stage == "layer1" and getattr(ctx.ops, "LAZY_STEM_TAIL", False):
+        ss, base._stem_ss = getattr(base, "_stem_ss", None), None
+        assert ss is not None, "layer1 runs behind the stem stage of the same pass"
+        u = Raw(x, ss, None, None, None, None, None)
     for chain, ds in _video_blocks(getattr(base, stage)):
         rec = block_fwd(ctx, u, chain, ds)
         recs.append(rec)

@@ -122,6 +122,8 @@ from . import ops as _ops
 # layer-1 backward-data launches +300 us against the 45-110 us of the separate coalesced reduce pass it replaces
 # (profiles/r02_notes.md); SELAVI_CL16_FUSE_BNR=1 switches it on.
 FUSE_BNR = os.environ.get("SELAVI_CL16_FUSE_BNR", "0") == "1"
+# engine.video_stage_forward: the stem's block output is applied on load by its consumers instead of being materialised
+LAZY_STEM_TAIL = os.environ.get("SELAVI_CL16_LAZY_STEM", "1") == "1"
 # the stem's weight gradient on the direct kernel as well (then no W-patch tensor exists in the step)
 STEM_DIRECT_WGRAD = os.environ.get("SELAVI_CL16_STEM_WGRAD", "1") == "1"
 bn_train_finalize = _ops.bn_train_finalize
@@ -530,11 +532,14 @@ def _pc(x, C_real):
     return x.numel() // Cp, Cp
 
 
-def bn_act(x, ss, res=None, res_ss=None, relu=True):
+def bn_act(x, ss, res=None, res_ss=None, relu=True, res_relu=False):
+    """relu?(x*s + h + residual); residual = res, or res*rs + rh (res_ss), or -- res_relu -- the bf16-rounded relu(res*rs + rh)
+    a consumer's load prologue would make of the raw tensor ``res``."""
     Cc = ss.shape[1]
     P, Cp = _pc(x, Cc)
     out = torch.empty_like(x)
-    C.slv_cl16_bn_act(ptr(x), ptr(ss), ptr(res), ptr(res_ss), int(relu), ptr(out), P, Cc, Cp, stream())
+    assert not res_relu or res_ss is not None
+    C.slv_cl16_bn_act(ptr(x), ptr(ss), ptr(res), ptr(res_ss), int(relu) | (2 if res_relu else 0), ptr(out), P, Cc, Cp, stream())
     return out
 
 

@@ -448,6 +448,12 @@ def test_batchnorm_kernels_channels_last(C, shape):
         assert (out[..., C:] == 0).all()
         got = _ncthw(out, C).double()
         assert ((got - want).abs() <= want.abs() * 2.0 ** -8 + 1e-6).all()
+    # the residual as the ACTIVATED output of its BatchNorm the way a consumer's load prologue makes it (ReLU, one rounding to
+    # bf16): the block tail over the stem's un-materialised output must equal the tail over the materialised tensor, bit for bit
+    act = ops16.bn_act(rc, rss.cuda(), relu=True)
+    a = ops16.bn_act(xc, ss.cuda(), res=act, relu=True)
+    b = ops16.bn_act(xc, ss.cuda(), res=rc, res_ss=rss.cuda(), relu=True, res_relu=True)
+    assert torch.equal(a, b)
     # --- backward reductions
     mi = torch.stack([torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5]).contiguous()
     mi2 = torch.stack([torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5]).contiguous()
