@@ -353,10 +353,12 @@ int slv_cl16_stem_fwd(const float* x, const float* w, void* y_bf16, float* stat_
                       int H, int W, int Cout, slv_stream_t stream);
 /* ... and its weight gradient: dy bf16 [N][T][Ho][Wo][64] (the gradient w.r.t. the conv's raw output), dw fp32
  * [Cout][Cin][1][7][7] (the reference layout), ws: slv_cl16_stem_wgrad_ws_bytes() of scratch (per-workgroup partials,
- * summed in a fixed order: deterministic). */
+ * summed in a fixed order: deterministic).  y_bf16 / bwd5 (nullable, together) / relu: dy is the gradient w.r.t. the ACTIVATED
+ * output of the conv's BatchNorm and the kernel applies that BatchNorm's backward on load -- what slv_cl16_bn_bwd_apply(dy,
+ * y, bwd5, relu) would have stored, bit for bit, without the pass (the stem's first conv has no backward-data launch). */
 size_t slv_cl16_stem_wgrad_ws_bytes(int N, int Cin, int T, int H, int W, int Cout);
 int slv_cl16_stem_wgrad(const float* x, const void* dy_bf16, float* dw, float* ws, size_t ws_bytes, int N, int Cin, int T, int H,
-                        int W, int Cout, slv_stream_t stream);
+                        int W, int Cout, const void* y_bf16, const float* bwd5, int relu, slv_stream_t stream);
 /* MaxPool2d(3, 2, 1) on [N][H][W][Cp] bf16; AdaptiveAvgPool(1)+flatten: [N][S][Cp] bf16 -> fp32 [N][C] */
 int slv_maxpool_cl16(const void* x_bf16, void* y_bf16, int64_t N, int H, int W, int Cp, slv_stream_t stream);
 int slv_avgpool_cl16(const void* x_bf16, float* y, int64_t N, int64_t S, int C, int Cp, slv_stream_t stream);

@@ -199,10 +199,15 @@ constexpr int ST_GT = 64 * ST_GP;                     // 10 240 per tile
 constexpr int ST_LDS_WG = ST_IMG + 2 * ST_GT + 256 * 8;               // 42 688
 
 // part [gridDim.x][16 MT][7][32] fp32: this workgroup's sum over its bands; column k = 4 dw + c of kernel row dh
-template <int MT>
+// APPLY: dy is the gradient w.r.t. the ACTIVATED output of the conv's BatchNorm; the staged tile is what slv_cl16_bn_bwd_apply
+// would make of it (A1 * mask * g + A2 + A3 * y with y = the conv's raw output, b5 = {s, h, A1, A2, A3}[Cout]), bit for bit --
+// the stem's first conv has no backward-data launch, so its weight gradient was that pass's only reader
+template <int MT, bool APPLY>
 __global__ __launch_bounds__(256, MT == 3 ? 2 : 1) void cl16_stem_wgrad_kernel(const float* __restrict__ x,
                                                                               const unsigned short* __restrict__ dy,
-                                                                              float* __restrict__ part, StemGeom g, int total) {
+                                                                              float* __restrict__ part, StemGeom g, int total,
+                                                                              const unsigned short* __restrict__ yraw,
+                                                                              const float* __restrict__ b5, int relu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -211,11 +216,26 @@ __global__ __launch_bounds__(256, MT == 3 ? 2 : 1) void cl16_stem_wgrad_kernel(c
   unsigned char* const gl = lds + ST_IMG;             // [2][ST_GT]
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)g.N * g.Cin * g.T * g.H * g.W * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)g.N * g.T * g.Ho * g.Wo * 128u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ryr = __builtin_amdgcn_make_buffer_rsrc((void*)(APPLY ? yraw : dy), 0, (int)((unsigned)g.N * g.T * g.Ho * g.Wo * 128u), 0x00020000);
+  float cs[8], ch[8], c1[8], c2[8], c3[8];            // this thread's 8 channels (piece tid & 7 of every tile position it stages)
+  if constexpr (APPLY) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = (tid & 7) * 8 + e;
+      const bool ok = c < g.Cout;
+      cs[e] = ok ? b5[c] : 0.f;
+      ch[e] = ok ? b5[g.Cout + c] : 0.f;
+      c1[e] = ok ? b5[2 * g.Cout + c] : 0.f;
+      c2[e] = ok ? b5[3 * g.Cout + c] : 0.f;
+      c3[e] = ok ? b5[4 * g.Cout + c] : 0.f;
+    }
+  }
   StemFill fill;
   stem_fill_init(fill, tid, g.W);
   float r[ST_FIT][3];
   // dY tile: piece id = tid + 256 h of 512: position id >> 3 = (row, column) of the 8 x 8 tile, 16-byte piece id & 7
-  u32x4 gr[2];
+  u32x4 gr[2], yr[2];
+  unsigned gok = 0;                                   // bit h: piece h of the staged tile is a pixel of the image
   auto load_g = [&](int b, int cg) __attribute__((always_inline)) {
     const int f = b / g.nbf, band = b - f * g.nbf, oy0 = band * ST_ROWS;
 #pragma unroll
@@ -224,13 +244,33 @@ __global__ __launch_bounds__(256, MT == 3 ? 2 : 1) void cl16_stem_wgrad_kernel(c
       const bool ok = b < total && cg < g.ncg && oy < g.Ho && ox < g.Wo;
       const unsigned off = ((unsigned)((f * g.Ho + oy) * g.Wo + ox)) * 128u + (id & 7) * 16u;
       gr[h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : 0xFFFFFFF0u, 0, 0));
+      if constexpr (APPLY) {
+        yr[h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ryr, ok ? off : 0xFFFFFFF0u, 0, 0));
+        gok = (gok & ~(1u << h)) | ((unsigned)ok << h);
+      }
     }
   };
   auto store_g = [&](int par) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int id = tid + 256 * h;
-      *(u32x4*)(gl + par * ST_GT + (id >> 3) * ST_GP + (id & 7) * 16) = gr[h];
+      u32x4 v = gr[h];
+      if constexpr (APPLY) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float o2[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int k = 2 * i + e;
+            const float xx = e ? bf_hi(yr[h][i]) : bf_lo(yr[h][i]);
+            float gg = e ? bf_hi(gr[h][i]) : bf_lo(gr[h][i]);
+            if (relu && !(bn_affine(xx, cs[k], ch[k]) > 0.f)) gg = 0.f;
+            o2[e] = bn_bwd_apply1(gg, xx, c1[k], c2[k], c3[k]);
+          }
+          v[i] = ((gok >> h) & 1u) ? pack_bf2(o2[0], o2[1]) : 0u;     // (outside the image: no gradient, not A2)
+        }
+      }
+      *(u32x4*)(gl + par * ST_GT + (id >> 3) * ST_GP + (id & 7) * 16) = v;
     }
   };
   // the transposing reads: lane (fr, fk) supplies the address of position 4 fk + (fr >> 2) (+ 16) and 8 bytes (4 columns) at
@@ -385,19 +425,25 @@ size_t slv_cl16_stem_wgrad_ws_bytes(int N, int Cin, int T, int H, int W, int Cou
 }
 
 int slv_cl16_stem_wgrad(const float* x, const void* dy_bf16, float* dw, float* ws, size_t ws_bytes, int N, int Cin, int T, int H,
-                        int W, int Cout, slv_stream_t stream) {
+                        int W, int Cout, const void* y_bf16, const float* bwd5, int relu, slv_stream_t stream) {
   using namespace slv;
   StemGeom g;
   SLV_CHECK_ARG(x && dy_bf16 && dw && ws && stem_geom(g, N, Cin, T, H, W, Cout),
                 "7 x 7 stride-2 stem over <= 3 channels, W <= 112, 33..64 output channels");
   SLV_CHECK_ARG(ws_bytes >= slv_cl16_stem_wgrad_ws_bytes(N, Cin, T, H, W, Cout), "workspace too small");
+  SLV_CHECK_ARG(!y_bf16 == !bwd5, "y_bf16 and bwd5 come together");
   const int total = N * T * g.nbf, grid = stem_grid(total), mrows = Cout <= 48 ? 48 : 64;
-  if (Cout <= 48)
-    hipLaunchKernelGGL((cl16_stem_wgrad_kernel<3>), dim3(grid), dim3(256), ST_LDS_WG, (hipStream_t)stream, x,
-                       (const unsigned short*)dy_bf16, ws, g, total);
-  else
-    hipLaunchKernelGGL((cl16_stem_wgrad_kernel<4>), dim3(grid), dim3(256), ST_LDS_WG, (hipStream_t)stream, x,
-                       (const unsigned short*)dy_bf16, ws, g, total);
+#define SLV_STEM_WG(MT_, AP_)                                                                                                  \
+  hipLaunchKernelGGL((cl16_stem_wgrad_kernel<MT_, AP_>), dim3(grid), dim3(256), ST_LDS_WG, (hipStream_t)stream, x,             \
+                     (const unsigned short*)dy_bf16, ws, g, total, (const unsigned short*)y_bf16, bwd5, relu)
+  if (Cout <= 48) {
+    if (y_bf16) SLV_STEM_WG(3, true);
+    else SLV_STEM_WG(3, false);
+  } else {
+    if (y_bf16) SLV_STEM_WG(4, true);
+    else SLV_STEM_WG(4, false);
+  }
+#undef SLV_STEM_WG
   SLV_LAUNCH_CHECK();
   hipLaunchKernelGGL(cl16_stem_wgrad_reduce_kernel, dim3((Cout * Cin * 49 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws,
                      dw, grid, mrows, Cout, Cin);

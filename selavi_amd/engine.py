@@ -152,7 +152,13 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
     # materialise dXout once (in place over g, which is dead afterwards unless it doubles as the
     # residual addend) and feed plain tensors to both GEMMs (1.8x faster than folding the BN backward
     # into the wgrad/dgrad operand loaders, which is what round 1 started with)
-    dxo = g if applied else ctx.ops.bn_bwd_apply(g, r.y, b5, a_relu, out=torch.empty_like(g) if (keep_g or addend is g) else None)
+    # the stem's first conv on the 16-bit path: no backward data, and its weight gradient applies the BatchNorm backward on load
+    wg_apply = (not need_dx and not applied and not fuse_bn and getattr(ctx.ops, "stem_wgrad_apply_ok", None) is not None
+                and ctx.ops.stem_wgrad_apply_ok(r.plan))
+    if wg_apply:
+        dxo = g
+    else:
+        dxo = g if applied else ctx.ops.bn_bwd_apply(g, r.y, b5, a_relu, out=torch.empty_like(g) if (keep_g or addend is g) else None)
 
     def dgrad():
         wt = r.wt if r.wt is not None else ctx.ops.conv_wt_transform(r.plan, r.conv.weight)
@@ -167,6 +173,8 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
         dw_out = dw_out.view(w.shape[0], -1)
 
     def wgrad():
+        if wg_apply:
+            return ctx.ops.conv_wgrad(r.plan, dxo, xin, out=dw_out, bn_apply=(r.y, b5, a_relu))
         if r.patch is not None:
             return ctx.ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None, out=dw_out, patch=r.patch)
         return ctx.ops.conv_wgrad(r.plan, dxo, xin, in_ss=in_ss, in_relu=in_ss is not None, out=dw_out)
@@ -195,7 +203,7 @@ def backprop_raw(ctx, r, g, b5, a_relu, need_dx=True, addend=None, out=None, kee
         side.wait_event(ready)
         with torch.cuda.stream(side):
             dw = wgrad()
-        for t in (dxo, xin, in_ss, r.patch):        # allocated on `cur`, read on `side`
+        for t in (dxo, xin, in_ss, r.patch) + ((r.y, b5) if wg_apply else ()):        # allocated on `cur`, read on `side`
             if t is not None:
                 t.record_stream(side)
         if dw_out is None:

@@ -124,6 +124,8 @@ from . import ops as _ops
 FUSE_BNR = os.environ.get("SELAVI_CL16_FUSE_BNR", "0") == "1"
 # engine.video_stage_forward: the stem's block output is applied on load by its consumers instead of being materialised
 LAZY_STEM_TAIL = os.environ.get("SELAVI_CL16_LAZY_STEM", "1") == "1"
+# ... with the BatchNorm-backward apply of the stem's first conv folded into its loader (no bn_bwd_apply pass over that tensor)
+STEM_WGRAD_APPLY = os.environ.get("SELAVI_CL16_STEM_WGRAD_APPLY", "1") == "1"
 # the stem's weight gradient on the direct kernel as well (then no W-patch tensor exists in the step)
 STEM_DIRECT_WGRAD = os.environ.get("SELAVI_CL16_STEM_WGRAD", "1") == "1"
 bn_train_finalize = _ops.bn_train_finalize
@@ -487,8 +489,13 @@ def wgrad_bnr_ok(plan):
     return WGRAD_BNR and wgrad_bnr_available(plan)
 
 
+def stem_wgrad_apply_ok(plan):
+    """Does conv_wgrad(..., bn_apply=...) take this layer (the direct stem weight gradient)?"""
+    return bool(plan.stem and plan.stem_direct and STEM_DIRECT_WGRAD and STEM_WGRAD_APPLY)
+
+
 def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, in_relu=False, out=None, patch=None,
-               bnr=None):
+               bnr=None, bn_apply=None):
     """dw (fp32, [Cout][Cin*taps] = the reference layout flattened) from bf16 dy and act(x_in).
     bnr = (mean_invstd of the BatchNorm behind in_ss, this conv's fp32 weights): the kernel forms the weight gradient from
     the gradients against the masked raw activation and against the mask, which also gives that BatchNorm's backward
@@ -505,11 +512,16 @@ def conv_wgrad(plan, dy, x_in, x_out=None, bwd5=None, a_relu=False, in_ss=None, 
                              ptr(part), plan.Cout, ptr(ws), plan.ws_wgrad_bnr, stream())
         return dw, part
     if plan.stem and plan.stem_direct and STEM_DIRECT_WGRAD and patch is None:
+        # bn_apply = (y, bwd5, relu): dy is the gradient w.r.t. the activated output of this conv's BatchNorm; the kernel
+        # applies the BatchNorm backward on load (= bn_bwd_apply(dy, y, bwd5, relu) bit for bit, without the pass)
         N, Cc, T, H, W = plan.src_shape
         nb = C.slv_cl16_stem_wgrad_ws_bytes(N, Cc, T, H, W, plan.Cout)
         ws = _ops.workspace(nb, dy.device)
-        C.slv_cl16_stem_wgrad(ptr(x_in.contiguous()), ptr(dy), ptr(dw), ptr(ws), nb, N, Cc, T, H, W, plan.Cout, stream())
+        ay, ab5, arelu = bn_apply if bn_apply is not None else (None, None, False)
+        C.slv_cl16_stem_wgrad(ptr(x_in.contiguous()), ptr(dy), ptr(dw), ptr(ws), nb, N, Cc, T, H, W, plan.Cout, ptr(ay),
+                              ptr(ab5), int(arelu), stream())
         return dw
+    assert bn_apply is None
     if plan.stem:
         x_in = patch if patch is not None else _patch(plan, x_in)
     if plan.chunks is not None:

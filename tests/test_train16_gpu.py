@@ -422,6 +422,13 @@ def test_stem_direct_forward_and_weight_gradient(case):
     dw = ops16.conv_wgrad(plan, _cl(dy), x.cuda())
     gotw = dw.view(Cout, Cin, *k).double().cpu()
     assert float((gotw - wantw).abs().max()) <= 2e-5 * float(wantw.abs().max()) * max(1.0, (N * T * H * W / 2640.0) ** 0.5)
+    # the BatchNorm-backward apply folded into the weight gradient's loader == the separate pass, bit for bit
+    b5 = (torch.randn(5, Cout, generator=g) * 0.5).cuda()
+    dyc = _cl(dy)
+    for relu in (True, False):
+        ref = ops16.conv_wgrad(plan, ops16.bn_bwd_apply(dyc, y, b5, relu, out=torch.empty_like(dyc)), x.cuda())
+        fused = ops16.conv_wgrad(plan, dyc, x.cuda(), bn_apply=(y, b5, relu))
+        assert torch.equal(ref, fused)
 
 
 @pytest.mark.parametrize("C,shape", [(144, (2, 3, 6, 5)), (45, (1, 2, 4, 4)), (921, (1, 2, 3, 3)), (64, (3, 4, 7, 9))])
