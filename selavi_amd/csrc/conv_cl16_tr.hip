@@ -20,6 +20,7 @@
 // Frames outside the clip (temporal zero padding) are skipped MFMAs, not zero rows.
 #include "cl16.hpp"
 #include "../../include/selavi_hip.h"
+#include <utility>
 
 namespace slv {
 
@@ -56,6 +57,15 @@ __device__ __forceinline__ void tr_mfma0(f32x4& acc, const bf16x8& a, const bf16
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #endif
 }
+// one fragment from LDS, invisible to the compiler's scheduler and wait counting (see the step's MFMA section)
+template <int OFF>
+__device__ __forceinline__ void tr_lds_read(bf16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <class F, int... I>
+__device__ __forceinline__ void tr_for_seq(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
 __device__ __forceinline__ void tr_mfma_settle() {
 #if SLV_TR_ASM_MFMA
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // 8-pass XDL result -> VALU read: 11+ wait states
@@ -91,6 +101,8 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
                                                       // idle lanes' pieces go (no branches, one address form for every lane)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const ring = lds;                    // 3 x SLOT
+  typedef __attribute__((address_space(3))) void* tr_lds_void;
+  const unsigned ring_a = (unsigned)(unsigned long)(tr_lds_void)lds;
   unsigned char* const ost = lds + 3 * SLOT;          // [TR_PX][orow]
   const int lane = threadIdx.x;
   const int fr = lane & 15, fk = lane >> 4;
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
   for (int i = 0; i < MT; ++i) accS[i] = accQ[i] = 0.f;
   // one step: `cur` = register set holding step s + 2 (requested one step ago), `nxt` = the set step s + 3 goes to
 #ifdef SLV_TR_TRACE
-  unsigned long long trc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  unsigned long long trc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
   auto step = [&](u32x4* cur, unsigned& vcur, u32x4* nxt, unsigned& vnxt) __attribute__((always_inline)) {
     load_frame(pf, nxt, vnxt);                        // two frames in flight behind this step's MFMAs
@@ -277,25 +289,79 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
     TR_STAMP(0);                                      // requests issued
     f32x4 acc[MT][2];
     int pi = 0;                                       // next staged piece to get its BatchNorm + ReLU
+    if constexpr (MT * KC * 3 <= 24) {
+      // (the stem's 45 <-> 64 kernels: two waves per SIMD cover each other's fragment reads; the hand-placed reads below
+      //  measured 10 % slower there -- 0.171 -> 0.189 ms with the prologue -- so the compiler keeps this form)
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-      const int j = jj == 0 ? 1 : jj == 1 ? 0 : 2;    // the centre tap (always inside the clip) first: it initialises
-      const int f = cc.t + dt[j];
-      const bool live = f >= 0 && f < T;              // temporal zero padding: nothing to add
-      const unsigned char* src = ring + (dt[j] < 0 ? sprev : dt[j] > 0 ? snext : slot) * SLOT + boff;
+      for (int jj = 0; jj < 3; ++jj) {
+        const int j = jj == 0 ? 1 : jj == 1 ? 0 : 2;    // the centre tap (always inside the clip) first: it initialises
+        const int f = cc.t + dt[j];
+        const bool live = f >= 0 && f < T;              // temporal zero padding: nothing to add
+        const unsigned char* src = ring + (dt[j] < 0 ? sprev : dt[j] > 0 ? snext : slot) * SLOT + boff;
 #pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        if (live) {
-          const bf16x8 b0 = *(const bf16x8*)(src + c * TR_CHS);
-          const bf16x8 b1 = *(const bf16x8*)(src + c * TR_CHS + 16 * 64);
+        for (int c = 0; c < KC; ++c) {
+          if (live) {
+            const bf16x8 b0 = *(const bf16x8*)(src + c * TR_CHS);
+            const bf16x8 b1 = *(const bf16x8*)(src + c * TR_CHS + 16 * 64);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              if (jj == 0 && c == 0) {
+                tr_mfma0(acc[i][0], A[j][c][i], b0);
+                tr_mfma0(acc[i][1], A[j][c][i], b1);
+              } else {
+                tr_mfma(acc[i][0], A[j][c][i], b0);
+                tr_mfma(acc[i][1], A[j][c][i], b1);
+              }
+            }
+          }
+#if SLV_TR_INTERLEAVE >= 1      // the VALU work of the staged frame in the shadow of the MFMA groups
+          constexpr int GROUPS = 3 * KC, PER = (NIT + GROUPS - 1) / GROUPS;
+#pragma unroll
+          for (int q = 0; q < PER; ++q)
+            if (pi < NIT) affine_piece(cur, vcur, pi++);
+#if SLV_TR_INTERLEAVE >= 2
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
+        }
+      }
+    } else {
+      // 3 KC groups (tap, chunk) of 2 fragment reads + 2 MT MFMAs.  The reads of group g + 1 are issued IN FRONT of the MFMAs of
+      // group g (two register sets), unconditionally -- only the MFMAs of a tap outside the clip (temporal zero padding) are
+      // skipped.  Left to the compiler, the reads sat inside the per-group "is this tap live" block, each group began with a full
+      // LDS round trip and the 120 MFMAs of a step took 3 175 cycles instead of 2 160 (tools/tr_trace.py, round 5).  Inline asm:
+      // the compiler must neither sink the reads into the conditional block nor wait for them early; the wait is a full drain
+      // (lgkmcnt also counts scalar loads the compiler may have in flight) placed BEFORE the next group's reads are issued.
+      unsigned sa[3];                                   // LDS byte address of this lane's fragment rows in the tap's ring slot
+      bool lv[3];
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        const int j = jj == 0 ? 1 : jj == 1 ? 0 : 2;    // the centre tap (always inside the clip) first: it initialises
+        const int f = cc.t + dt[j];
+        lv[jj] = f >= 0 && f < T;                       // temporal zero padding: nothing to add
+        sa[jj] = ring_a + (unsigned)((dt[j] < 0 ? sprev : dt[j] > 0 ? snext : slot) * SLOT + boff);
+      }
+      bf16x8 bq[2][2];
+      tr_lds_read<0>(bq[0][0], sa[0]);
+      tr_lds_read<16 * 64>(bq[0][1], sa[0]);
+      tr_for_seq(std::make_integer_sequence<int, 3 * KC>{}, [&](auto G) __attribute__((always_inline)) {
+        constexpr int gq = decltype(G)::value, jj = gq / KC, c = gq % KC;
+        const int j = jj == 0 ? 1 : jj == 1 ? 0 : 2;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[gq & 1][0]), "+v"(bq[gq & 1][1]));      // group gq's fragments have landed
+        if constexpr (gq + 1 < 3 * KC) {
+          constexpr int jn = (gq + 1) / KC, cn = (gq + 1) % KC;
+          tr_lds_read<cn * TR_CHS>(bq[(gq + 1) & 1][0], sa[jn]);
+          tr_lds_read<cn * TR_CHS + 16 * 64>(bq[(gq + 1) & 1][1], sa[jn]);
+        }
+        if (lv[jj]) {
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
-            if (jj == 0 && c == 0) {
-              tr_mfma0(acc[i][0], A[j][c][i], b0);
-              tr_mfma0(acc[i][1], A[j][c][i], b1);
+            if constexpr (gq == 0) {
+              tr_mfma0(acc[i][0], A[j][c][i], bq[0][0]);
+              tr_mfma0(acc[i][1], A[j][c][i], bq[0][1]);
             } else {
-              tr_mfma(acc[i][0], A[j][c][i], b0);
-              tr_mfma(acc[i][1], A[j][c][i], b1);
+              tr_mfma(acc[i][0], A[j][c][i], bq[gq & 1][0]);
+              tr_mfma(acc[i][1], A[j][c][i], bq[gq & 1][1]);
             }
           }
         }
@@ -308,7 +374,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #endif
-      }
+      });
     }
     TR_STAMP(1);                                      // the MFMAs (and the fragment reads they wait for)
 #pragma unroll
@@ -320,6 +386,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
 #pragma unroll
     for (int i = 0; i < MT; ++i) mfma_pin(acc[i][0]), mfma_pin(acc[i][1]);
 #endif
+    TR_STAMP(8);                                      // (trace: the settle nops)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -327,6 +394,7 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
         const unsigned lo = pack_bf2(acc[i][nn][0], acc[i][nn][1]), hi = pack_bf2(acc[i][nn][2], acc[i][nn][3]);
         *(uint2*)(ost + (nn * 16 + fr) * orow + (i * 16 + fk * 4) * 2) = make_uint2(lo, hi);
       }
+    TR_STAMP(9);                                      // (trace: rounding + the output tile's LDS writes)
     store_frame(sprev, cur);                          // step s + 2 takes the slot of step s - 1: no longer read
     TR_STAMP(3);                                      // output tile + staged frame into LDS
     if constexpr (EPI == 1) {                         // statistics of the 32 rounded rows on the matrix cores
@@ -392,8 +460,8 @@ __global__ __launch_bounds__(64, 1) void conv_cl16_tr_kernel(const unsigned shor
   }
 #ifdef SLV_TR_TRACE
   if (lane == 0) {
-    unsigned long long* o_ = (unsigned long long*)y + blockIdx.x * 8;
-    for (int i_ = 0; i_ < 8; ++i_) o_[i_] = i_ == 7 ? (unsigned long long)S : trc[i_];
+    unsigned long long* o_ = (unsigned long long*)y + blockIdx.x * 10;
+    for (int i_ = 0; i_ < 10; ++i_) o_[i_] = i_ == 7 ? (unsigned long long)S : trc[i_];
   }
 #endif
 }
