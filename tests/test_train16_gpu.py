@@ -651,6 +651,32 @@ def _oracle_step_on_rounded(B, T, S, hc, K, round_activations, damp=None):
     return float(loss), grads
 
 
+def test_passes_removed_in_round_5_leave_the_step_bit_identical(monkeypatch):
+    """The stem's un-materialised block output (ops16.LAZY_STEM_TAIL) and the BatchNorm-backward apply inside the stem weight
+    gradient's loader (ops16.STEM_WGRAD_APPLY) are rearrangements of WHERE a value is formed, not of its arithmetic: losses,
+    every parameter gradient and the weights after three steps equal those of the materialised / separate-pass forms bit for bit."""
+    from selavi_amd import ops16, train
+    from selavi_amd.utils import get_loss
+    outs = []
+    for lazy, fused in ((True, True), (False, False), (True, False), (False, True)):
+        monkeypatch.setattr(ops16, "LAZY_STEM_TAIL", lazy)
+        monkeypatch.setattr(ops16, "STEM_WGRAD_APPLY", fused)
+        m, opt, video, audio, sl, sel, hc = _step_setup("bf16", B=4, T=8, S=64)
+        fv, fa = m(video, audio)
+        labels = sl[sel, :]
+        loss = 0.5 * get_loss(fv, labels, headcount=hc) + 0.5 * get_loss(fa, labels, headcount=hc)
+        opt.zero_grad()
+        loss.backward()
+        grads = [p.grad.detach().clone() for p in m.parameters()]
+        opt.step()
+        losses = [float(loss.detach())] + [float(train.train_step(m, opt, video, audio, sl, sel, hc)) for _ in range(2)]
+        outs.append((losses, grads, torch.cat([p.detach().flatten() for p in m.parameters()])))
+    for losses, grads, w in outs[1:]:
+        assert losses == outs[0][0]
+        assert all(torch.equal(a, b) for a, b in zip(grads, outs[0][1]))
+        assert torch.equal(w, outs[0][2])
+
+
 @pytest.mark.parametrize("shape", [(8, 8, 64, None), (4, 8, 112, 0.1)], ids=["b8_t8_64px", "b4_t8_112px_layer1_maps_56x56"])
 def test_bf16_step_against_the_cpu_oracle_on_rounded_operands(shape):
     """DIRECT oracle check of the 16-bit step (no HIP-vs-HIP transitivity, no damped init): oracle/step_ref.train_step in
