@@ -44,7 +44,7 @@ constexpr int SR_ONIT = SR_OPIECES / 64;              // = 20 store instructions
 
 #ifndef SLV_SR_ABL
 #define SLV_SR_ABL 0      // timing ablations (results wrong): 1 no MFMAs (a VALU xor keeps the operands alive), 2 no global
-#endif                    // patch loads, 3 no output stores, 4 no epilogue at all, 5 no sched_barrier between MFMA groups, 6 two fragment sets per tile
+#endif                    // patch loads, 3 no output stores, 4 no epilogue at all, 5 no sched_barrier between MFMA groups, 6 two fragment sets per tile, 7 no statistics instructions
 __device__ __forceinline__ void sr_mfma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
 #if SLV_SR_ABL == 1
   acc[0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, b)[0]);
@@ -101,10 +101,14 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
   const int fr = lane & 15, fk = lane >> 4;
   const int nt = blockIdx.x < (unsigned)ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int H = g.Hi, W = g.Wi;
+  // tile id -> (frame, tile row, tile column) by multiply-high with the reciprocals (exact: ids stay far below 2^32 / divisor).
+  // As plain divisions the decode was ~70 instructions, once per tile in every MFMA wave that masks ragged tiles and twice per
+  // tile in the data-movement wave: 300 of the 4 600 cycles of a tile with statistics.
+  const unsigned per_u = (unsigned)(th * tw), mper = 0xFFFFFFFFu / per_u + 1u, mtw = 0xFFFFFFFFu / (unsigned)tw + 1u;
   auto tile_of = [&](int k) __attribute__((always_inline)) {
     SrTile t;
-    const int id = blockIdx.x + k * gridDim.x;
-    const int per = th * tw, f = id / per, rem = id - f * per, ty = rem / tw;
+    const unsigned idu = blockIdx.x + (unsigned)k * gridDim.x;
+    const int per = (int)per_u, f = (int)__umulhi(idu, mper), rem = (int)idu - f * per, ty = (int)__umulhi((unsigned)rem, mtw);
     t.y0 = ty * SR_T;
     t.x0 = (rem - ty * tw) * SR_T;
     t.fpos = (unsigned)f * H * W;
@@ -157,7 +161,8 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
         else if (sub == 4) *(uint2*)(ost + obase + nn * 16 * SR_OROW + i * 32) = make_uint2(dlo, dhi);
         else {
           const int e = (sub - 5) / 3, w = (sub - 5) % 3;      // element e of the tile's four, instruction w of its three
-          if (w == 0) dv = e == 0 ? bf_lo(dlo) : e == 1 ? bf_hi(dlo) : e == 2 ? bf_lo(dhi) : bf_hi(dhi);
+          if (SLV_SR_ABL == 7) {                      // (ablation: the statistics' slots stay empty)
+          } else if (w == 0) dv = e == 0 ? bf_lo(dlo) : e == 1 ? bf_hi(dlo) : e == 2 ? bf_lo(dhi) : bf_hi(dhi);
           else if (w == 1) sr_add(stS[i][e], dv);
           else sr_sq(stQ[i][e], dv);
         }
