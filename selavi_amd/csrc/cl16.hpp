@@ -37,6 +37,11 @@ __device__ __forceinline__ unsigned relu_bf2(unsigned v) {
 // backward kernels must reproduce the forward's sign decision bit for bit.
 __device__ __forceinline__ float bn_affine(float x, float s, float h) { return __builtin_fmaf(x, s, h); }
 
+// n / d for the tile decodes of the persistent kernels (n < 2^32 / d): one multiply-high with m = cl_recip(d) = 2^32 / d + 1; d == 1
+// has no 32-bit reciprocal -- its m wraps to 0 and stands for "the quotient is n"
+__host__ __device__ __forceinline__ unsigned cl_recip(unsigned d) { return 0xFFFFFFFFu / d + 1u; }
+__device__ __forceinline__ unsigned cl_div(unsigned n, unsigned m) { return m ? __umulhi(n, m) : n; }
+
 // cache-policy operand of the buffer accesses that stream a tensor exactly once (outputs of the register-resident convs, the
 // temporal kernel's input rows): 2 = non-temporal
 #ifndef SLV_CL16_NT

@@ -89,10 +89,13 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sd_kernel(const unsigned sho
   // steps: the workgroup takes tile pairs (2 k, 2 k + 1) of its sequence; this wave's pair takes one of the two
   const int npairs = (ntiles + 1) >> 1;
   const int nst = blockIdx.x < (unsigned)npairs ? (npairs - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  // (tile id -> frame / row / column by multiply-high with the reciprocals, exact for ids < 2^32 / divisor: two tile decodes per
+  //  step as integer divisions were ~140 instructions in front of the step's MFMAs)
+  const unsigned per_u = (unsigned)(th * tw), mper = cl_recip(per_u), mtw = cl_recip((unsigned)tw);
   auto tile_of = [&](int k) __attribute__((always_inline)) {
     SdTile t;
     const int id = (blockIdx.x + k * gridDim.x) * 2 + pr;
-    const int per = th * tw, f = id / per, rem = id - f * per, ty = rem / tw;
+    const int per = (int)per_u, f = (int)cl_div((unsigned)id, mper), rem = id - f * per, ty = (int)cl_div((unsigned)rem, mtw);
     t.y0 = ty * SD_T;
     t.x0 = (rem - ty * tw) * SD_T;
     t.fpos = (unsigned)f * H * W;
@@ -306,6 +309,10 @@ bool cl16_sd_applies(const ClConv& g) {
     if (dt != 0 || dh != -(t / 3 - 1) || dw != -(t % 3 - 1) || (g.tap[t] >> 12) != t) return false;
   }
   if ((long long)g.N * g.Ti * g.Hi * g.Wi * SD_ROWB >= 0xFFFFFFF0LL) return false;
+  {                                                   // the tile decode by multiply-high is exact for ids < 2^32 / (tiles per frame)
+    const long long per = (long long)(g.Hi / SD_T) * (g.Wi / SD_T);
+    if (per < 1 || ((long long)g.N * g.Ti * per + 4096) * per >= 0xFFFFFFFFLL) return false;
+  }
   return true;
 }
 

@@ -104,11 +104,11 @@ __global__ __launch_bounds__(256, 1) void conv_cl16_sr_kernel(const unsigned sho
   // tile id -> (frame, tile row, tile column) by multiply-high with the reciprocals (exact: ids stay far below 2^32 / divisor).
   // As plain divisions the decode was ~70 instructions, once per tile in every MFMA wave that masks ragged tiles and twice per
   // tile in the data-movement wave: 300 of the 4 600 cycles of a tile with statistics.
-  const unsigned per_u = (unsigned)(th * tw), mper = 0xFFFFFFFFu / per_u + 1u, mtw = 0xFFFFFFFFu / (unsigned)tw + 1u;
+  const unsigned per_u = (unsigned)(th * tw), mper = cl_recip(per_u), mtw = cl_recip((unsigned)tw);
   auto tile_of = [&](int k) __attribute__((always_inline)) {
     SrTile t;
     const unsigned idu = blockIdx.x + (unsigned)k * gridDim.x;
-    const int per = (int)per_u, f = (int)__umulhi(idu, mper), rem = (int)idu - f * per, ty = (int)__umulhi((unsigned)rem, mtw);
+    const int per = (int)per_u, f = (int)cl_div(idu, mper), rem = (int)idu - f * per, ty = (int)cl_div((unsigned)rem, mtw);
     t.y0 = ty * SR_T;
     t.x0 = (rem - ty * tw) * SR_T;
     t.fpos = (unsigned)f * H * W;
@@ -427,6 +427,10 @@ bool cl16_sr_applies(const ClConv& g) {
     if (dt != 0 || dh != t / 3 - 1 || dw != t % 3 - 1 || (g.tap[t] >> 12) != t) return false;
   }
   if ((long long)g.N * g.Ti * g.Hi * g.Wi * SR_COUTP * 2 >= 0xFFFFFFF0LL) return false;
+  {                                                   // the tile decode by multiply-high is exact for ids < 2^32 / (tiles per frame)
+    const long long per = (long long)((g.Hi + SR_T - 1) / SR_T) * ((g.Wi + SR_T - 1) / SR_T);
+    if (((long long)g.N * g.Ti * per + 4096) * per >= 0xFFFFFFFFLL) return false;
+  }
   return true;
 }
 

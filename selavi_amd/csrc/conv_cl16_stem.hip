@@ -38,7 +38,9 @@ constexpr int ST_LDS_FWD = ST_IMG + 4 * ST_STAGE + 256 * 8;           // + where
 struct StemGeom {
   int N, Cin, T, H, W, Ho, Wo, Cout;
   int nbf, ncg;                                       // bands per frame, 8-column groups per row
-};
+  unsigned mnbf, mT, mncg;                            // their reciprocals (2^32 / d + 1: exact quotients by multiply-high; the
+};                                                    // band / tile decodes run per band and per 16-position tile)
+__device__ __forceinline__ int st_div(int n, unsigned m) { return (int)cl_div((unsigned)n, m); }
 
 // the staged image of a band: pixel idx = tid + 256 it -> (row, j); image column ix = j - 3
 struct StemFill {
@@ -62,8 +64,8 @@ __device__ __forceinline__ void stem_fill_init(StemFill& f, int tid, int W) {
 // channels >= Cin come back as zeros (out-of-range offsets)
 __device__ __forceinline__ void stem_load(const StemFill& f, const StemGeom& g, __amdgpu_buffer_rsrc_t rx, int b, int total,
                                           float (&r)[ST_FIT][3]) {
-  const int fr = b / g.nbf, band = b - fr * g.nbf;
-  const int n = fr / g.T, t = fr - n * g.T;
+  const int fr = st_div(b, g.mnbf), band = b - fr * g.nbf;
+  const int n = st_div(fr, g.mT), t = fr - n * g.T;
   const int iy0 = 2 * band * ST_ROWS - 3;
   const int HW = g.H * g.W;
   const int lo = b < total ? -iy0 : (1 << 21), hi = g.H - iy0;       // image rows row with lo <= row < hi exist
@@ -138,9 +140,9 @@ __global__ __launch_bounds__(256, MT == 3 ? 2 : 1) void cl16_stem_fwd_kernel(con
     stem_store(fill, lds, r);
     __syncthreads();
     stem_load(fill, g, rx, b + gridDim.x, total, r);  // the next band's pixels: in flight behind this band's MFMAs
-    const int fr = b / g.nbf, band = b - fr * g.nbf, oy0 = band * ST_ROWS;
+    const int fr = st_div(b, g.mnbf), band = b - fr * g.nbf, oy0 = band * ST_ROWS;
     for (int q = wave; q < 4 * g.ncg; q += 4) {
-      const int rp = q / g.ncg, cg = q - rp * g.ncg;
+      const int rp = st_div(q, g.mncg), cg = q - rp * g.ncg;
       const unsigned char* src = lds + lbase + rp * (4 * ST_PITCH) + cg * 128;
       f32x4 acc[MT];
 #pragma unroll
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256, MT == 3 ? 2 : 1) void cl16_stem_wgrad_kernel(c
   u32x4 gr[2], yr[2];
   unsigned gok = 0;                                   // bit h: piece h of the staged tile is a pixel of the image
   auto load_g = [&](int b, int cg) __attribute__((always_inline)) {
-    const int f = b / g.nbf, band = b - f * g.nbf, oy0 = band * ST_ROWS;
+    const int f = st_div(b, g.mnbf), band = b - f * g.nbf, oy0 = band * ST_ROWS;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int id = tid + 256 * h, pos = id >> 3, oy = oy0 + (pos >> 3), ox = cg * 8 + (pos & 7);
@@ -377,9 +379,10 @@ static bool stem_geom(StemGeom& g, int N, int Cin, int T, int H, int W, int Cout
   g.N = N, g.Cin = Cin, g.T = T, g.H = H, g.W = W, g.Cout = Cout;
   g.Ho = (H + 6 - 7) / 2 + 1, g.Wo = (W + 6 - 7) / 2 + 1;
   g.nbf = (g.Ho + ST_ROWS - 1) / ST_ROWS, g.ncg = (g.Wo + 7) / 8;
+  g.mnbf = cl_recip((unsigned)g.nbf), g.mT = cl_recip((unsigned)T), g.mncg = cl_recip((unsigned)g.ncg);
   if (2 * (g.ncg * 8 - 1) + 8 > ST_JW) return false;                   // the last column group's fragments stay inside a staged row
   if ((long long)N * Cin * T * H * W * 4 >= 0xFFFFFFF0LL || (long long)N * T * g.Ho * g.Wo * 128 >= 0xFFFFFFF0LL) return false;
-  if ((long long)N * T * g.nbf >= 0x7FFFFFFFLL) return false;
+  if (((long long)N * T * g.nbf + 4096) * (g.nbf > T ? g.nbf : T) >= 0xFFFFFFFFLL) return false;      // (exact multiply-high decodes)
   return true;
 }
 
