@@ -156,6 +156,36 @@ class BasicBlock(nn.Module):
         return self.relu(out)
 
 
+class Bottleneck(nn.Module):
+    """torchvision.models.resnet.Bottleneck (the "v1.5" form torchvision ships: the stride sits on the 3x3 conv), groups = 1,
+    base_width = 64 -> width = planes.  Used by model.py:105-106 for aud_base_arch = 'resnet50'."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64,
+                 dilation=1, norm_layer=None):
+        super().__init__()
+        width = int(planes * (base_width / 64.)) * groups
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, planes * self.expansion, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out = out + identity
+        return self.relu(out)
+
+
 class ResNet(nn.Module):
     def __init__(self, block, layers, num_classes=1000):
         super().__init__()
@@ -205,6 +235,14 @@ def _resnet(arch, block, layers, pretrained, progress, **kwargs):
 
 def resnet18(pretrained=False, progress=True, **kwargs):
     return _resnet('resnet18', BasicBlock, [2, 2, 2, 2], pretrained, progress, **kwargs)
+
+
+def resnet34(pretrained=False, progress=True, **kwargs):
+    return _resnet('resnet34', BasicBlock, [3, 4, 6, 3], pretrained, progress, **kwargs)
+
+
+def resnet50(pretrained=False, progress=True, **kwargs):
+    return _resnet('resnet50', Bottleneck, [3, 4, 6, 3], pretrained, progress, **kwargs)
 
 
 # --------------------------------------------------------------------------------------
@@ -262,9 +300,11 @@ def get_video_feature_extractor(vid_base_arch='r2plus1d_18', pretrained=False): 
 
 
 def get_audio_feature_extractor(aud_base_arch='resnet9'):                         # model.py:103-121
-    assert aud_base_arch in ('resnet9', 'resnet18')
-    layers = [1, 1, 1, 1] if aud_base_arch == 'resnet9' else [2, 2, 2, 2]
-    model = _resnet(aud_base_arch, BasicBlock, layers, False, False)
+    assert aud_base_arch in ('resnet9', 'resnet18', 'resnet34', 'resnet50')
+    if aud_base_arch == 'resnet9':                                                # model.py:112-115
+        model = _resnet(aud_base_arch, BasicBlock, [1, 1, 1, 1], False, False)
+    else:                                                                         # model.py:105-106
+        model = {'resnet18': resnet18, 'resnet34': resnet34, 'resnet50': resnet50}[aud_base_arch](pretrained=False)
     # conv1 is replaced AFTER the kaiming init -> default nn.Conv2d init for this layer
     model.conv1 = nn.Conv2d(1, 64, kernel_size=(7, 7), stride=(2, 2), padding=(3, 3), bias=False)
     model.fc = Identity()

@@ -367,7 +367,8 @@ def video_backward(ctx, saved, dfeat):
 
 
 def audio_forward(ctx, base, spec):
-    """ResNet-9/18 on 1 x F x T' spectrograms (torchvision ResNet), 2-D = 3-D with T=1."""
+    """ResNet-9/18/34 (two-conv blocks) and ResNet-50 (three-conv bottlenecks) on 1 x F x T' spectrograms (torchvision ResNet,
+    SURVEY 8 a3, model.py:103-121), 2-D = 3-D with T=1."""
     x = _as5d(spec)
     r0 = conv_bn(ctx, x, base.conv1, base.bn1, need_dx=False)
     u, idx = ctx.ops.bnrelu_maxpool_fwd(r0.y, r0.ss)
@@ -375,6 +376,8 @@ def audio_forward(ctx, base, spec):
     for layer in (base.layer1, base.layer2, base.layer3, base.layer4):
         for blk in layer:
             chain = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+            if hasattr(blk, "conv3"):
+                chain.append((blk.conv3, blk.bn3))
             ds = (blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
             rec = block_fwd(ctx, u, chain, ds)
             recs.append(rec)

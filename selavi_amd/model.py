@@ -21,8 +21,9 @@ def get_video_feature_extractor(vid_base_arch='r2plus1d_18', pretrained=False, d
 
 
 def get_audio_feature_extractor(aud_base_arch='resnet9', pretrained=False, duration=1):       # model.py:103-121
-    assert aud_base_arch in ('resnet9', 'resnet18')
-    return snn.AudioResNet((1, 1, 1, 1) if aud_base_arch == 'resnet9' else (2, 2, 2, 2))
+    layers = {'resnet9': (1, 1, 1, 1), 'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3), 'resnet50': (3, 4, 6, 3)}
+    assert aud_base_arch in layers
+    return snn.AudioResNet(layers[aud_base_arch], bottleneck=aud_base_arch == 'resnet50')
 
 
 class VideoBaseNetwork(nn.Module):    # model.py:135-149
@@ -155,6 +156,10 @@ class AVModel(nn.Module):             # model.py:169-252
             img_features = self.video_network(img).squeeze()
         if self.return_features:                                  # model.py:226-227
             return img_features, aud_features
+        if aud_features.shape[-1] != 512:
+            # the reference builds its heads for encoder_dim_a = 512 (model.py:198-199): its nn.Linear raises the same way
+            raise RuntimeError("size mismatch: the heads take 512-d audio features, this audio trunk yields %d "
+                               "(use return_features)" % aud_features.shape[-1])
         if aud_features.dim() == 1:
             aud_features = aud_features.unsqueeze(0)
         if img_features.dim() == 1:

@@ -161,11 +161,31 @@ class AudioBlock(nn.Module):
         self.downsample = downsample
 
 
-class AudioResNet(nn.Module):
-    """torchvision ResNet(BasicBlock, layers) with the 1-channel conv1 of model.py:117-119."""
+class AudioBottleneck(nn.Module):
+    """torchvision Bottleneck (1x1 -> 3x3 carrying the stride -> 1x1 to 4 x planes), same attribute / state_dict names
+    (model.py:105-106, aud_base_arch = 'resnet50').  The engine sees it as a three-conv chain (engine.audio_forward)."""
+    expansion = 4
 
-    def __init__(self, layers=(1, 1, 1, 1)):
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
+        self.conv1 = Conv(inplanes, planes, (1, 1), (1, 1), (0, 0), dims=2)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv(planes, planes, (3, 3), (stride, stride), (1, 1), dims=2)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = Conv(planes, planes * 4, (1, 1), (1, 1), (0, 0), dims=2)
+        self.bn3 = BatchNorm2d(planes * 4)
+        self.relu = ReLU()
+        self.downsample = downsample
+
+
+class AudioResNet(nn.Module):
+    """torchvision ResNet(block, layers) with the 1-channel conv1 of model.py:117-119: BasicBlock for resnet9 / 18 / 34,
+    Bottleneck (2048 features) for resnet50."""
+
+    def __init__(self, layers=(1, 1, 1, 1), bottleneck=False):
+        super().__init__()
+        block, exp = (AudioBottleneck, 4) if bottleneck else (AudioBlock, 1)
+        self.feature_dim = 512 * exp
         self.conv1 = Conv(1, 64, (7, 7), (2, 2), (3, 3), dims=2, init="default")
         self.bn1 = BatchNorm2d(64)
         self.relu = ReLU()
@@ -176,10 +196,10 @@ class AudioResNet(nn.Module):
             for j in range(n):
                 s = stride if j == 0 else 1
                 ds = None
-                if s != 1 or inpl != planes:
-                    ds = nn.Sequential(Conv(inpl, planes, (1, 1), (s, s), (0, 0), dims=2), BatchNorm2d(planes))
-                blocks.append(AudioBlock(inpl, planes, s, ds))
-                inpl = planes
+                if s != 1 or inpl != planes * exp:
+                    ds = nn.Sequential(Conv(inpl, planes * exp, (1, 1), (s, s), (0, 0), dims=2), BatchNorm2d(planes * exp))
+                blocks.append(block(inpl, planes, s, ds))
+                inpl = planes * exp
             setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
         self.avgpool = Identity()
         self.fc = Identity()

@@ -1,0 +1,120 @@
+"""The audio trunks beside ResNet-9 that ``get_audio_feature_extractor`` accepts (/root/reference/model.py:103-110):
+resnet18 / resnet34 (two-conv blocks, 512 features) and resnet50 (three-conv bottlenecks, 2048 features) -- the HIP engine
+against the CPU oracle's restatement of torchvision's ResNet (oracle/model_ref.py), forward and every parameter gradient.
+
+Same recipe as test_model_gpu.test_gradients_against_the_fp64_oracle_on_a_well_conditioned_network: blocks start close to the
+identity (last BatchNorm gamma 0.1) and every BatchNorm sees >= 96 values per channel, so that the comparison is not swamped
+by BatchNorm's amplification of rounding noise; the oracle runs in fp64 and, as the yardstick, in fp32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref
+from oracle.model_ref import portable_fill_, portable_init_
+
+ARCHS = ["resnet18", "resnet34", "resnet50"]
+
+
+def _damp(trunk):
+    with torch.no_grad():
+        for li in range(1, 5):
+            for blk in getattr(trunk, f"layer{li}"):
+                (blk.bn3 if hasattr(blk, "bn3") else blk.bn2).weight.fill_(0.1)
+
+
+def _trunks(arch):
+    from selavi_amd import model as smodel
+    return smodel.get_audio_feature_extractor(arch), model_ref.get_audio_feature_extractor(arch)
+
+
+@pytest.mark.parametrize("arch", ["resnet9"] + ARCHS)
+def test_state_dict_layout_is_torchvisions(arch):
+    """CPU: same keys, shapes and parameter counts as the restated torchvision trunk (fc removed, 1-channel conv1)."""
+    hip, ref = _trunks(arch)
+    a = {k: tuple(v.shape) for k, v in hip.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert a == b
+    assert [n for n, _ in hip.named_parameters()] == [n for n, _ in ref.named_parameters()]
+    # torchvision's documented sizes (3-channel conv1, fc-1000): resnet34 21 797 672, resnet50 25 557 032
+    full = {"resnet34": (21797672, 512), "resnet50": (25557032, 2048)}.get(arch)
+    if full is not None:
+        n = sum(p.numel() for p in ref.parameters())
+        assert n + 2 * 64 * 49 + full[1] * 1000 + 1000 == full[0]
+    assert hip.feature_dim == (2048 if arch == "resnet50" else 512)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ARCHS)
+def test_audio_trunk_forward_and_gradients_match_the_fp64_oracle(arch):
+    B = 8
+    spec = portable_fill_(torch.empty(B, 1, 128, 96), 6)
+    res = {}
+    for kind in ("hip", "oracle64", "oracle32"):
+        hip, ref = _trunks(arch)
+        m = hip if kind == "hip" else ref
+        portable_init_(m, seed=31)
+        _damp(m)
+        w = portable_fill_(torch.empty(B, hip.feature_dim), 9)
+        if kind == "hip":
+            m = m.cuda().train()
+            feat = m(spec.cuda()).reshape(B, -1)
+            (feat * w.cuda()).sum().backward()
+        else:
+            dt = torch.float64 if kind == "oracle64" else torch.float32
+            m = m.to(dt).train()
+            feat = m(spec.to(dt)).reshape(B, -1)
+            (feat * w.to(dt)).sum().backward()
+        res[kind] = (feat.detach().double().cpu(), {n: p.grad.detach().double().cpu() for n, p in m.named_parameters()},
+                     {n: b.detach().double().cpu() for n, b in m.named_buffers() if "running" in n})
+    f64, g64, r64 = res["oracle64"]
+    names = sorted(g64)
+    rows = {}
+    for kind in ("hip", "oracle32"):
+        f, g, r = res[kind]
+        assert set(g) == set(g64)
+        ferr = float((f - f64).norm() / f64.norm())
+        rel = np.array([float((g[n] - g64[n]).norm() / (g64[n].norm() + 1e-300)) for n in names])
+        rerr = max(float((r[n] - r64[n]).norm() / (r64[n].norm() + 1e-300)) for n in r64)
+        rows[kind] = (ferr, rel, rerr)
+        print(f"{arch} {kind}: features {ferr:.2e}; gradients rel L2 median {np.median(rel):.2e} worst {rel.max():.2e} "
+              f"({names[int(rel.argmax())]}); running statistics {rerr:.2e}")
+    ferr, rel, rerr = rows["hip"]
+    ferr32, rel32, rerr32 = rows["oracle32"]
+    assert ferr <= max(1e-5, 3 * ferr32), (ferr, ferr32)
+    assert rerr <= max(1e-5, 3 * rerr32), (rerr, rerr32)
+    # ReLU-mask flips of elements within one rounding of zero are the irreducible part of ANY fp32 run (see the test named
+    # above): one flipped element moves the tensors upstream of it by 1e-4 .. 2e-3 -- the oracle's own fp32 run shows it on
+    # resnet18 (5.8e-4 on layer2.0.bn1.bias, the HIP run lands on the same value), the HIP run on resnet34 (2.3e-3 on
+    # layer2.0.bn2.bias, 2e-4 .. 1.3e-3 upstream) where the oracle's fp32 run happens to flip nothing.  So: every tensor within
+    # 5e-3 (a 1 % error in any one tensor fails), the bulk (median) at rounding level.
+    tol = max(5e-3, 3 * rel32.max())
+    assert tol <= 2e-2, rel32.max()
+    bad = [(n, r) for n, r in zip(names, rel) if r > tol]
+    assert not bad, (tol, bad[:8])
+    assert np.median(rel) <= max(1e-5, 3 * np.median(rel32)), (np.median(rel), np.median(rel32))
+
+
+@pytest.mark.gpu
+def test_resnet34_model_steps_and_resnet50_meets_the_reference_heads():
+    """AVModel(aud_base_arch=...): resnet34 feeds the 512-d heads (logits against the oracle, eval mode, 1e-3 = BASELINE's
+    tolerance); resnet50's 2048 features do not fit the heads the reference builds (encoder_dim_a = 512, model.py:198-199:
+    its nn.Linear raises a size mismatch) -- here a RuntimeError as well, while return_features works."""
+    from selavi_amd import model as smodel
+    video = portable_fill_(torch.empty(4, 3, 8, 64, 64), 5)
+    audio = portable_fill_(torch.empty(4, 1, 80, 64), 6)
+    outs = {}
+    for mod in (smodel, model_ref):
+        m = mod.load_model(aud_base_arch="resnet34", use_mlp=True, num_classes=12, norm_feat=False, headcount=2)
+        portable_init_(m, seed=31)
+        m = (m.cuda() if mod is smodel else m).eval()
+        with torch.no_grad():
+            v, a = m(video.cuda(), audio.cuda()) if mod is smodel else m(video, audio)
+        outs[mod is smodel] = torch.stack([x.float().cpu() for x in list(v) + list(a)])
+    assert (outs[True] - outs[False]).abs().max().item() <= 1e-3
+    m = smodel.load_model(aud_base_arch="resnet50", use_mlp=True, num_classes=12, headcount=2).cuda().eval()
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            m(video.cuda(), audio.cuda())
+        m.return_features = True
+        fv, fa = m(video.cuda(), audio.cuda())
+    assert tuple(fv.shape) == (4, 512) and tuple(fa.shape) == (4, 2048)
