@@ -44,7 +44,7 @@ FWD_MB_PER_CLIP = 518.1 + 3.38          # sum over convs of (in + out
 def _pmc_traffic(key):
     """Measured HBM bytes/launch recorded by the PMC passes of this round (tools/pmc_traffic.sh ->
     profiles/r01_pmc.json; None if not recorded)."""
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             v = d.get(key)
@@ -189,10 +189,27 @@ def sk_bench(rank, world, dev, iters=50):
         t = torch.tensor([ms], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = t.item()
+    split = None
+    if world > 1:
+        # the same shard without the exchange (the single-GPU loop on the local rows): what of an iteration is the pass over
+        # the shard and what is the K-vector all-reduce (+ its launch latency) -- SURVEY 8e-2
+        be.iterate(P, beta, r, 0.0, 10 ** 9, 5, ws, grid)
+        torch.cuda.synchronize()
+        e0.record()
+        be.iterate(P, beta, r, 0.0, 10 ** 9, iters, ws, grid)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_local = e0.elapsed_time(e1) / iters
+        t = torch.tensor([ms_local], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_local = t.item()
+        split = dict(us_pass_reduce_update=ms_local * 1e3, us_allreduce=max(ms - ms_local, 0.0) * 1e3,
+                     transport="native: slv_sk_iterate_sharded (RCCL on the compute stream)" if comm is not None
+                     else "torch.distributed all_reduce per iteration")
     gbs = n * K * 8 / ms / 1e6      # per-GPU algorithmic bytes (one read of the fp64 shard) / time
     note = None if world == 1 else ("rows sharded over %d GPUs: the pass over a shard takes ~%.0f us, each iteration is then bound by "
                                     "the latency of its K-vector all-reduce (RCCL on the compute stream, slv_sk_iterate_sharded)" % (world, 76.0 / world))
-    return dict(iters_per_s=1e3 / ms, us_per_iter=ms * 1e3, N=N, K=K, rows_per_gpu=n, grid=grid, note=note,
+    return dict(iters_per_s=1e3 / ms, us_per_iter=ms * 1e3, us_per_iter_split=split, N=N, K=K, rows_per_gpu=n, grid=grid, note=note,
                 roofline=dict(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
                               traffic=_pmc_traffic("sk_pass") if world == 1 else None))
 
@@ -263,23 +280,38 @@ PEAK_BF16_MFMA_TF = 2500.0
 
 
 HOT_X3_KERNEL = "igemm3_kernel<9, 2, 1, 0, 4, 2, true>"     # csrc/igemm3.hpp: MT, NT, PRO, EPI, WAVES, OCC, FUSE of the layer-1 spatial forward
-HOT16_KERNEL = "conv_cl16_sr_kernel<1, 1>"      # csrc/conv_cl16_sr.hip: one persistent workgroup per CU (grid 256)
+RIDGE_BF16 = PEAK_BF16_MFMA_TF_DENSE * 1e3 / PEAK_HBM_GBS      # 312.5 FLOP/B: above it a bf16 kernel is MFMA-bound, below HBM-bound
+# The two layer-1 forward kernels of the 16-bit path (68 % of the forward's bytes, 45 % of its FLOPs), one on each side of the ridge:
+#   spatial  Conv3d(64 -> 144, (1,3,3)): 2*144*64*9 FLOP / ((64+144)*2 B) = 399 FLOP/B  -> MFMA-bound
+#   temporal Conv3d(144 -> 64, (3,1,1)): 2*144*64*3 FLOP / ((144+64)*2 B) = 133 FLOP/B  -> HBM-bound   
+HOT16 = {
+    "l1_spatial": dict(cin=64, cout=144, k=(1, 3, 3), pad=(0, 1, 1), kernel="conv_cl16_sr_kernel<1, 1>", grid=256, pmc="hot_conv16_fwd",
+                       what="conv_cl16_sr_kernel<1,1> (csrc/conv_cl16_sr.hip: weights resident in registers, three MFMA waves + a "
+                            "data-movement wave per CU, persistent) layer1 (1,3,3) 64->144 train forward"),
+    "l1_temporal": dict(cin=144, cout=64, k=(3, 1, 1), pad=(1, 0, 0), kernel="conv_cl16_tr_kernel<4, 5, 1, 1>", grid=1024,
+                        pmc="hot_conv16_fwd_temporal",
+                        what="conv_cl16_tr_kernel<4,5,1,1> (csrc/conv_cl16_tr.hip: weights resident in registers, 32-pixel columns "
+                             "walked frame by frame) layer1 (3,1,1) 144->64 train forward"),
+}
 
 
-def hot_conv16_roofline(batch, T, dev):
-    """Dominant kernel of the 16-bit forward: conv_cl16_sr_kernel<PRO, EPI> (csrc/conv_cl16_sr.hip: weights resident in
-    registers, three MFMA waves + a data-movement wave per CU) on the layer-1 spatial conv Conv3d(64->144,(1,3,3)) (train
-    mode: BatchNorm + ReLU prologue on load, statistics epilogue), timed with HIP events on its stream.  Algorithmic
-    bytes = input + output in bf16 (64 + 144 channels x 2 B per position)."""
-    from selavi_amd import ops16
-
+def _conv16_holder(L):
     class Conv:
-        in_channels, out_channels, kernel3, stride3, padding3 = 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)
+        in_channels, out_channels, kernel3, stride3, padding3 = L["cin"], L["cout"], L["k"], (1, 1, 1), L["pad"]
+    return Conv
+
+
+def hot_conv16_roofline(name, batch, T, dev):
+    """One of the two dominant kernels of the 16-bit forward (HOT16) in train mode (BatchNorm + ReLU prologue on load,
+    statistics epilogue), alone on the chip, timed with HIP events on its stream.  Algorithmic bytes = input + output in bf16
+    ((Cin + Cout) channels x 2 B per position), FLOPs = 2 Cin Cout taps per position."""
+    from selavi_amd import ops16
+    L = HOT16[name]
     g = torch.Generator(device=dev).manual_seed(7)
-    x = ops16.to_channels_last16(torch.randn(batch, 64, T, 56, 56, device=dev, generator=g))
-    plan = ops16.plan_for(x, Conv)
-    w = torch.randn(144, 64, 1, 3, 3, device=dev, generator=g) * 0.04
-    ss = torch.stack([torch.rand(64, device=dev, generator=g) + 0.5, torch.randn(64, device=dev, generator=g) * 0.1]).contiguous()
+    x = ops16.to_channels_last16(torch.randn(batch, L["cin"], T, 56, 56, device=dev, generator=g))
+    plan = ops16.plan_for(x, _conv16_holder(L))
+    w = torch.randn(L["cout"], L["cin"], *L["k"], device=dev, generator=g) * 0.04
+    ss = torch.stack([torch.rand(L["cin"], device=dev, generator=g) + 0.5, torch.randn(L["cin"], device=dev, generator=g) * 0.1]).contiguous()
     wf, _ = ops16.conv_w_transform(plan, w, need_wt=False)
     for _ in range(3):
         ops16.conv_fwd(plan, x, w, in_ss=ss, in_relu=True, wf=wf)
@@ -290,9 +322,40 @@ def hot_conv16_roofline(batch, T, dev):
         ops16.conv_fwd(plan, x, w, in_ss=ss, in_relu=True, wf=wf)
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    pos = batch * T * 56 * 56
-    return dict(ms=ms, flop=2.0 * pos * 144 * 64 * 9, bytes=pos * (64 + 144) * 2.0)
+    return dict(ms=e0.elapsed_time(e1) / reps, clips=batch)
+
+
+def _roof16(name, T, iso, live, frozen, pmc_bytes_16x16):
+    """Roofline object of one HOT16 kernel: `bound` follows its arithmetic intensity against the ridge; `frac` is the fraction
+    of THAT roof; the other roof's fraction rides along.  iso = isolated launch, live = the launches inside the cfg5 step
+    (HIP events on the launch's stream, this run), frozen = the committed rocprofv3 average of the same launch (digest-matched)."""
+    L = HOT16[name]
+    taps = L["k"][0] * L["k"][1] * L["k"][2]
+    flop_pos, byte_pos = 2.0 * L["cin"] * L["cout"] * taps, (L["cin"] + L["cout"]) * 2.0
+    ai = flop_pos / byte_pos
+    bound = "mfma" if ai > RIDGE_BF16 else "hbm"
+
+    def rates(ms, clips):
+        pos = clips * T * 56 * 56
+        gbs, tf = pos * byte_pos / ms / 1e6, pos * flop_pos / ms / 1e9
+        return dict(ms=ms, clips_per_launch=clips, hbm_gbs=gbs, hbm_frac=gbs / PEAK_HBM_GBS, mfma_tflops=tf,
+                    mfma_frac=tf / PEAK_BF16_MFMA_TF_DENSE,
+                    achieved=tf if bound == "mfma" else gbs, frac=tf / PEAK_BF16_MFMA_TF_DENSE if bound == "mfma" else gbs / PEAK_HBM_GBS)
+    r = rates(iso["ms"], iso["clips"])
+    out = {"bound": bound, "achieved": r["achieved"], "peak": PEAK_BF16_MFMA_TF_DENSE if bound == "mfma" else PEAK_HBM_GBS,
+           "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": r["frac"],
+           "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": RIDGE_BF16,
+           "kernel": L["what"] + " at bs %d (alone on the chip)" % iso["clips"], "ms_per_launch": iso["ms"],
+           "hbm_gbs": r["hbm_gbs"], "hbm_frac": r["hbm_frac"], "mfma_tflops": r["mfma_tflops"], "mfma_frac": r["mfma_frac"],
+           # PMC bytes per launch at 16 clips x 16 frames (tools/pmc_traffic.sh), scaled to this launch's positions
+           "traffic": None if pmc_bytes_16x16 is None else pmc_bytes_16x16 * (iso["clips"] * T) / (16.0 * 16.0),
+           "algorithmic_bytes_per_launch": iso["clips"] * T * 56 * 56 * byte_pos}
+    if live is not None:
+        out["in_step_live"] = live if "error" in live else dict(
+            rates(live["ms"], live["clips"]), launches=live["launches"], min_ms=live["min_ms"], max_ms=live["max_ms"], how=live["how"])
+    if frozen is not None:
+        out["in_step"] = dict(frozen, **{k: v for k, v in rates(frozen["ms"], frozen["clips"]).items() if k != "ms"})
+    return out
 
 
 def bf16_leg(a, rank, world, local, dev):
@@ -349,10 +412,38 @@ def bf16_leg(a, rank, world, local, dev):
             m(video, audio)
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - tf0) / 5 * 1e3
-    hot = hot_conv16_roofline(min(B, 64), T, dev)
     from selavi_amd import ops16 as _o16
-    _hp = _o16.Plan16.get(B, T, 56, 56, 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), dev)
-    hot_clips = B if _hp.chunks is None else _hp.chunks[0][1] - _hp.chunks[0][0]      # clips one launch of that conv covers in the step
+    # the two layer-1 forward kernels: alone on the chip, and LIVE inside the step (HIP events around each of their launches on
+    # the stream they run on, over 2 extra untimed steps -- in the step they share the chip with the audio trunk's stream)
+    plans, clips_per_launch = {}, {}
+    for name, L in HOT16.items():
+        hp = _o16.Plan16.get(B, T, 56, 56, L["cin"], L["cout"], L["k"], (1, 1, 1), L["pad"], dev)
+        if hp.chunks is None:
+            plans[name], clips_per_launch[name] = hp, B
+        else:                               # sliced at the 32-bit buffer range: the first slice's launches
+            plans[name], clips_per_launch[name] = hp.chunks[0][2], hp.chunks[0][1] - hp.chunks[0][0]
+    live = {}
+    try:
+        with _o16.probe_conv_fwd(plans, prologue=True) as pr:
+            for _ in range(2):
+                train.train_step(net, opt, video, audio, selflabels, selected, hc)
+        for name, tms in pr.ms().items():
+            if tms:
+                live[name] = dict(ms=sum(tms) / len(tms), launches=len(tms), min_ms=min(tms), max_ms=max(tms),
+                                  clips=clips_per_launch[name],
+                                  how="HIP events around the launch on its stream, 2 extra steps after the timed region")
+    except Exception as e:          # measurement garnish: never take the leg down
+        if world > 1:
+            raise
+        live = {name: dict(error=repr(e)) for name in HOT16}
+    roofs = {}
+    for name, L in HOT16.items():
+        iso = hot_conv16_roofline(name, min(B, 64), T, dev)
+        fz = _rocprof_in_step(L["kernel"], L["grid"], ("r06_step16_cfg5_kernel_summary.txt", "r05_step16_cfg5_kernel_summary.txt")) \
+            if B == CFG5["batch"] else None
+        if fz is not None:
+            fz = dict(fz, clips=clips_per_launch[name])
+        roofs[name] = _roof16(name, T, iso, live.get(name), fz, _pmc_traffic(L["pmc"]))
     step_tf = 3 * FWD_GFLOP_PER_CLIP_T32 * B / ms
     step_gbs = 3 * FWD_MB_PER_CLIP_T32_BF16 * B / ms
     loss_v = float(loss.item())
@@ -370,22 +461,10 @@ def bf16_leg(a, rank, world, local, dev):
                                "per-GPU bs=%d, 32x112x112 video, 1x129x100 log-mel, K=309, headcount=10" % B,
                    "global_batch": world * B, "parallelism": "dp%d" % world, "loss_last_step": loss_v,
                    "peak_hbm_gb": round(peak / 2 ** 30, 2)},
-        "roofline": {"bound": "hbm", "achieved": hot["bytes"] / hot["ms"] / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": hot["bytes"] / hot["ms"] / 1e6 / PEAK_HBM_GBS,
-                     # PMC bytes per launch at 16 clips x 16 frames (tools/pmc_traffic.sh), scaled to this launch's positions
-                     "traffic": (lambda t: None if t is None else t * (min(B, 64) * T) / (16.0 * 16.0))(_pmc_traffic("hot_conv16_fwd")),
-                     "kernel": "conv_cl16_sr_kernel<1,1> (register-resident weights, persistent) layer1 (1,3,3) 64->144 train forward at bs %d" % min(B, 64),
-                     "ms_per_launch": hot["ms"], "mfma_tflops": hot["flop"] / hot["ms"] / 1e9,
-                     "mfma_frac": hot["flop"] / hot["ms"] / 1e9 / PEAK_BF16_MFMA_TF,
-                     # the same kernel inside the cfg5 step (full 128 x 32-frame launch; frozen figure, see _rocprof_in_step)
-                     "in_step": (lambda r: None if r is None else dict(
-                         # (a launch covers the whole batch: 128 clips x 32 frames x 160 stored channels = 4.11 GB stays under the
-                         #  32-bit buffer range, ops16.Plan16 does not slice it -- rounds 3-4 priced this figure as if it were half)
-                         r, clips_per_launch=hot_clips, achieved=hot_clips * T * 56 * 56 * (64 + 144) * 2.0 / r["ms"] / 1e6,
-                         frac=hot_clips * T * 56 * 56 * (64 + 144) * 2.0 / r["ms"] / 1e6 / PEAK_HBM_GBS))(
-                         _rocprof_in_step(HOT16_KERNEL, 256, ("r05_step16_cfg5_kernel_summary.txt",))
-                         if B == CFG5["batch"] else None),
-                     "note": "bf16: this conv's arithmetic intensity (128 FLOP/B) is below the ridge (312): HBM-bound"},
+        # `roofline` = the HBM-bound one of the two dominant forward kernels (the north star quotes the forward against the HBM
+        # roofline); `roofline_mfma_kernel` = the MFMA-bound one (the largest single kernel of the forward by time)
+        "roofline": roofs["l1_temporal"],
+        "roofline_mfma_kernel": roofs["l1_spatial"],
         "step_roofline": {"mfma": {"achieved": step_tf, "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s per GPU",
                                    "frac": step_tf / PEAK_BF16_MFMA_TF},
                           "hbm": {"achieved": step_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s per GPU (algorithmic)",
@@ -601,7 +680,21 @@ def main():
         if world > 1:
             raise                   # (but ranks must not diverge inside the step's collectives)
         in_step_live = dict(error=repr(e))
+    # N > 1: what the data-parallel exchanges cost, so that the first real multi-GPU line explains itself (main.py:117-118,
+    # 156-160; utils.py:133-146): transport and the ranks RCCL reports per communicator, SyncBN exchanges per step and their
+    # mean duration, the gradient buckets' bytes and the EXPOSED wait for them -- over 2 extra (untimed) steps
+    comm_diag = None
+    if world > 1:
+        from selavi_amd import comm as scomm
+        with scomm.diagnostics() as dg:
+            for _ in range(2):
+                step()
+        comm_diag = dg.report(steps=2)
     sk = None if a.no_sk else sk_bench(rank, world, dev)
+    if comm_diag is not None:
+        comm_diag = dict(scomm.describe(), wrapper=type(net).__name__, **comm_diag)      # (after SK: its communicator exists now)
+        if sk is not None:
+            comm_diag["sk"] = dict(us_per_iter=sk["us_per_iter"], **(sk["us_per_iter_split"] or {}))
     sk_round = sk_round_estimate(m, dev, world, clips, sk) if sk else None
     # the same step on the NATIVE fp32-input MFMA kernels (csrc/igemm.hpp, v_mfma_f32_16x16x4_f32): what the headline was in
     # rounds 1-3, for comparison with the split-operand arithmetic the headline runs on now (csrc/igemm3.hpp)
@@ -707,7 +800,7 @@ def main():
                              r, achieved=hot["flop"] / r["ms"] / 1e9,
                              frac=hot["flop"] / r["ms"] / 1e9 / (PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF)))(
                              _rocprof_in_step(HOT_X3_KERNEL if hot["x3"] else "igemm_kernel<0, 9, 2, true, 1, 1, 0, 0, 0>", 6272,
-                                              ("r05_bench_kernel_summary.txt",))
+                                              ("r06_bench_kernel_summary.txt", "r05_bench_kernel_summary.txt"))
                              if B == CFG2["batch"] else None)},
             "step_roofline": {"bound": "mfma", "achieved": step_tflops, "peak": PEAK_X3_TF if hot["x3"] else PEAK_FP32_MFMA_TF,
                               "unit": "TFLOP/s per GPU (algorithmic 3 x %.2f GFLOP/clip)" % FWD_GFLOP_PER_CLIP,
@@ -722,6 +815,7 @@ def main():
                                 "frac": FWD_MB_PER_CLIP * B / fwd_ms / PEAK_HBM_GBS,
                                 "note": "algorithmic fused-forward bytes (SURVEY 8d: 518.1 + 3.4 MB/clip); the fp32 "
                                         "forward is MFMA-bound, its compute ceiling is 12.5 % of the HBM roofline"}},
+            "comm": comm_diag,
             "sk": sk,
             "sk_round": sk_round,
             "cfg5_bf16": cfg5,

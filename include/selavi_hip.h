@@ -48,6 +48,7 @@ int slv_comm_init(slv_comm_t* comm_out /* host */, const void* unique_id_128 /* 
 int slv_comm_destroy(slv_comm_t comm);
 int slv_comm_abort(slv_comm_t comm);               /* ncclCommAbort: tear down a communicator whose collective hangs (watchdog) */
 int slv_comm_async_error(slv_comm_t comm);         /* ncclCommGetAsyncError: 0 = healthy / in progress, < 0 = failed            */
+int32_t slv_comm_count(slv_comm_t comm);          /* ncclCommCount: the ranks RCCL itself reports for this communicator (-1: not available) */
 int32_t slv_comm_rank(slv_comm_t comm);
 int32_t slv_comm_world(slv_comm_t comm);
 int slv_comm_allreduce_f64(slv_comm_t comm, double* buf, int64_t n, slv_stream_t stream);              /* sum */

@@ -188,6 +188,102 @@ class NativeComm:
         return p.decode() if p else ""
 
 
+# ---------------------------------------------------------------------------------------------------------------- diagnostics
+DIAG = None          # {"syncbn": [(event, event)], "grad_wait": [...], "grad_bytes": n, "grad_collectives": n} while comm.diagnostics() is open
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOSPAN = _NoSpan()
+
+
+class _Span:
+    """HIP events on the current stream around an exchange (two records; measurement only)."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def __exit__(self, *exc):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        if DIAG is not None:
+            DIAG[self.kind].append((self.e0, e1))
+        return False
+
+
+def span(kind):
+    """``with comm.span("syncbn"): <partials -> sums, all-reduce, sums -> coefficients>`` -- a no-op unless a
+    ``comm.diagnostics()`` block is open (bench.py's N > 1 line)."""
+    return _NOSPAN if DIAG is None else _Span(kind)
+
+
+class diagnostics:
+    """``with comm.diagnostics() as d: step(); step()`` then ``d.report(steps=2)``: what the data-parallel exchanges of those
+    steps cost ON THE DEVICE, from HIP events on the streams they run on --
+      * syncbn: every SyncBN exchange (main.py:117-118; partials -> fp64 sums, K-vector all-reduce, sums -> coefficients),
+        count per step and mean / total duration;
+      * grad: the gradient buckets (main.py:156-160): collectives and bytes per step, and the EXPOSED wait -- how long the
+        compute stream stood still in the final callback until the last bucket had landed (0 = fully overlapped).
+    Measurement only: the events add two records per exchange."""
+
+    def __enter__(self):
+        global DIAG
+        DIAG = self.state = {"syncbn": [], "grad_wait": [], "grad_bytes": 0, "grad_collectives": 0, "grad_wait_host_s": 0.0}
+        return self
+
+    def __exit__(self, *exc):
+        global DIAG
+        DIAG = None
+        return False
+
+    def report(self, steps):
+        torch.cuda.synchronize()
+        st = self.state
+        sb = [a.elapsed_time(b) for a, b in st["syncbn"]]
+        gw = [a.elapsed_time(b) for a, b in st["grad_wait"]]
+        n = max(steps, 1)
+        return {"syncbn": {"exchanges_per_step": len(sb) / n, "mean_ms": (sum(sb) / len(sb)) if sb else None,
+                           "max_ms": max(sb) if sb else None, "total_ms_per_step": sum(sb) / n,
+                           "how": "HIP events around each exchange on its compute stream (kernels of the exchange included)"},
+                "grad_allreduce": {"collectives_per_step": st["grad_collectives"] / n, "bytes_per_step": st["grad_bytes"] / n,
+                                   "exposed_wait_ms_per_step": sum(gw) / n,
+                                   "host_blocked_ms_per_step": st["grad_wait_host_s"] * 1e3 / n,
+                                   "how": "HIP events around the compute stream's wait for the buckets' stream in the "
+                                          "backward's final callback: 0 = the all-reduces were hidden behind backward"}}
+
+
+def describe(group=None):
+    """Which transport carries the exchanges of ``group`` in this process, and what RCCL itself reports about it."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"transport": "none (single process)"}
+    gid_ = 0 if (group is None or group is dist.group.WORLD) else id(group)
+    comms = {tag: c for (g, tag), c in NativeComm._cache.items() if g == gid_}
+    out = {"world": dist.get_world_size(group), "bootstrap_backend": dist.get_backend(group),
+           "native_comm_mode": NativeComm.mode(), "preflight": "failed: " + NativeComm._disabled if NativeComm._disabled else "ok"}
+    if comms:
+        any_c = next(iter(comms.values()))
+        out["transport"] = "native: RCCL behind the C ABI (slv_comm_*) on the compute / bucket streams"
+        out["library"] = any_c.library()
+        # ncclCommCount per communicator: the ranks RCCL itself has in it (-1: the loaded library has no ncclCommCount)
+        out["communicators"] = {tag: {"ranks_rccl_reports": int(C.slv_comm_count(c.h)), "world": c.world, "rank": c.rank}
+                                for tag, c in sorted(comms.items())}
+    else:
+        out["transport"] = "torch.distributed (%s) collectives" % dist.get_backend(group)
+        out["communicators"] = {}
+    return out
+
+
 def allreduce_sum_(t, where):
     """Sum ``t`` in place over ``where``: a NativeComm (RCCL call on the current stream) or a torch process group."""
     if isinstance(where, NativeComm):

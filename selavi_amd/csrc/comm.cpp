@@ -28,6 +28,7 @@ struct RcclApi {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                       // optional (watchdog path)
   ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr; // optional
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;            // optional (diagnostics)
   char path[512] = {0};
 };
 static RcclApi g_api;
@@ -68,6 +69,7 @@ static int load_api(const char* path_hint) {
 #undef SLV_SYM
   *(void**)(&g_api.CommAbort) = dlsym(h, "ncclCommAbort");
   *(void**)(&g_api.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");
+  *(void**)(&g_api.CommCount) = dlsym(h, "ncclCommCount");
   g_api.handle = h;
   return 0;
 }
@@ -159,6 +161,16 @@ int slv_comm_async_error(slv_comm_t comm) {
   SLV_NCCL(g_api.CommGetAsyncError(c->nccl, &st));
   if (st != ncclSuccess && st != ncclInProgress) return fail(-6, "slv_comm_async_error: %s", g_api.GetErrorString(st));
   return 0;
+}
+
+int32_t slv_comm_count(slv_comm_t comm) {
+  using namespace slv;
+  if (!comm) return 0;
+  Comm* c = (Comm*)comm;
+  if (!g_api.CommCount) return -1;
+  int n = 0;
+  if (g_api.CommCount(c->nccl, &n) != ncclSuccess) return -1;
+  return n;
 }
 
 int32_t slv_comm_rank(slv_comm_t comm) { return comm ? ((slv::Comm*)comm)->rank : 0; }

@@ -58,7 +58,7 @@ __device__ __forceinline__ void sd_mfma0_a(f32x4& acc, const bf16x8& a, const bf
 // one LDS-DMA instruction: 64 lanes x 16 bytes from memory (per-lane byte offset voff into the buffer rsrc) to the
 // wave-uniform LDS address lds_addr + 16 lane.  Invisible to the compiler's wait-count bookkeeping (on purpose).
 __device__ __forceinline__ void sd_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" SLV_DMA_NT_STR " lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" SLV_DMA_NT_STR " lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "m0", "memory");
 }
 
 struct SdTile {

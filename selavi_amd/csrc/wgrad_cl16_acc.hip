@@ -48,7 +48,7 @@ constexpr int WA_LDS = 3 * WA_XBUF + 3 * WA_YBUF;      // 129 024
 constexpr int WA_NA = 64;                      // accumulator tiles in AGPRs (of 81)
 
 __device__ __forceinline__ void wa_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" SLV_DMA_NT_STR " lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" SLV_DMA_NT_STR " lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "m0", "memory");
 }
 
 struct WaTile {

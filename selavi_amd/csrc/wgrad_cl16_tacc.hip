@@ -45,7 +45,7 @@ constexpr int TA_NYB = 6;                           // dY tiles in the ring
 constexpr int TA_LDS = 2 * TA_XBUF + TA_NYB * TA_YBUF;   // 75 776
 
 __device__ __forceinline__ void ta_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" SLV_DMA_NT_STR " lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" SLV_DMA_NT_STR " lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "m0", "memory");
 }
 
 struct TaStep {

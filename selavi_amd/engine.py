@@ -302,11 +302,13 @@ def _video_blocks(layer):
         yield chain, ds
 
 
-def video_stage_forward(ctx, base, stage, x):
+def video_stage_forward(ctx, base, stage, x, aux=None):
     """One stage of R(2+1)D-18 (torchvision VideoResNet): the stem, or a residual layer
     (layer4 ends with the global average pool -> feat [B,512]).  Returns (output, saved record).
     The trunk is cut into stages so that every stage is its own autograd node: under DDP the
-    gradients of layer4 (75 % of the parameters) are all-reduced while layers 3..1 still run backward."""
+    gradients of layer4 (75 % of the parameters) are all-reduced while layers 3..1 still run backward.
+    ``aux``: what the previous stage returned beside its output -- the stem's scale / shift when its output is handed over
+    un-materialised (LAZY_STEM_TAIL: the stem then returns (raw tensor, scale_shift) and layer1 takes that pair)."""
     if stage == "stem":
         st = base.stem
         r0 = conv_bn(ctx, x, st[0], st[1], need_dx=False)
@@ -314,16 +316,14 @@ def video_stage_forward(ctx, base, stage, x):
         if getattr(ctx.ops, "LAZY_STEM_TAIL", False):
             # the stem's output relu(bn(.)) is NOT materialised: layer 1's first conv and its first block tail apply the
             # BatchNorm + ReLU on load (one pass over a 64-channel tensor less: 0.7 ms of the cfg5 forward).  The stage hands
-            # the RAW tensor to the next autograd node and its scale / shift beside it (base._stem_ss); the gradient that
-            # comes back is, as before, the one w.r.t. the ACTIVATED output.
-            base._stem_ss = r1.ss
-            return r1.y, (r0, r1)
+            # the RAW tensor to the next autograd node and its scale / shift beside it as a second (non-differentiable)
+            # output; the gradient that comes back is, as before, the one w.r.t. the ACTIVATED output.
+            return (r1.y, r1.ss), (r0, r1)
         return tail(ctx, r1), (r0, r1)
     u, recs = x, []
-    if stage == "layer1" and getattr(ctx.ops, "LAZY_STEM_TAIL", False):
-        ss, base._stem_ss = getattr(base, "_stem_ss", None), None
-        assert ss is not None, "layer1 runs behind the stem stage of the same pass"
-        u = Raw(x, ss, None, None, None, None, None)
+    if aux is not None:
+        assert stage == "layer1", "only the stem hands its output over un-materialised"
+        u = Raw(x, aux, None, None, None, None, None)
     for chain, ds in _video_blocks(getattr(base, stage)):
         rec = block_fwd(ctx, u, chain, ds)
         recs.append(rec)
@@ -353,9 +353,10 @@ def video_stage_backward(ctx, stage, saved, dout):
 
 def video_forward(ctx, base, x):
     """Whole trunk in one call (used by tools/tests): returns (feat [B,512], saved records)."""
-    saved = []
+    saved, aux = [], None
     for st in VIDEO_STAGES:
-        x, sv = video_stage_forward(ctx, base, st, x)
+        x, sv = video_stage_forward(ctx, base, st, x, aux)
+        x, aux = x if isinstance(x, tuple) else (x, None)
         saved.append(sv)
     return x, saved
 

@@ -144,9 +144,12 @@ class VideoResNet(nn.Module):
         self.precision = "fp32"        # "bf16": the 16-bit MFMA path (ops16; main.py:151 --use_fp16), see AVModel.set_precision
 
     def forward(self, x):
-        u = x.contiguous()
+        u, aux = x.contiguous(), None
         for stage in engine.VIDEO_STAGES:       # one autograd node per stage (see engine.video_stage_forward)
-            u = VideoStageFunction.apply(self, stage, u, *_stage_params(self, stage))
+            u = VideoStageFunction.apply(self, stage, u, aux, *_stage_params(self, stage))
+            # (the 16-bit stem hands over its RAW output and the scale / shift its consumers apply on load: a second,
+            #  non-differentiable output of its node, an input of layer1's)
+            u, aux = u if isinstance(u, tuple) else (u, None)
         return u
 
 
@@ -374,12 +377,14 @@ class VideoStageFunction(torch.autograd.Function):
     """One autograd node per stage of the video trunk (stem, layer1..4)."""
 
     @staticmethod
-    def forward(fctx, trunk, stage, x, *params):
+    def forward(fctx, trunk, stage, x, aux, *params):
         training = trunk.training
         need_grad = training and any(fctx.needs_input_grad)
         ectx = engine.Ctx(training, sync=_sync_of(trunk) if training else None, ops=_backend(trunk))
         ectx.wimg = _weight_images(trunk, x, training, first=(stage == "stem"))
-        out, saved = engine.video_stage_forward(ectx, trunk, stage, x)
+        out, saved = engine.video_stage_forward(ectx, trunk, stage, x, aux)
+        if isinstance(out, tuple):
+            fctx.mark_non_differentiable(out[1])
         if stage == "layer4":
             _weight_images(trunk, x, training, first=False, last_done=True)
         fctx.need = need_grad
@@ -388,7 +393,7 @@ class VideoStageFunction(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(fctx, dout):
+    def backward(fctx, dout, *_daux):
         if not fctx.need:
             raise RuntimeError("selavi_amd: backward through a trunk that ran in eval / no_grad mode")
         ectx = engine.Ctx(True, sync=fctx.sync, ops=fctx.ops)
@@ -401,9 +406,9 @@ class VideoStageFunction(torch.autograd.Function):
         din = din if fctx.needs_input_grad[2] else None
         if sink is not None:
             sink.deliver(("video", fctx.stage), params)
-            return (None, None, din) + (None,) * len(params)
+            return (None, None, din, None) + (None,) * len(params)
         grads = [ectx.grads.get(id(p)) for p in params]
-        return (None, None, din) + tuple(grads)
+        return (None, None, din, None) + tuple(grads)
 
 
 # ------------------------------------------------------------------------------------------ heads
@@ -555,7 +560,8 @@ class HeadsFunction(torch.autograd.Function):
                 sums = torch.empty(G, 2, HID, dtype=torch.float64, device=dev)
                 C.slv_heads_bn_stats(ptr(h), ptr(sums), G, B, HID, st)
                 if spec.sync is not None:
-                    ops._allreduce(sums, spec.sync[0])
+                    with ops._span("syncbn"):
+                        ops._allreduce(sums, spec.sync[0])
                     ops.EXCHANGES[0] += 1
                     count *= spec.sync[1]
                 for b in bns:
@@ -619,7 +625,8 @@ class HeadsFunction(torch.autograd.Function):
             sums = torch.empty(G, 2, HID, dtype=torch.float64, device=dev)
             C.slv_heads_bn_bwd_stats(ptr(da), ptr(h), ptr(mi), ga.p, be.p, ptr(m2), msc, ptr(sums), G, B, HID, st)
             if spec.sync is not None:
-                ops._allreduce(sums, spec.sync[0])
+                with ops._span("syncbn"):
+                    ops._allreduce(sums, spec.sync[0])
                 ops.EXCHANGES[0] += 1
             dh = f32(G, B, HID)
             C.slv_heads_bn_bwd_apply(ptr(da), ptr(h), ptr(mi), ga.p, be.p, ptr(m2), msc, ptr(sums), count, ptr(dh),

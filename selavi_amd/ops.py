@@ -71,13 +71,18 @@ class ConvPlan:
         self.wt_elems = C.slv_conv_wt_elems(self.gp)
         self.set_configs(0, 0, 0)
         if benchmark:
-            # (bare keys = the native kernels, as every cache written before the split-operand kernels existed: their
-            #  configurations -- mf = 1 tiles among them -- must never reach the x3 kernels)
-            key = ",".join(str(int(v)) for v in self.geom) + (",x3" if C.slv_conv_get_arithmetic() else "")
+            # the key names the arithmetic EXPLICITLY and carries the key-scheme version: bare keys meant "x3" in round 4 and
+            # "native" in round 5 -- entries of either scheme are simply never found (retuned), and a configuration the
+            # library rejects for this arithmetic (an mf = 1 tile on a split-operand layer) is retuned instead of raised
+            key = ",".join(str(int(v)) for v in self.geom) + ",k3," + conv_arithmetic()
             hit = _tune_cache().get(key)
             if hit is not None:
-                self.set_configs(*hit)
-            else:
+                try:
+                    self.set_configs(*hit)
+                except ValueError:
+                    hit = None
+                    self.set_configs(0, 0, 0)
+            if hit is None:
                 _autotune(self)
                 _tune_cache()[key] = [self.cfg_fwd, self.cfg_dgrad, self.cfg_wgrad]
                 _tune_cache_save()
@@ -437,6 +442,12 @@ def _native(sync):
     return sync[0] if isinstance(sync[0], NativeComm) else None
 
 
+def _span(kind):
+    """comm.span: HIP events around an exchange while a comm.diagnostics() block is open, otherwise nothing."""
+    from . import comm
+    return comm.span(kind)
+
+
 def bn_train_finalize(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps, sync=None):
     """conv-epilogue partials -> (mean_invstd [2][C], scale_shift [2][C]); updates running stats.
     ``sync`` = (group, world_count): SyncBN -- sums are all-reduced, count is the global count."""
@@ -451,15 +462,16 @@ def bn_train_finalize(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps,
     sums = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
     EXCHANGES[0] += 1
     comm = _native(sync)
-    if comm is not None:        # one library call, one stream: partials -> sums -> RCCL all-reduce -> finalize
-        C.slv_bn_sync_finalize(comm.h, ptr(ssum), ptr(ssq), ssum.shape[1], float(count), ptr(gamma), ptr(beta), ptr(rmean),
-                               ptr(rvar), float(momentum), float(eps), ptr(mi), ptr(ss), Cc, ptr(sums), stream())
-        return mi, ss
-    C.slv_bn_partials_to_sums(ptr(ssum), ptr(ssq), ssum.shape[1], Cc, ptr(sums), stream())
-    _allreduce(sums, sync[0])
-    count = count * sync[1]
-    C.slv_bn_finalize(ptr(sums), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(momentum),
-                      float(eps), ptr(mi), ptr(ss), Cc, stream())
+    with _span("syncbn"):
+        if comm is not None:        # one library call, one stream: partials -> sums -> RCCL all-reduce -> finalize
+            C.slv_bn_sync_finalize(comm.h, ptr(ssum), ptr(ssq), ssum.shape[1], float(count), ptr(gamma), ptr(beta), ptr(rmean),
+                                   ptr(rvar), float(momentum), float(eps), ptr(mi), ptr(ss), Cc, ptr(sums), stream())
+            return mi, ss
+        C.slv_bn_partials_to_sums(ptr(ssum), ptr(ssq), ssum.shape[1], Cc, ptr(sums), stream())
+        _allreduce(sums, sync[0])
+        count = count * sync[1]
+        C.slv_bn_finalize(ptr(sums), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(momentum),
+                          float(eps), ptr(mi), ptr(ss), Cc, stream())
     return mi, ss
 
 
@@ -471,6 +483,11 @@ def bn_train_finalize_many(items, sync):
     block and its downsample conv: nothing consumes either before the block tail) finalised behind ONE exchange:
     items = [(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps), ...] -> [(mean_invstd, scale_shift), ...].
     The 2C fp64 sums of all items travel in one buffer; kernels and arithmetic are those of bn_train_finalize."""
+    with _span("syncbn"):
+        return _bn_train_finalize_many(items, sync)
+
+
+def _bn_train_finalize_many(items, sync):
     dev = items[0][3].device
     tot = sum(2 * it[3].numel() for it in items)
     sums = torch.empty(tot, dtype=torch.float64, device=dev)
@@ -538,6 +555,13 @@ def bn_bwd(g, x, mi, gamma, ss_mask=None, v_mask=None, x2=None, mi2=None, gamma2
 def bn_bwd_finish(part, part2, ns, count, mi, gamma, ss_mask, mi2, gamma2, sync, dgamma, dbeta, dgamma2, dbeta2):
     """Slice partials [C][ns][2] -> folded BatchNorm-backward coefficients bwd5 [5][C] (+ dgamma, dbeta); SyncBN: the
     fp64 sums are all-reduced in between.  Shared by the fp32 (N,C,T,H,W) and the bf16 channels-last reductions."""
+    if sync is None:
+        return _bn_bwd_finish(part, part2, ns, count, mi, gamma, ss_mask, mi2, gamma2, sync, dgamma, dbeta, dgamma2, dbeta2)
+    with _span("syncbn"):
+        return _bn_bwd_finish(part, part2, ns, count, mi, gamma, ss_mask, mi2, gamma2, sync, dgamma, dbeta, dgamma2, dbeta2)
+
+
+def _bn_bwd_finish(part, part2, ns, count, mi, gamma, ss_mask, mi2, gamma2, sync, dgamma, dbeta, dgamma2, dbeta2):
     Cc = gamma.numel()
     dev = gamma.device
     comm = _native(sync) if sync is not None else None

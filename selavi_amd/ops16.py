@@ -181,6 +181,24 @@ def _pick_w(n):
     return best[0]
 
 
+_flags_reconciled = False
+
+
+def _reconcile_flags():
+    """Before the first plan is built: the opt-in SELAVI_CL16_FUSE_BNR=1 (BatchNorm-backward sums from the backward-data
+    epilogue) needs launches the 8-wave kernel's default dispatch would take away (layer-4 backward data, no fused sums
+    there: slv_cl16_conv returns an error) -- the 8-wave kernel is switched off for the process then, loudly."""
+    global _flags_reconciled
+    if _flags_reconciled:
+        return
+    _flags_reconciled = True
+    if FUSE_BNR and C.slv_cl16_g8_mode(-1) != 0:
+        import sys
+        C.slv_cl16_g8_mode(0)
+        sys.stderr.write("selavi_amd.ops16: SELAVI_CL16_FUSE_BNR=1 -> the 8-wave conv kernel (SELAVI_CL16_G8) is off for this "
+                         "process: it has no fused BatchNorm-backward sums\n")
+
+
 class Plan16:
     """Geometry of one conv layer on the bf16 path for a given input shape: forward, backward-data (one launch per
     stride-parity class) and weight-gradient launch descriptions.  ``stem``: the (1, kh, kw) conv over <= 4 input
@@ -197,6 +215,7 @@ class Plan16:
         return p
 
     def __init__(self, N, Ti, Hi, Wi, Cin, Cout, k, stride, pad, device, stem):
+        _reconcile_flags()
         self.device, self.stem = device, stem
         self.w_shape_taps = k[0] * k[1] * k[2]
         self.Cin_w, self.Cout = Cin, Cout                  # channel counts of the fp32 weight tensor
@@ -416,9 +435,43 @@ def conv_fwd(plan, x, w, in_ss=None, in_relu=False, want_stats=True, wf=None, ou
         else:
             ssum = torch.empty(plan.Cout, plan.nblk, dtype=torch.float32, device=x.device)
             ssq = torch.empty_like(ssum)
+    ev = _probe["plans"].get(id(plan)) if (_probe is not None and (in_ss is not None) == _probe["prologue"]) else None
+    if ev is not None:       # bench.py: HIP events around THIS launch, on the stream it runs on, inside the training step
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     C.slv_cl16_conv(plan.g_fwd.ctypes.data, plan.mt_f, ptr(x), ptr(wf), ptr(y), ptr(in_ss), 0, 0, 0, ptr(ssum), ptr(ssq),
                     0, 0, 0, 0, 0, 0, stream())
+    if ev is not None:
+        e1.record()
+        ev.append((e0, e1))
     return y, ssum, ssq
+
+
+_probe = None
+
+
+class probe_conv_fwd:
+    """``with ops16.probe_conv_fwd({"name": plan, ...}, prologue=True) as p: step()`` -- every training-forward launch of the
+    named plans (with / without the BatchNorm + ReLU load prologue) inside the block is bracketed by HIP events on the stream it
+    runs on; ``p.ms()`` -> {name: [durations]} after a synchronize.  Measurement only (bench.py's live in-step figures of
+    the cfg5 leg, the counterpart of ops.probe_conv_fwd): two event records per probed launch."""
+
+    def __init__(self, plans, prologue=True):
+        self.names = {id(pl): k for k, pl in plans.items()}
+        self.state = dict(plans={id(pl): [] for pl in plans.values()}, prologue=prologue)
+
+    def __enter__(self):
+        global _probe
+        _probe = self.state
+        return self
+
+    def __exit__(self, *exc):
+        global _probe
+        _probe = None
+
+    def ms(self):
+        torch.cuda.synchronize()
+        return {self.names[k]: [a.elapsed_time(b) for a, b in v] for k, v in self.state["plans"].items()}
 
 
 # the BatchNorm-backward apply in the epilogue of the backward-data conv that produces the gradient (conv_dgrad(bn_apply=...),

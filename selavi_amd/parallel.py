@@ -100,6 +100,10 @@ class GradSink:
         self.reduce([flat])
 
     def reduce(self, tensors):
+        from . import comm as _comm
+        if _comm.DIAG is not None:                # bench.py's N > 1 line: collectives / bytes per step
+            _comm.DIAG["grad_collectives"] += len(tensors)
+            _comm.DIAG["grad_bytes"] += sum(t.numel() * t.element_size() for t in tensors)
         if self.native is not None:               # RCCL behind the C ABI, on the buckets' own stream
             cur = torch.cuda.current_stream()
             if self.stream is None:
@@ -123,6 +127,18 @@ class GradSink:
 
     def finalize(self):
         pending, self.pending = self.pending, []
+        if not pending:
+            return
+        from . import comm as _comm
+        if _comm.DIAG is None:
+            return self._wait(pending)
+        import time
+        t0 = time.perf_counter()
+        with _comm.span("grad_wait"):             # (diagnostics only) how long the compute stream stands still here
+            self._wait(pending)
+        _comm.DIAG["grad_wait_host_s"] += time.perf_counter() - t0      # (host-driven transports block here instead)
+
+    def _wait(self, pending):
         for work, t in pending:
             if t is None:                         # native path: an event on the buckets' stream
                 torch.cuda.current_stream().wait_event(work)
@@ -171,8 +187,12 @@ class DataParallel(torch.nn.Module):
         drops the ragged last batch, main.py:95-103).  The check is a collective, so EVERY rank issues it on EVERY call (a
         rank-local condition would leave the one rank with the ragged batch alone in the all-reduce: a hang on the native
         communicators, a mismatched pairing on torch.distributed).  It never stalls the host in the steady state: on RCCL
-        the result lands in pinned memory behind an event and is read at a later call; only a rank whose OWN batch size
-        just changed (the first call, a ragged batch) waits for it before launching the step."""
+        the result lands in pinned memory behind an event.  The result of the PREVIOUS call is read -- blocking on its event,
+        which completed at the head of the previous step -- BEFORE this call launches anything: a ragged batch on another rank
+        raises here on every rank, one step late at most and before this step's SyncBN / bucket collectives could wait for a
+        rank that has already left; a rank whose OWN batch size just changed (the first call, its ragged batch) also waits
+        for this call's result before launching the step."""
+        self._read_batch_checks(block=True)                                # the previous call's verdict (steady state: ready)
         if dist.get_backend(self.group) == "nccl":
             t = torch.full((2,), b, dtype=torch.int64, device=device)
             t[1] = -b                                                  # (fill kernels: no host-to-device copy, no sync)
@@ -186,7 +206,8 @@ class DataParallel(torch.nn.Module):
             t = torch.tensor([b, -b], dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             self._batch_checks.append((None, t, b))
-        self._read_batch_checks(block=(b != self._last_batch))
+        if b != self._last_batch:
+            self._read_batch_checks(block=True)
         self._last_batch = b
 
     def forward(self, *args, **kwargs):

@@ -40,6 +40,8 @@ def install_torchvision_standin():
     resnet.BasicBlock = model_ref.BasicBlock
     resnet.resnet18 = model_ref.resnet18
     models.video, models.resnet, models.resnet18 = video, resnet, model_ref.resnet18
+    models.resnet34, models.resnet50 = model_ref.resnet34, model_ref.resnet50      # model.py:106 torchvision.models.__dict__[arch]
+    resnet.resnet34, resnet.resnet50, resnet.Bottleneck = model_ref.resnet34, model_ref.resnet50, model_ref.Bottleneck
     tv.models = models
     for name, m in [("torchvision", tv), ("torchvision.models", models),
                     ("torchvision.models.video", video), ("torchvision.models.resnet", resnet)]:
@@ -202,6 +204,49 @@ def cfg2_fixture(ref_model, ref_utils, hc=10, K=309, B=16, T=16, fname="cfg2_ful
     print(fname, "full-size fixture: loss", loss.item())
 
 
+def audio_archs_fixture(ref_model, fname="audio_archs.npz"):
+    """The audio trunks model.py:103-110 accepts beside resnet9 -- resnet18 / resnet34 / resnet50 -- through the EXECUTED
+    reference's own load_model (get_audio_feature_extractor: torchvision.models.__dict__[arch], conv1 replaced by a
+    1-channel 7x7 conv AFTER the init, fc -> Identity), tiny shapes: eval- and train-mode logits of a 2-head model for the
+    512-d trunks, eval- and train-mode trunk features for all three (resnet50's 2048 features do not fit the 512-d heads the
+    reference builds: return_features only), and the running statistics one train-mode forward leaves behind."""
+    hc, K, B = 2, 12, 4
+    video = portable_fill_(torch.empty(B, 3, 4, 32, 32), 5, kind="normal")
+    audio = portable_fill_(torch.empty(B, 1, 80, 64), 6, kind="normal")
+    out = {}
+    for arch in ("resnet18", "resnet34", "resnet50"):
+        m = ref_model.load_model(vid_base_arch='r2plus1d_18', aud_base_arch=arch, use_mlp=True, num_classes=K,
+                                 pretrained=False, norm_feat=False, use_max_pool=False, headcount=hc)
+        portable_init_(m, seed=31)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        heads = arch != "resnet50"
+        m.eval()
+        with torch.no_grad():
+            m.return_features = True
+            _, ga = m(video, audio)
+            m.return_features = False
+            out[arch + "/eval_feat_a"] = ga.numpy()
+            if heads:
+                _, fa = m(video, audio)
+                out[arch + "/eval_a"] = np.stack([t.numpy() for t in fa])
+        m.train()
+        with torch.no_grad():
+            m.return_features = True
+            _, ga = m(video, audio)
+            m.return_features = False
+            out[arch + "/train_feat_a"] = ga.numpy()
+        sd = m.state_dict()
+        last = "audio_network.base.layer4.%d." % (len(m.audio_network.base.layer4) - 1)
+        key = last + ("bn3" if arch == "resnet50" else "bn2") + ".running_var"
+        out[arch + "/post_running_var"] = sd[key].numpy().copy()
+        out[arch + "/n_keys_audio"] = len([k for k in sd if k.startswith("audio_network.")])
+        out[arch + "/n_params_audio"] = sum(p.numel() for p in m.audio_network.parameters())
+        print("audio arch fixture", arch, "features", ga.shape, "params", out[arch + "/n_params_audio"])
+    np.savez_compressed(os.path.join(OUT, fname), hc=hc, K=K, B=B, **out)
+
+
 def sk_kinetics_fixture(ref_sk, name="sk_kinetics_full", N=230976, K=400, scale=1.0, seed=41, hc=2, head=1):
     """BASELINE configs[3]'s Sinkhorn-Knopp problem solved by the reference itself (sk_utils.py:359-422 with the gauss
     branch :368-388, cluster sizes per head GIVEN -- torch's randn stream does not travel): digest / histogram / head and
@@ -232,6 +277,11 @@ def main():
         ref_model, ref_utils, ref_sk = import_reference()
         torch.set_num_threads(os.cpu_count())
         (cfg1_fixture if "--only-cfg1" in sys.argv else cfg2_fixture)(ref_model, ref_utils)
+        return
+    if "--only-audio-archs" in sys.argv:      # model.py:103-110: resnet18 / resnet34 / resnet50 audio trunks (seconds of CPU)
+        ref_model, ref_utils, ref_sk = import_reference()
+        torch.set_num_threads(os.cpu_count())
+        audio_archs_fixture(ref_model)
         return
     if "--only-sk-kinetics" in sys.argv:      # configs[3]: N = 230 976, K = 400, gauss marginals per head, the reference on CPU (~minutes)
         ref_model, ref_utils, ref_sk = import_reference()
@@ -374,6 +424,7 @@ def main():
 
     cfg1_fixture(ref_model_mod, ref_utils)
     cfg2_fixture(ref_model_mod, ref_utils)
+    audio_archs_fixture(ref_model_mod)
 
     # state-dict key lists of the full-size configs (cfg1 hc=1, cfg2 hc=10): names only
     for hc, K in [(1, 28), (10, 309)]:

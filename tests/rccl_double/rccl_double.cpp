@@ -165,6 +165,12 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {                    // (optional symbol: slv_comm_count's diagnostics)
+  if (!comm || !count) return ncclInvalidArgument;
+  *count = ((const Comm*)comm)->world;
+  return ncclSuccess;
+}
+
 ncclResult_t ncclCommAbort(ncclComm_t comm) { return ncclCommDestroy(comm); }     // (optional symbol of the product's watchdog path)
 
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm,

@@ -118,3 +118,73 @@ def test_resnet34_model_steps_and_resnet50_meets_the_reference_heads():
         m.return_features = True
         fv, fa = m(video.cuda(), audio.cuda())
     assert tuple(fv.shape) == (4, 512) and tuple(fa.shape) == (4, 2048)
+
+
+# ---- pinned to the EXECUTED reference (tests/golden/audio_archs.npz <- tests/golden/make_golden.py --only-audio-archs: the
+# reference's own load_model / get_audio_feature_extractor, model.py:103-110,255-275, run on CPU in the build container)
+def _golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "audio_archs.npz"))
+
+
+def _run_fixture_case(mod, arch, dev):
+    """What make_golden.audio_archs_fixture ran, on ``mod`` (the HIP package or the oracle)."""
+    g = _golden()
+    hc, K, B = int(g["hc"]), int(g["K"]), int(g["B"])
+    video = portable_fill_(torch.empty(B, 3, 4, 32, 32), 5).to(dev)
+    audio = portable_fill_(torch.empty(B, 1, 80, 64), 6).to(dev)
+    m = mod.load_model(vid_base_arch='r2plus1d_18', aud_base_arch=arch, use_mlp=True, num_classes=K, pretrained=False,
+                       norm_feat=False, use_max_pool=False, headcount=hc)
+    portable_init_(m, seed=31)
+    for sub in m.modules():
+        if isinstance(sub, torch.nn.Dropout):
+            sub.p = 0.0
+    m = m.to(dev)
+    out = {}
+    m.eval()
+    with torch.no_grad():
+        m.return_features = True
+        out["eval_feat_a"] = m(video, audio)[1].float().cpu().numpy()
+        m.return_features = False
+        if arch != "resnet50":
+            out["eval_a"] = np.stack([t.float().cpu().numpy() for t in m(video, audio)[1]])
+        m.train()
+        m.return_features = True
+        out["train_feat_a"] = m(video, audio)[1].float().cpu().numpy()
+        m.return_features = False
+    sd = m.state_dict()
+    key = "audio_network.base.layer4.%d.%s.running_var" % (len(m.audio_network.base.layer4) - 1, "bn3" if arch == "resnet50" else "bn2")
+    out["post_running_var"] = sd[key].float().cpu().numpy()
+    out["n_keys_audio"] = len([k for k in sd if k.startswith("audio_network.")])
+    out["n_params_audio"] = sum(p.numel() for p in m.audio_network.parameters())
+    return out
+
+
+@pytest.mark.parametrize("arch", ARCHS)
+def test_oracle_reproduces_the_executed_reference_on_the_audio_trunks(arch):
+    """CPU: oracle/model_ref.load_model(aud_base_arch=...) against the fixture the reference's own model.py produced -- the
+    restated get_audio_feature_extractor (conv1 swapped after the init, fc -> Identity, Bottleneck for resnet50) is pinned."""
+    g, out = _golden(), _run_fixture_case(model_ref, arch, "cpu")
+    for k, v in out.items():
+        ref = g[arch + "/" + k]
+        if np.ndim(v) == 0:
+            assert int(v) == int(ref), k
+        else:
+            assert v.shape == ref.shape and np.abs(v - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (k, np.abs(v - ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ARCHS)
+def test_audio_trunks_match_the_executed_reference(arch):
+    """GPU: the HIP model with aud_base_arch = resnet18 / 34 / 50 against the executed reference's fixture: eval-mode features
+    and logits, train-mode (batch statistics) features, the running variance one train-mode forward leaves -- 1e-3
+    (BASELINE's tolerance), state-dict size and parameter count exact."""
+    from selavi_amd import model as smodel
+    g, out = _golden(), _run_fixture_case(smodel, arch, "cuda")
+    for k, v in out.items():
+        ref = g[arch + "/" + k]
+        if np.ndim(v) == 0:
+            assert int(v) == int(ref), k
+        else:
+            err = np.abs(v - ref).max()
+            assert v.shape == ref.shape and err <= 1e-3 * max(1.0, np.abs(ref).max()), (arch, k, err)

@@ -17,6 +17,27 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+def _check_comm(out, world, native):
+    """The N > 1 line explains its exchanges: transport, ranks per communicator as RCCL counts them,
+    SyncBN exchanges and their duration, bucket bytes and the exposed wait, the SK iteration split into pass and all-reduce."""
+    c = out["comm"]
+    assert c["world"] == world and c["preflight"] == "ok" and c["wrapper"] == "DataParallel"
+    if native:
+        assert c["transport"].startswith("native") and c["library"]
+        tags = set(c["communicators"])
+        assert {"bn", "bn_audio", "grad"} <= tags, tags
+        for tag, d in c["communicators"].items():
+            assert d["ranks_rccl_reports"] == world and d["world"] == world, (tag, d)
+    else:
+        assert c["transport"].startswith("torch.distributed") and c["communicators"] == {}
+    sb, gr = c["syncbn"], c["grad_allreduce"]
+    assert sb["exchanges_per_step"] >= 40 and sb["mean_ms"] > 0 and sb["total_ms_per_step"] > 0
+    assert gr["collectives_per_step"] == 7 and gr["bytes_per_step"] > 170e6 and gr["exposed_wait_ms_per_step"] >= 0
+    sk = c["sk"]
+    assert sk["us_per_iter"] > 0 and sk["us_pass_reduce_update"] > 0 and sk["us_allreduce"] >= 0
+    assert abs(sk["us_pass_reduce_update"] + sk["us_allreduce"] - sk["us_per_iter"]) <= 1e-6 * sk["us_per_iter"] or sk["us_allreduce"] == 0
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -47,6 +68,7 @@ def test_driver_scale_command_two_ranks_on_one_gpu(transport):
     assert "error" not in c5 and c5["n_gpus"] == 2 and c5["config"]["parallelism"] == "dp2" and c5["value"] > 0
     assert out["cpu_baseline"] is None                                                         # rank 0 at N = 1 only
     assert "FAILED their preflight" not in p.stderr
+    _check_comm(out, 2, native=(transport == "native_double"))
 
 
 def test_driver_scale_command_eight_ranks_on_one_gpu():
@@ -73,3 +95,4 @@ def test_driver_scale_command_eight_ranks_on_one_gpu():
     assert "error" not in c5 and c5["n_gpus"] == 8 and c5["config"]["parallelism"] == "dp8" and c5["value"] > 0
     assert out["cpu_baseline"] is None
     assert "FAILED their preflight" not in p.stderr
+    _check_comm(out, 8, native=True)
