@@ -217,60 +217,78 @@ def sk_bench(rank, world, dev, iters=50):
 def sk_round_estimate(m, dev, world, step_clips_per_s, sk):
     """What one Sinkhorn-Knopp round costs next to the training it interleaves with (BASELINE metric: "clips/sec
     (video+audio fwd/bwd+SK)").  Measured here: the eval-mode feature pass of sk_utils.py:137-233 at its batch size
-    (64, :168) on this GPU.  Derived with the reference's defaults (opt.py:71,88,102: 100 epochs, nopts=100 rounds,
+    (64, :168) on this GPU, as selavi_amd.sk_utils runs it by default: the fp32 trunks with BatchNorm folded into the weights
+    for the length of the pass (selavi_amd/infer32.py; the exact three-piece operand split of the training path).  Beside it:
+    the plain eval forward of rounds 1-5 ("fp32_unfolded"), the two-piece opt-in ("fp32x2") and the bf16 opt-in.
+    Derived with the reference's defaults (opt.py:71,88,102: 100 epochs, nopts=100 rounds,
     ind_groups=1) at the VGG-Sound size: round = N / (W x feature-pass rate) + hc heads x 200 SK iterations at the
     measured it/s (71-271 iterations to converge), against the epochs x N / nopts clips trained between
     two rounds."""
+    from selavi_amd import infer32
     B = 64
     g = torch.Generator(device=dev).manual_seed(77)
     video = torch.randn(B, 3, CFG2["T"], CFG2["S"], CFG2["S"], device=dev, generator=g)
     audio = torch.randn(B, 1, CFG2["F"], CFG2["Tp"], device=dev, generator=g)
     m.eval()
     m.return_features = True
+
+    def rate_of(fn, reps=4):
+        fn()
+        fn()                                   # (plans, launch configurations, the folded weight images)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return B / ((time.perf_counter() - t0) / reps)
+    rates = {}
     try:
         with torch.no_grad():
-            m(video, audio)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                m(video, audio)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / 3 * 1e3
+            rates["fp32_unfolded"] = rate_of(lambda: m(video, audio))
+            for name, pieces in (("fp32", 3), ("fp32x2", 2)):
+                try:
+                    with infer32.folded_eval(m, pieces=pieces):
+                        rates[name] = rate_of(lambda: m(video, audio))
+                except Exception as e:             # never take the bench line down with a side measurement
+                    print(f"feature pass {name} not measured: {e!r}", file=sys.stderr)
         # opt-in alternative (NOT the bit-exact path): the same pass in bf16 on the channels-last MFMA kernels
-        rate16 = None
         try:
             from selavi_amd import infer16
             eng = infer16.Engine(m)
-            eng.features(video, audio)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                eng.features(video, audio)
-            torch.cuda.synchronize()
-            rate16 = B / ((time.perf_counter() - t0) / 3)
+            rates["bf16"] = rate_of(lambda: eng.features(video, audio))
             del eng
         except Exception as e:                     # experimental path: never take the bench line down with it
-            rate16 = None
             print(f"bf16 feature pass not measured: {e!r}", file=sys.stderr)
     finally:
         m.return_features = False
         m.train()
-    rate = B / ms * 1e3
     N, hc, epochs, rounds, its = CFG2["N"], CFG2["hc"], 100, 100, 200
-    t_feat = N / (rate * world)
     t_sk = hc * its / sk["iters_per_s"] if sk else float("nan")
     t_train = epochs * N / rounds / step_clips_per_s
-    return {"feature_pass_clips_per_s_per_gpu": rate, "feature_pass_batch": B, "feature_pass_s": t_feat,
+
+    def incl(rate):
+        return step_clips_per_s * t_train / (N / (rate * world) + t_sk + t_train)
+    default = "fp32" if "fp32" in rates else "fp32_unfolded"
+    rate = rates[default]
+    t_feat = N / (rate * world)
+    notes = {"fp32": "default: BatchNorm folded into the weights, conv + BN (+ shortcut) + ReLU in one launch, exact three-piece operand split",
+             "fp32_unfolded": "SELAVI_FEATURE_PASS=fp32_unfolded: the model's plain eval forward (rounds 1-5)",
+             "fp32x2": "SELAVI_FEATURE_PASS=fp32x2 (opt-in): folded, two bf16 pieces per operand / three partial products: features ~1e-5 "
+                       "relative off the exact split, labels not guaranteed identical",
+             "bf16": "SELAVI_FEATURE_PASS=bf16 (opt-in): eval forward on bf16 channels-last activations (selavi_amd/infer16.py); features "
+                     "within ~5e-3 of fp32, labels not bit-exact"}
+    return {"feature_pass": default, "feature_pass_clips_per_s_per_gpu": rate, "feature_pass_batch": B, "feature_pass_s": t_feat,
+            "feature_pass_mfma_frac": rate * FWD_GFLOP_PER_CLIP / 1e3 / PEAK_X3_TF,
             "sk_solve_s": t_sk, "round_s": t_feat + t_sk, "training_between_rounds_s": t_train,
             "fraction_of_wall_clock": (t_feat + t_sk) / (t_feat + t_sk + t_train),
-            "clips_per_s_including_sk": step_clips_per_s * t_train / (t_feat + t_sk + t_train),
+            "clips_per_s_including_sk": incl(rate),
             "assumes": f"N={N}, hc={hc}, {rounds} rounds over {epochs} epochs, ind_groups=1, {its} SK iterations per head",
-            "bf16_feature_pass_opt_in": None if rate16 is None else {
-                "feature_pass_clips_per_s_per_gpu": rate16,
-                "hbm_roofline_frac": rate16 * FWD_MB_PER_CLIP / 2 / 1e3 / PEAK_HBM_GBS,
-                "clips_per_s_including_sk": step_clips_per_s * t_train / (N / (rate16 * world) + t_sk + t_train),
-                "note": "SELAVI_FEATURE_PASS=bf16 / args.feature_pass: eval forward on bf16 channels-last activations "
-                        "(selavi_amd/infer16.py); features within ~5e-3 of fp32, labels not bit-exact; off by default"}}
+            "by_feature_pass": {k: {"feature_pass_clips_per_s_per_gpu": v, "clips_per_s_including_sk": incl(v), "note": notes[k]}
+                                for k, v in rates.items()},
+            "bf16_feature_pass_opt_in": None if "bf16" not in rates else {
+                "feature_pass_clips_per_s_per_gpu": rates["bf16"],
+                "hbm_roofline_frac": rates["bf16"] * FWD_MB_PER_CLIP / 2 / 1e3 / PEAK_HBM_GBS,
+                "clips_per_s_including_sk": incl(rates["bf16"]), "note": notes["bf16"]}}
 
 
 CFG5 = dict(batch=128, T=32, S=112, F=129, Tp=100, K=309, hc=10)
@@ -762,6 +780,8 @@ def main():
             "clips_per_s_including_sk": None if not sk_round else sk_round["clips_per_s_including_sk"],
             "clips_per_s_including_sk_bf16_feature_pass": None if not (sk_round and sk_round.get("bf16_feature_pass_opt_in"))
             else sk_round["bf16_feature_pass_opt_in"]["clips_per_s_including_sk"],
+            "clips_per_s_including_sk_fp32x2_feature_pass": None if not (sk_round and "fp32x2" in sk_round.get("by_feature_pass", {}))
+            else sk_round["by_feature_pass"]["fp32x2"]["clips_per_s_including_sk"],
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg2: R(2+1)D-18 + ResNet-9, per-GPU bs=%d, 16x112x112 video, 1x129x100 "
                                    "log-mel, K=309, headcount=10, SGD(m=0.9, wd=1e-5), fp32" % B,

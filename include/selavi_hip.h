@@ -174,6 +174,16 @@ int slv_conv_w_transform(const int32_t* geom, const float* w, float* wf /* nulla
 int32_t slv_conv_w_job_words(void);
 int32_t slv_conv_w_jobs(const int32_t* geom, const float* w, float* wf, float* wt, int32_t* out_jobs, int32_t max_jobs);
 int slv_conv_w_transform_jobs(const int32_t* jobs_dev, int32_t njobs, int32_t blocks_per_job, slv_stream_t stream);
+/* Eval-mode forward with BatchNorm FOLDED into the weights (the SK feature pass, sk_utils.py:137-254; selavi_amd/infer32.py):
+ * y = relu?(conv(x, w') + bias[co] (+ res)) in one launch of the split-operand kernel -- wf = slv_conv_w_transform's image of
+ * w' = w * scale[co] (made once per pass, the weights do not change during it), bias = the BatchNorm shift, res = the block's
+ * shortcut (y's shape) or NULL.  pieces = 3: the exact three-piece split of the training path (6 partial products); 2 (opt-in):
+ * two pieces, 3 partial products -- 16-17 significand bits per product at half the matrix-core work.  Unsplit K (cfg's slice
+ * count is ignored), no statistics, x read as stored.  Layers without a split-operand image (slv_conv_fwd_eval_ok == 0: the
+ * 3 / 1-channel stems, the native arithmetic) keep slv_conv_fwd + slv_bn_act. */
+int32_t slv_conv_fwd_eval_ok(const int32_t* geom);
+int slv_conv_fwd_eval(const int32_t* geom, const float* x, const float* wf, const int32_t* tab, const float* bias /* [Cout], nullable */,
+                      const float* res /* nullable */, int relu, int pieces, float* y, int32_t cfg, slv_stream_t stream);
 int slv_conv_fwd(const int32_t* geom, const float* x, const float* w /* nullable if wf is used */,
                  const float* wf /* nullable if slv_conv_wf_elems() == 0 */, const int32_t* tab,
                  const float* in_scale_shift /* nullable */, int in_relu, float* y,

@@ -52,7 +52,7 @@ enum { PRO_NONE = 0, PRO_ACT = 1 };
 enum { KORD_CHAN = 0, KORD_TAP = 1 };
 // CONV epilogue: plain store (+ addend, + forward BN statistics) or store + BatchNorm-backward partial sums
 // (IgemmArgs::R).  A template parameter: the plain kernels keep their register budget.
-enum { EPI_PLAIN = 0, EPI_BNR = 1 };
+enum { EPI_PLAIN = 0, EPI_BNR = 1, EPI_EVAL = 2 };     // EPI_EVAL: igemm3.hpp only (bias + addend + ReLU, eval-mode forward)
 
 constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond any buffer -> load returns 0
 
@@ -71,7 +71,8 @@ struct IgemmArgs {
   const int* tapd;   // per-tap packed deltas: (d0+64) | (d1+64)<<8 | (d2+64)<<16, 64 entries
   float* C;          // output
   const float* E;    // optional epilogue addend, same indexing as C
-  const float* bias; // GEMM: optional per-column bias
+  const float* bias; // GEMM: optional per-column bias; CONV with EPI_EVAL: per-ROW (output channel) bias [M]
+  int epi_relu;      // EPI_EVAL: ReLU behind bias + addend
   float* stat_sum;   // CONV: [M][nblkN] per-channel partial sums of the output (or null)
   float* stat_sq;
   // CONV (backward-data) epilogue: BatchNorm-backward reductions of the layer that PRODUCED this launch's

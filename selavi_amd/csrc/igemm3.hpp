@@ -34,6 +34,16 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
   const float r2 = r1 - __uint_as_float(m);           // exact, <= 8 significant bits: a bf16
   l = __float_as_uint(r2);
 }
+// "x2" (the eval-mode feature pass, opt-in; NP = 2 below): two pieces instead of three.  h = the upper 8 significand bits by
+// truncation, m = the remainder ROUNDED to bf16: x = h + m (1 + e), |e| <= 2^-9 on a term <= 2^-8 |x| -> |x - h - m| <= 2^-17 |x|;
+// a product then takes the three partial products a1 b1 + a1 b2 + a2 b1 (dropped: a2 b2 <= 2^-16 |a b| and the weights' third
+// piece, <= 2^-16): 16-17 significand bits -- 30 x finer than TF32 -- at HALF the matrix-core work of the exact split.  Never
+// used by the training step.  Two elements at a time: the packed dwords of the h and m planes.
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& hpk, unsigned& mpk) {
+  const unsigned u0 = __float_as_uint(x0) & 0xffff0000u, u1 = __float_as_uint(x1) & 0xffff0000u;
+  hpk = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  mpk = pack_bf2(x0 - __uint_as_float(u0), x1 - __uint_as_float(u1));       // exact differences, one RN each
+}
 // One LDS-DMA piece: 64 lanes x 16 bytes, memory (buffer offset voff + soff) -> LDS at lds_addr + 16 * lane.  Inline asm: through
 // the builtin, hipcc orders every LDS read it can see behind a DMA "that may alias" with s_waitcnt vmcnt(0) -- the whole
 // round trip in front of the chunk's MFMAs.  The compiler does not count these requests: the consumer waits explicitly.
@@ -92,17 +102,23 @@ constexpr int X3_MAXC = 1152;     // widest gathered tensor of the two trunks (p
 // waves 4-7 one later): stage c & 1 is read in slots 2c and 2c + 1; the DMA pieces of chunk c + 1 go into the other stage
 // from slot 2c on (its tenant, chunk c - 1, was last read in slot 2c - 1) and are waited for by their issuing wave at the end
 // of its M(c) (slots 2c / 2c + 1): landed before slot 2c + 2.
-template <int MT, int NT, int PRO, int EPI, int WAVES, int OCC, bool FUSE>
+// NP: bf16 pieces per operand -- 3 (exact split, 6 partial products: every training launch) or 2 (3 partial products: the
+// opt-in eval-mode feature pass, see split2_pair).  EPI_EVAL (eval-mode forward with BatchNorm folded into the weights, selavi_amd/
+// infer32.py): y = acc + bias[row] (+ E) and ReLU if g.epi_relu -- conv + BN (+ residual) + ReLU of a torchvision block in
+// one launch, no statistics, no prologue on the consumer's side.
+template <int MT, int NT, int PRO, int EPI, int WAVES, int OCC, bool FUSE, int NP = 3>
 __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs g) {
+  static_assert(NP == 2 || NP == 3, "two or three bf16 pieces per operand");
   constexpr int BM = MT * 16, BN = NT * 16 * WAVES, NTHR = 64 * WAVES;
   constexpr bool PP = WAVES == 8 && !FUSE;
-  constexpr int A_BYTES = 3 * BM * 64;
+  constexpr int NPROD = NP == 3 ? 6 : 3;
+  constexpr int A_BYTES = NP * BM * 64;
   constexpr int EPI_BYTES = (2 * WAVES + 4) * BM * 4;
 #ifndef SLV_X3_LDS_PAD
 #define SLV_X3_LDS_PAD 0          // experiment: extra LDS bytes per workgroup (forces fewer workgroups per CU)
 #endif
   constexpr int SMEM = (2 * A_BYTES > EPI_BYTES ? 2 * A_BYTES : EPI_BYTES) + SLV_X3_LDS_PAD;
-  constexpr int NDMA = 3 * MT;          // 1 KiB pieces of an A stage (16 rows of one plane each)
+  constexpr int NDMA = NP * MT;         // 1 KiB pieces of an A stage (16 rows of one plane each; NP = 2: the image's first two planes)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
   // dynamic LDS: the tap table of this launch ([Kd / 16 + 4] entries {offset, tap | first channel << 8}: read per chunk
   // without a vector-memory round trip) and, PRO_ACT, [2][CbP] scale, shift (padding channels 0)
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
   int ptoff[2] = {0, 0};                 // PRO_ACT: this lane's 8 channels in the table
   float lim_lo[2][NT], lim_hi[2][NT];    // PRO_ACT: the activation is clamp(x*s + h, lo, hi): (0, inf) with ReLU,
                                          // (-inf, inf) without, (0, 0) where the tap leaves the tensor (zero padding)
-  bf16x8 bfr[2][NT][3];                  // B fragments (three planes)
+  bf16x8 bfr[2][NT][NP];                 // B fragments (NP planes)
   (void)ptoff; (void)lim_lo; (void)lim_hi;
 
   auto load_chunk = [&](int c, auto par) __attribute__((always_inline)) {
@@ -284,6 +300,19 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+      if constexpr (NP == 2) {
+        float v8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          v8[q] = rb[P][j][q];
+          if constexpr (PRO == PRO_ACT) v8[q] = __builtin_amdgcn_fmed3f(v8[q] * s8[q] + h8[q], lim_lo[P][j], lim_hi[P][j]);
+        }
+        unsigned hp[4], mp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split2_pair(v8[2 * q], v8[2 * q + 1], hp[q], mp[q]);
+        bfr[P][j][0] = __builtin_bit_cast(bf16x8, (u32x4){hp[0], hp[1], hp[2], hp[3]});
+        bfr[P][j][1] = __builtin_bit_cast(bf16x8, (u32x4){mp[0], mp[1], mp[2], mp[3]});
+      } else {
       unsigned h[8], m[8], l[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -294,7 +323,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
       }
       bfr[P][j][0] = __builtin_bit_cast(bf16x8, (u32x4){pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])});
       bfr[P][j][1] = __builtin_bit_cast(bf16x8, (u32x4){pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])});
-      bfr[P][j][2] = __builtin_bit_cast(bf16x8, (u32x4){pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])});
+      bfr[P][j][NP - 1] = __builtin_bit_cast(bf16x8, (u32x4){pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])});
+      }
     }
   };
 
@@ -319,7 +349,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
     constexpr int G = NT == 1 ? 2 : 1;
     constexpr int NS = (MT + G - 1) / G;
     const unsigned char* As = smem + buf * A_BYTES + foff;
-    bf16x8 a[2][G][3];
+    bf16x8 a[2][G][NP];
     __builtin_amdgcn_sched_barrier(0);
 #ifdef SLV_X3_PRIO
     __builtin_amdgcn_s_setprio(SLV_X3_PRIO);      // the wave in its MFMA stream wins the SIMD's arbitration: the co-resident wave
@@ -327,7 +357,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) a[0][gi][p] = *(const bf16x8*)(As + (gi < MT ? gi : 0) * 1024 + p * BM * 64);
+      for (int p = 0; p < NP; ++p) a[0][gi][p] = *(const bf16x8*)(As + (gi < MT ? gi : 0) * 1024 + p * BM * 64);
     if constexpr (SPLIT && FULL && FUSE) split_chunk(std::integral_constant<int, P ^ 1>{});
     (void)cnext;
 #pragma unroll
@@ -337,21 +367,21 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
         for (int gi = 0; gi < G; ++gi) {
           const int i = (s + 1) * G + gi < MT ? (s + 1) * G + gi : MT - 1;
 #pragma unroll
-          for (int p = 0; p < 3; ++p) a[(s + 1) & 1][gi][p] = *(const bf16x8*)(As + i * 1024 + p * BM * 64);
+          for (int p = 0; p < NP; ++p) a[(s + 1) & 1][gi][p] = *(const bf16x8*)(As + i * 1024 + p * BM * 64);
         }
       }
       if constexpr (!FULL || !FUSE) __builtin_amdgcn_sched_barrier(0);
       // products (plane of A, plane of B), small terms first; the G x NT accumulators of the step alternate
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0}, PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
           const int i = s * G + gi;
           if (i < MT && (FULL || i < mtv)) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-              if (SLV_X3_ABL == 4) { if (t == 0) acc[i][j][0] += (float)a[s & 1][gi][0][0] + (float)a[s & 1][gi][1][0] + (float)a[s & 1][gi][2][0] + (float)bfr[P][j][0][0] + (float)bfr[P][j][1][0] + (float)bfr[P][j][2][0]; }
+              if (SLV_X3_ABL == 4) { if (t == 0) acc[i][j][0] += (float)a[s & 1][gi][0][0] + (float)a[s & 1][gi][1][0] + (float)a[s & 1][gi][NP - 1][0] + (float)bfr[P][j][0][0] + (float)bfr[P][j][1][0] + (float)bfr[P][j][NP - 1][0]; }
               else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][gi][PA[t]], bfr[P][j][PB[t]], acc[i][j], 0, 0, 0);
             }
           }
@@ -361,12 +391,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
     if constexpr (FULL && FUSE) {
       // the order of the region: [reads of step 0 (+ the table reads of the split)] then per step [reads of step s + 1]
       // [its MFMAs, two VALU behind each]
-      __builtin_amdgcn_sched_group_barrier(0x100, 3 * G + (SPLIT && PRO == PRO_ACT ? 4 : 0), 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NP * G + (SPLIT && PRO == PRO_ACT ? 4 : 0), 0);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        if (s + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 3 * G, 0);
+        if (s + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, NP * G, 0);
 #pragma unroll
-        for (int t = 0; t < 6 * G * NT; ++t) {
+        for (int t = 0; t < NPROD * G * NT; ++t) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           if (SPLIT) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
@@ -477,6 +507,35 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void igemm3_kernel(const IgemmArgs
       }
     };
     if (g.E) store_all(std::true_type{});      // (one wave-uniform branch, not one per element)
+    else store_all(std::false_type{});
+  } else if constexpr (EPI == EPI_EVAL) {
+    // y = relu?(acc + bias[row] (+ E)): conv + folded BatchNorm (+ residual) + ReLU of a torchvision block (model.py:95,114)
+    auto store_all = [&](auto has_e) __attribute__((always_inline)) {
+      constexpr bool HAS_E = decltype(has_e)::value;
+      const float lo = g.epi_relu ? 0.f : -__builtin_inff();
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (i < mtv) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = i * 16 + fk * 4 + r;
+            if (m < mrem) {
+              const float bv = g.bias ? g.bias[m0 + m] : 0.f;
+#pragma unroll
+              for (int j = 0; j < NT; ++j) {
+                if (cok[j]) {
+                  const size_t ad = obase[j] + (size_t)(m0 + m) * dP;
+                  float v = acc[i][j][r] + bv;
+                  if constexpr (HAS_E) v += g.E[ad];
+                  Cp[ad] = fmaxf(v, lo);
+                }
+              }
+            }
+          }
+        }
+      }
+    };
+    if (g.E) store_all(std::true_type{});
     else store_all(std::false_type{});
   } else {
     float* rpar = red + 2 * WAVES * BM;  // [4][BM] s, h, mean, invstd of this block's rows
@@ -610,6 +669,18 @@ inline void launch_igemm3(IgemmArgs a, int splits, hipStream_t st) {
   }
   SLV_K3(PRO_NONE, EPI_PLAIN);
 #undef SLV_K3
+}
+
+// eval-mode forward (EPI_EVAL, no prologue, unsplit K), NP pieces per operand
+template <int MT, int NT_BLK, int NP>
+inline void launch_igemm3_eval(IgemmArgs a, hipStream_t st) {
+  constexpr int WAVES = NT_BLK >= 4 ? 8 : 4, NT = NT_BLK >= 4 ? NT_BLK / 2 : NT_BLK;
+  dim3 grid(a.nblkM * a.nblkN, 1, 1);
+  a.chunks_per_split = 0;
+  constexpr bool FUSE_ = WAVES == 8 || MT >= 9;
+  constexpr int OCC_ = WAVES == 8 ? 1 : ((FUSE_ || MT * NT >= 16) ? 2 : 3);      // (the 128 x 128 lean tile spills under the 3-per-CU cap)
+  const size_t dyn = (size_t)((((a.Kd >> 4) + 4) & ~1) * 8);
+  hipLaunchKernelGGL((igemm3_kernel<MT, NT, PRO_NONE, EPI_EVAL, WAVES, OCC_, FUSE_, NP>), grid, dim3(64 * WAVES), dyn, st, a);
 }
 
 }  // namespace slv

@@ -62,6 +62,7 @@ class Ctx:
         self.wimg = None            # ops.WeightImages of this trunk pass (all weight re-layouts in one launch), if any
         self.side = None            # HIP stream carrying this pass' weight-gradient launches, if any
         self.wgrad_side = WGRAD_SIDE_STREAM      # (off for a trunk that itself runs on a side stream: nn.TrunkFunction)
+        self.folded = None          # infer32.FoldedEval: eval-mode forward with BatchNorm folded into the weights, if any
 
     def grad_like(self, p):
         """Where the gradient of parameter p is written: the data-parallel bucket view if there is one."""
@@ -252,6 +253,17 @@ def block_fwd(ctx, u, chain_mods, ds_mods):
     return rec
 
 
+def block_fwd_folded(ctx, u, chain_mods, ds_mods):
+    """Eval mode, BatchNorm folded into the weights (infer32.FoldedEval): every conv + BN (+ shortcut) + ReLU of the block is
+    one launch on materialised tensors -- relu(bn(last) + shortcut) comes out of the last conv's epilogue."""
+    f = ctx.folded
+    x = u
+    for conv, bn in chain_mods[:-1]:
+        x = f.conv_bn(x, conv, bn, relu=True)
+    shortcut = u if ds_mods is None else f.conv_bn(u, ds_mods[0], ds_mods[1], relu=False)
+    return f.conv_bn(x, chain_mods[-1][0], chain_mods[-1][1], res=shortcut, relu=True)
+
+
 def block_bwd(ctx, rec, dv, need_du=True):
     """dv: gradient w.r.t. the block output.  Returns gradient w.r.t. the block input."""
     last = rec.chain[-1]
@@ -309,6 +321,14 @@ def video_stage_forward(ctx, base, stage, x, aux=None):
     gradients of layer4 (75 % of the parameters) are all-reduced while layers 3..1 still run backward.
     ``aux``: what the previous stage returned beside its output -- the stem's scale / shift when its output is handed over
     un-materialised (LAZY_STEM_TAIL: the stem then returns (raw tensor, scale_shift) and layer1 takes that pair)."""
+    if ctx.folded is not None and not ctx.training:
+        if stage == "stem":
+            st = base.stem
+            return ctx.folded.conv_bn(ctx.folded.conv_bn(x, st[0], st[1]), st[3], st[4]), None
+        u = x
+        for chain, ds in _video_blocks(getattr(base, stage)):
+            u = block_fwd_folded(ctx, u, chain, ds)
+        return (ctx.ops.avgpool_fwd(u) if stage == "layer4" else u), None
     if stage == "stem":
         st = base.stem
         r0 = conv_bn(ctx, x, st[0], st[1], need_dx=False)
@@ -371,9 +391,17 @@ def audio_forward(ctx, base, spec):
     """ResNet-9/18/34 (two-conv blocks) and ResNet-50 (three-conv bottlenecks) on 1 x F x T' spectrograms (torchvision ResNet,
     SURVEY 8 a3, model.py:103-121), 2-D = 3-D with T=1."""
     x = _as5d(spec)
+    folded = ctx.folded if not ctx.training else None
     r0 = conv_bn(ctx, x, base.conv1, base.bn1, need_dx=False)
     u, idx = ctx.ops.bnrelu_maxpool_fwd(r0.y, r0.ss)
     recs = []
+    if folded is not None:
+        for layer in (base.layer1, base.layer2, base.layer3, base.layer4):
+            for blk in layer:
+                chain = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)] + ([(blk.conv3, blk.bn3)] if hasattr(blk, "conv3") else [])
+                ds = (blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+                u = block_fwd_folded(ctx, u, chain, ds)
+        return ctx.ops.avgpool_fwd(u), None
     for layer in (base.layer1, base.layer2, base.layer3, base.layer4):
         for blk in layer:
             chain = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]

@@ -235,6 +235,15 @@ def _backend(trunk):
     return ops
 
 
+def _folded_of(trunk, ectx, need_grad):
+    """infer32.FoldedEval attached to this trunk (infer32.folded_eval) -- taken for eval-mode forwards without autograd state
+    on the fp32 backend only."""
+    f = getattr(trunk, "_folded_eval", None)
+    if f is None or ectx.training or need_grad or torch.is_grad_enabled() or ectx.ops is not ops:
+        return None
+    return f
+
+
 def _sync_of(mod):
     s = getattr(mod, "sync", None)
     if s == "auto":
@@ -305,6 +314,7 @@ class TrunkFunction(torch.autograd.Function):
         training = trunk.training
         need_grad = training and any(fctx.needs_input_grad)
         ectx = engine.Ctx(training, sync=_sync_of(trunk) if training else None, ops=_backend(trunk))
+        ectx.folded = _folded_of(trunk, ectx, need_grad)
         fwd = engine.video_forward if kind == "video" else engine.audio_forward
         side = getattr(trunk, "side_stream", None) if x.is_cuda else None
         if side is not None:
@@ -381,7 +391,8 @@ class VideoStageFunction(torch.autograd.Function):
         training = trunk.training
         need_grad = training and any(fctx.needs_input_grad)
         ectx = engine.Ctx(training, sync=_sync_of(trunk) if training else None, ops=_backend(trunk))
-        ectx.wimg = _weight_images(trunk, x, training, first=(stage == "stem"))
+        ectx.folded = _folded_of(trunk, ectx, need_grad)
+        ectx.wimg = _weight_images(trunk, x, training, first=(stage == "stem")) if ectx.folded is None else None
         out, saved = engine.video_stage_forward(ectx, trunk, stage, x, aux)
         if isinstance(out, tuple):
             fctx.mark_non_differentiable(out[1])
