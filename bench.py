@@ -273,7 +273,7 @@ def sk_round_estimate(m, dev, world, step_clips_per_s, sk):
     t_feat = N / (rate * world)
     notes = {"fp32": "default: BatchNorm folded into the weights, conv + BN (+ shortcut) + ReLU in one launch, exact three-piece operand split",
              "fp32_unfolded": "SELAVI_FEATURE_PASS=fp32_unfolded: the model's plain eval forward (rounds 1-5)",
-             "fp32x2": "SELAVI_FEATURE_PASS=fp32x2 (opt-in): folded, two bf16 pieces per operand / three partial products: features ~1e-5 "
+             "fp32x2": "SELAVI_FEATURE_PASS=fp32x2 (opt-in): folded, two bf16 pieces per operand / three partial products: features ~2e-4 "
                        "relative off the exact split, labels not guaranteed identical",
              "bf16": "SELAVI_FEATURE_PASS=bf16 (opt-in): eval forward on bf16 channels-last activations (selavi_amd/infer16.py); features "
                      "within ~5e-3 of fp32, labels not bit-exact"}

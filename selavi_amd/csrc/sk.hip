@@ -17,12 +17,17 @@ namespace slv {
 thread_local char g_err[512] = {0};
 int g_stale_hip_errors = 0;
 
+constexpr int SK_NGRP = 8;   // workgroup groups of the fused pass's two-level grid reduction
 struct SkCtrl {       // lives at the head of the workspace (64 bytes)
   int counter;        // iterations executed so far (the reference's _counter)
   int done;           // 1 -> loop has terminated, later launches are no-ops
   double err;         // last tested err (init 1e6, sk_utils.py:396)
-  double pad[6];
+  // arrival counters of the fused pass (sk_pass_kernel<.., FUSED>): zero between launches (the last arriver resets them)
+  unsigned grp_arrive[SK_NGRP];
+  unsigned fin_arrive;
+  unsigned pad[3];
 };
+static_assert(sizeof(SkCtrl) == 64, "SkCtrl is the 64-byte head of the workspace");
 
 struct SkWs {
   SkCtrl* ctrl;
@@ -30,6 +35,7 @@ struct SkWs {
   double* s;        // Kp + 64 ; s[K] carries the err partial so one all-reduce moves both
   double* partial;  // grid * Kp
   double* errp;     // grid
+  double* gpart;    // SK_NGRP * Kp + SK_NGRP: per-group sums (+ the groups' err sums) of the fused pass
   int Kp;
 };
 
@@ -57,6 +63,8 @@ static inline SkWs carve(void* ws, int K, int grid) {
   w.partial = (double*)p;
   p += sizeof(double) * (size_t)grid * w.Kp;
   w.errp = (double*)p;
+  p += sizeof(double) * (size_t)grid;
+  w.gpart = (double*)p;
   return w;
 }
 
@@ -172,7 +180,15 @@ __global__ __launch_bounds__(256) void sk_pow_kernel(double* __restrict__ P, int
 // ------------------------------------------------------------------------------------------
 // block-level fixed-order reduction of the per-lane column accumulators -> partial[block][k]
 // ------------------------------------------------------------------------------------------
-template <int KJ>
+// Agent-coherent accesses without a fence: relaxed atomics at agent scope compile to plain global_load / global_store with
+// sc1 (write-through to / read from the device's coherence point, past the per-XCD L2).  A release / acquire FENCE at agent
+// scope is buffer_wbl2 + buffer_inv over the whole L2 of the XCD: measured at ~0.34 us per workgroup and serialised
+// (512 workgroups: 81 -> 255 us per iteration, profiles/r06_sk_fused_ab.txt) -- the fused tail below orders its few
+// coherent stores with s_waitcnt vmcnt(0) + the arrival atomic instead.
+__device__ __forceinline__ void coh_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double coh_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int KJ, bool COH = false>
 __device__ __forceinline__ void block_reduce_cols(const double (&acc)[KJ], double e, SkWs w,
                                                   double* sh /* SK_WAVES*KJ*64 + SK_WAVES */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -186,13 +202,15 @@ __device__ __forceinline__ void block_reduce_cols(const double (&acc)[KJ], doubl
 #pragma unroll
     for (int wv = 0; wv < SK_WAVES; ++wv) v += sh[wv * KJ * 64 + idx];
     // idx = j*64 + lane  <->  column k = lane + 64*j
-    w.partial[(size_t)blockIdx.x * w.Kp + idx] = v;
+    if constexpr (COH) coh_store(&w.partial[(size_t)blockIdx.x * w.Kp + idx], v);
+    else w.partial[(size_t)blockIdx.x * w.Kp + idx] = v;
   }
   if (threadIdx.x == 0) {
     double v = 0.0;
 #pragma unroll
     for (int wv = 0; wv < SK_WAVES; ++wv) v += she[wv];
-    w.errp[blockIdx.x] = v;
+    if constexpr (COH) coh_store(&w.errp[blockIdx.x], v);
+    else w.errp[blockIdx.x] = v;
   }
 }
 
@@ -225,11 +243,20 @@ __global__ __launch_bounds__(SK_THREADS) void sk_colsum_kernel(const double* __r
 //   t_i = sum_k P_ik alpha_k ; beta'_i = c / t_i ; err += |beta_i / beta'_i - 1| (tested iters)
 //   s'_k += beta'_i P_ik  (column sums the NEXT iteration's alpha needs)
 // ------------------------------------------------------------------------------------------
-template <int KJ, int ROWS>
+// FUSED: the grid-level reduction (and, with r != nullptr, the alpha update + loop control of sk_update_kernel) runs in the
+// TAIL of this launch instead of in two more launches: the workgroups are cut into SK_NGRP groups of consecutive indices; the
+// last workgroup of a group to arrive (a device-scope atomic behind a release fence) sums that group's partials in INDEX
+// order, the last group to finish sums the group sums in group order -- a fixed summation tree whatever the arrival order,
+// so the result is bit-reproducible run to run like the separate sk_local_reduce_kernel's (its tree differs: results agree to
+// fp64 rounding, labels / iteration counts / cost are pinned by the same goldens).  The idea: seven of the eight group sums are
+// formed while other workgroups still stream, only one group sum + the final stage stay exposed.  MEASURED SLOWER than the
+// two extra launches (see sk_fused() below): opt-in, SELAVI_SK_FUSED=1.
+template <int KJ, int ROWS, bool FUSED = false>
 __global__ __launch_bounds__(SK_THREADS) void sk_pass_kernel(const double* __restrict__ P,
                                                             int64_t N, int K, double c,
                                                             double* __restrict__ beta, SkWs w,
-                                                            int64_t rows_per_block) {
+                                                            int64_t rows_per_block, const double* __restrict__ r = nullptr,
+                                                            double tol = 0.0, int max_iter = 0) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   if (w.ctrl->done) return;
   const bool check = (w.ctrl->counter % 10) == 0;
@@ -277,7 +304,60 @@ __global__ __launch_bounds__(SK_THREADS) void sk_pass_kernel(const double* __res
       }
     }
   }
-  block_reduce_cols<KJ>(acc, e, w, sh);
+  block_reduce_cols<KJ, FUSED>(acc, e, w, sh);
+  if constexpr (FUSED) {
+    __shared__ int s_role;
+    const int grid = (int)gridDim.x, gs = (grid + SK_NGRP - 1) / SK_NGRP, ngrp = (grid + gs - 1) / gs;
+    const int grp = (int)blockIdx.x / gs, b0 = grp * gs, b1 = (b0 + gs < grid) ? b0 + gs : grid;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's coherent stores have reached the coherence point ...
+    __syncthreads();                                      // ... every thread's, before thread 0 announces the row
+    if (threadIdx.x == 0) s_role = (atomicAdd(&w.ctrl->grp_arrive[grp], 1u) == (unsigned)(b1 - b0 - 1)) ? 1 : 0;
+    __syncthreads();
+    if (!s_role) return;
+    for (int k = threadIdx.x; k < w.Kp; k += SK_THREADS) {
+      double v = 0.0;
+      for (int b = b0; b < b1; ++b) v += coh_load(&w.partial[(size_t)b * w.Kp + k]);       // index order
+      coh_store(&w.gpart[(size_t)grp * w.Kp + k], v);
+    }
+    if (threadIdx.x == 0) {
+      double v = 0.0;
+      for (int b = b0; b < b1; ++b) v += coh_load(&w.errp[b]);
+      coh_store(&w.gpart[(size_t)SK_NGRP * w.Kp + grp], v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_role = (atomicAdd(&w.ctrl->fin_arrive, 1u) == (unsigned)(ngrp - 1)) ? 2 : 0;
+    __syncthreads();
+    if (s_role != 2) return;
+    // final stage: s[k] = sum over groups in group order, s[K] = the err sum; then (single-GPU loop) sk_update_kernel's work
+    const int cnt = w.ctrl->counter;
+    double err = w.ctrl->err;
+    double ev = 0.0;
+    for (int g = 0; g < ngrp; ++g) ev += coh_load(&w.gpart[(size_t)SK_NGRP * w.Kp + g]);
+    int done = 0, newc = cnt;
+    if (r) {
+      if ((cnt % 10) == 0) err = ev;
+      newc = cnt + 1;
+      done = (!(err > tol)) || (newc >= max_iter);
+    }
+    for (int k = threadIdx.x; k < K; k += SK_THREADS) {
+      double v = 0.0;
+      for (int g = 0; g < ngrp; ++g) v += coh_load(&w.gpart[(size_t)g * w.Kp + k]);
+      w.s[k] = v;
+      if (r && !done) w.alpha[k] = r[k] / v;
+    }
+    __syncthreads();                              // everybody has read ctrl before thread 0 rewrites it
+    if (threadIdx.x == 0) {
+      w.s[K] = ev;
+      if (r) {
+        w.ctrl->counter = newc;
+        w.ctrl->done = done;
+        w.ctrl->err = err;
+      }
+      for (int g = 0; g < SK_NGRP; ++g) w.ctrl->grp_arrive[g] = 0u;      // clean for the next launch
+      w.ctrl->fin_arrive = 0u;
+    }
+  }
 }
 
 // grid-level fixed-order reduce: s[k] = sum_b partial[b][k];  s[K] = sum_b errp[b].
@@ -341,6 +421,8 @@ __global__ void sk_begin_kernel(SkWs w, double* __restrict__ beta, int64_t N_loc
     w.ctrl->counter = 0;
     w.ctrl->done = 0;
     w.ctrl->err = 1e6;
+    for (int g = 0; g < SK_NGRP; ++g) w.ctrl->grp_arrive[g] = 0u;
+    w.ctrl->fin_arrive = 0u;
   }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < N_local; i += stride) beta[i] = b0;
@@ -524,7 +606,7 @@ int slv_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_nam
 
 size_t slv_sk_workspace_bytes(int K, int grid) {
   const int Kp = kpad(K);
-  return sizeof(SkCtrl) + sizeof(double) * ((size_t)Kp + (Kp + 64) + (size_t)grid * Kp + grid);
+  return sizeof(SkCtrl) + sizeof(double) * ((size_t)Kp + (Kp + 64) + (size_t)grid * Kp + grid + (size_t)SK_NGRP * Kp + SK_NGRP);
 }
 
 int32_t slv_sk_default_grid(int64_t N, int K) {
@@ -650,9 +732,44 @@ int slv_sk_pass_reduce(const double* P, int64_t N_local, int64_t N_global, int K
   return rc ? rc : slv_sk_local_reduce(K, ws, grid, stream);
 }
 
+// SELAVI_SK_FUSED=1 (an experiment, OFF by default): one launch per iteration -- measured SLOWER than the three launches it
+// replaces on this chip (profiles/r06_sk_fused_ab*.txt, N = 170 752, K = 309, grid 512): 84-87 us per iteration as pass +
+// grid reduce + update; 255-268 us with the tail behind agent-scope fences (buffer_wbl2 / buffer_inv of the XCD's L2 per
+// workgroup, serialised: + 0.34 us per workgroup); 99-103 us with coherent (sc1) stores / loads and no fence -- the 512 arrival
+// atomics on 8 counters at the device's coherence point cost more than the two dispatch gaps they save, and the cost grows
+// with the grid (2 048 workgroups: 203 us).  Kept as the A/B of that measurement; results are identical to the default path's
+// up to fp64 rounding of a different (equally fixed) summation tree (tests/test_sk_gpu.py runs both).
+static bool sk_fused() {
+  static const bool on = []() {
+    const char* e = getenv("SELAVI_SK_FUSED");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+
+static int launch_pass_fused(const double* P, int64_t N_local, int64_t N_global, int K, double* beta, const double* r, double tol,
+                             int max_iter, void* ws, int grid, hipStream_t stream) {
+  SkWs w = carve(ws, K, grid);
+  const int64_t rpb = (N_local + grid - 1) / grid;
+  const double c = 1.0 / (double)N_global;  // sk_utils.py:395
+  SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_pass_kernel<KJ, SK_PASS_ROWS, true>), dim3(grid), dim3(SK_THREADS), sh_bytes(KJ), stream,
+                                        P, N_local, K, c, beta, w, rpb, r, tol, max_iter));
+  SLV_LAUNCH_CHECK();
+  return 0;
+}
+
 int slv_sk_iterate(const double* P, int64_t N, int K, double* beta, const double* r, double tol,
                    int max_iter, int n_iters, void* ws, int grid, slv_stream_t stream) {
-  // single-GPU fast path: n_iters x (pass, local_reduce, update) enqueued from C, no host sync
+  SLV_CHECK_ARG(P && beta && r && ws && N > 0 && K > 0 && grid > 0, "null pointer or empty shape");
+  if (sk_fused()) {
+    // one launch per iteration: pass + grid reduce + alpha update / loop control in its tail (sk_pass_kernel<.., FUSED>)
+    for (int it = 0; it < n_iters; ++it) {
+      const int rc = launch_pass_fused(P, N, N, K, beta, r, tol, max_iter, ws, grid, (hipStream_t)stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  // n_iters x (pass, local_reduce, update) enqueued from C, no host sync
   for (int it = 0; it < n_iters; ++it) {
     int rc = slv_sk_pass(P, N, N, K, beta, ws, grid, stream);
     if (rc) return rc;
@@ -671,11 +788,18 @@ int slv_sk_iterate_sharded(slv_comm_t comm, const double* P, int64_t N_local, in
                            const double* r, double tol, int max_iter, int n_iters, void* ws, int grid,
                            slv_stream_t stream) {
   SLV_CHECK_ARG(comm, "null communicator");
+  SLV_CHECK_ARG(P && beta && r && ws && N_local > 0 && K > 0 && grid > 0, "null pointer or empty shape");
   for (int it = 0; it < n_iters; ++it) {
-    int rc = slv_sk_pass(P, N_local, N_global, K, beta, ws, grid, stream);
-    if (rc) return rc;
-    rc = slv_sk_local_reduce(K, ws, grid, stream);
-    if (rc) return rc;
+    int rc;
+    if (sk_fused()) {     // the local column sums come out of the pass's tail (no update there: the all-reduce sits in between)
+      rc = launch_pass_fused(P, N_local, N_global, K, beta, nullptr, 0.0, 0, ws, grid, (hipStream_t)stream);
+      if (rc) return rc;
+    } else {
+      rc = slv_sk_pass(P, N_local, N_global, K, beta, ws, grid, stream);
+      if (rc) return rc;
+      rc = slv_sk_local_reduce(K, ws, grid, stream);
+      if (rc) return rc;
+    }
     rc = slv::comm_allreduce_sum_f64(comm, slv_sk_s_ptr(ws, K, grid), (size_t)K + 1, (hipStream_t)stream);
     if (rc) return rc;
     rc = slv_sk_update(r, K, tol, max_iter, 0, ws, grid, stream);

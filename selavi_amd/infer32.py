@@ -15,8 +15,8 @@ fp32 kernel followed by slv_bn_act.
 
 ``pieces``: 3 = the exact three-piece operand split of the training path (six partial products per fp32 product: the
 arithmetic every parity claim of the fp32 path rests on); 2 = two pieces / three partial products (opt-in,
-SELAVI_FEATURE_PASS=fp32x2): 16-17 significand bits per product at half the matrix-core work -- features move by ~1e-5
-relative, far inside the 1e-3 the north star allows for logits, but pseudo labels are an argmax and are only
+SELAVI_FEATURE_PASS=fp32x2): 16-17 significand bits per product at half the matrix-core work -- features move by ~2e-4
+relative (41 convs deep), inside the 1e-3 the north star allows for logits, but pseudo labels are an argmax and are only
 guaranteed identical with pieces = 3 (tests/test_infer32_gpu.py quantifies both).
 
     with infer32.folded_eval(model, pieces=3):       # model in eval mode, under torch.no_grad()
@@ -32,16 +32,28 @@ from . import ops
 from ._lib import C, ptr, stream
 
 
+def _round16_(w):
+    """fp32 -> the nearest value with 16 significand bits (round to nearest even), in place.  Such a value is EXACTLY the sum of
+    the first two pieces of the three-piece split (the third is zero), so the two-piece kernel reads its weights without the
+    one-sided truncation error of dropping a non-zero third piece: 40 layers of a -2^-17 relative bias added up coherently to
+    3.5e-4 on the features; rounded, the weights' error is unbiased (measured: tests/test_infer32_gpu.py)."""
+    b = w.view(torch.int32)
+    b.add_(0x7F + ((b >> 8) & 1)).bitwise_and_(~0xFF)
+    return w
+
+
 class _Folded:
     """One conv + BatchNorm pair: scaled weights, bias, and the split-operand image (made at first use)."""
     __slots__ = ("w", "bias", "ss", "img", "ok")
 
-    def __init__(self, conv, bn):
+    def __init__(self, conv, bn, pieces):
         _, ss = ops.bn_eval_params(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         w = conv.weight.detach()
         self.ss = ss
         self.bias = ss[1].contiguous()
         self.w = (w * ss[0].view(-1, *([1] * (w.dim() - 1)))).contiguous()       # one-time weight preparation
+        if pieces == 2:
+            _round16_(self.w)
         self.img = None
         self.ok = None
 
@@ -57,7 +69,7 @@ class FoldedEval:
         """relu?(bn(conv(x)) + res) on a MATERIALISED fp32 N,C,T,H,W tensor -> materialised tensor."""
         L = self.layers.get(id(conv))
         if L is None:
-            L = self.layers[id(conv)] = _Folded(conv, bn)
+            L = self.layers[id(conv)] = _Folded(conv, bn, self.pieces)
         plan = ops.plan_for(x, conv)
         first = plan if plan.chunks is None else plan.chunks[0][2]
         if L.ok is None:

@@ -407,7 +407,7 @@ def get_cluster_assignments_gpu(args, dataset, model, logger=None, writer=None, 
     # features are NOT the bit-exact fp32 ones -- the default stays fp32).  args.feature_pass or SELAVI_FEATURE_PASS
     # default "fp32": the fp32 trunks with BatchNorm folded into the weights for the length of the pass (selavi_amd/infer32.py:
     # conv + BN (+ shortcut) + ReLU in one launch, weight images made once per pass; the exact three-piece operand split of the
-    # training path); "fp32x2" (opt-in): the same with two pieces per operand (half the matrix-core work, features ~1e-5 off);
+    # training path); "fp32x2" (opt-in): the same with two pieces per operand (half the matrix-core work, features ~2e-4 off);
     # "fp32_unfolded": the model's plain eval forward (rounds 1-5)
     engine16 = None
     fp_mode = getattr(args, "feature_pass", None) or os.environ.get("SELAVI_FEATURE_PASS", "fp32")
