@@ -158,23 +158,26 @@ def sk_bench(rank, world, dev, iters=50):
     grp = dist.group.WORLD if world > 1 else None
     comm = sk_utils._comm_of(grp, be)        # RCCL behind the C ABI (None over gloo: torch.distributed carries it)
 
+    TOL = -1.0      # err >= 0 > tol: the loop never declares itself done (with tol = 0 it reaches an exact fixed point, err == 0.0,
+                    # after a few hundred iterations and every later launch is a no-op: the timed ones are checked below)
+
     def run(k):
         if world == 1:
-            be.iterate(P, beta, r, 0.0, 10 ** 9, k, ws, grid)
+            be.iterate(P, beta, r, TOL, 10 ** 9, k, ws, grid)
         elif comm is not None:               # the product's sharded loop: k iterations in one host call, one stream
             from selavi_amd._lib import C, ptr, stream
-            C.slv_sk_iterate_sharded(comm.h, ptr(P), n, N, K, ptr(beta), ptr(r), 0.0, 10 ** 9, k, ptr(ws), grid, stream())
+            C.slv_sk_iterate_sharded(comm.h, ptr(P), n, N, K, ptr(beta), ptr(r), TOL, 10 ** 9, k, ptr(ws), grid, stream())
         else:
             sv = be.s_view(ws, K, grid)
             for _ in range(k):
                 be.pass_reduce(P, N, beta, ws, grid)
                 dist.all_reduce(sv, group=grp)
-                be.update(r, K, 0.0, 10 ** 9, False, ws, grid)
+                be.update(r, K, TOL, 10 ** 9, False, ws, grid)
     be.begin(P, N, beta, ws, grid)
     be.local_reduce(K, ws, grid)
     if world > 1:
         sk_utils._allreduce(be.s_view(ws, K, grid), grp, comm)
-    be.update(r, K, 0.0, 10 ** 9, True, ws, grid)
+    be.update(r, K, TOL, 10 ** 9, True, ws, grid)
     run(5)
     torch.cuda.synchronize()
     if world > 1:
@@ -185,6 +188,9 @@ def sk_bench(rank, world, dev, iters=50):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
+    hb = torch.empty(4, dtype=torch.float64, pin_memory=True)
+    be.status_async(ws, K, grid, hb).synchronize()
+    assert int(hb[0]) == 5 + iters and int(hb[1]) == 0, f"the SK loop stopped early: counter {hb[0]}, done {hb[1]}"
     if world > 1:
         t = torch.tensor([ms], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -193,10 +199,10 @@ def sk_bench(rank, world, dev, iters=50):
     if world > 1:
         # the same shard without the exchange (the single-GPU loop on the local rows): what of an iteration is the pass over
         # the shard and what is the K-vector all-reduce (+ its launch latency) -- SURVEY 8e-2
-        be.iterate(P, beta, r, 0.0, 10 ** 9, 5, ws, grid)
+        be.iterate(P, beta, r, TOL, 10 ** 9, 5, ws, grid)
         torch.cuda.synchronize()
         e0.record()
-        be.iterate(P, beta, r, 0.0, 10 ** 9, iters, ws, grid)
+        be.iterate(P, beta, r, TOL, 10 ** 9, iters, ws, grid)
         e1.record()
         torch.cuda.synchronize()
         ms_local = e0.elapsed_time(e1) / iters
@@ -217,9 +223,9 @@ def sk_bench(rank, world, dev, iters=50):
 def sk_round_estimate(m, dev, world, step_clips_per_s, sk):
     """What one Sinkhorn-Knopp round costs next to the training it interleaves with (BASELINE metric: "clips/sec
     (video+audio fwd/bwd+SK)").  Measured here: the eval-mode feature pass of sk_utils.py:137-233 at its batch size
-    (64, :168) on this GPU, as selavi_amd.sk_utils runs it by default: the fp32 trunks with BatchNorm folded into the weights
-    for the length of the pass (selavi_amd/infer32.py; the exact three-piece operand split of the training path).  Beside it:
-    the plain eval forward of rounds 1-5 ("fp32_unfolded"), the two-piece opt-in ("fp32x2") and the bf16 opt-in.
+    (64, :168) on this GPU, as selavi_amd.sk_utils runs it by default: the model's own fp32 eval forward.  Beside it: the same
+    trunks with BatchNorm folded into the weights for the length of the pass (selavi_amd/infer32.py) with the exact three-piece
+    operand split ("fp32_folded") and with two pieces per operand ("fp32x2", opt-in), and the bf16 opt-in.
     Derived with the reference's defaults (opt.py:71,88,102: 100 epochs, nopts=100 rounds,
     ind_groups=1) at the VGG-Sound size: round = N / (W x feature-pass rate) + hc heads x 200 SK iterations at the
     measured it/s (71-271 iterations to converge), against the epochs x N / nopts clips trained between
@@ -244,8 +250,8 @@ def sk_round_estimate(m, dev, world, step_clips_per_s, sk):
     rates = {}
     try:
         with torch.no_grad():
-            rates["fp32_unfolded"] = rate_of(lambda: m(video, audio))
-            for name, pieces in (("fp32", 3), ("fp32x2", 2)):
+            rates["fp32"] = rate_of(lambda: m(video, audio))
+            for name, pieces in (("fp32_folded", 3), ("fp32x2", 2)):
                 try:
                     with infer32.folded_eval(m, pieces=pieces):
                         rates[name] = rate_of(lambda: m(video, audio))
@@ -268,11 +274,12 @@ def sk_round_estimate(m, dev, world, step_clips_per_s, sk):
 
     def incl(rate):
         return step_clips_per_s * t_train / (N / (rate * world) + t_sk + t_train)
-    default = "fp32" if "fp32" in rates else "fp32_unfolded"
+    default = "fp32"
     rate = rates[default]
     t_feat = N / (rate * world)
-    notes = {"fp32": "default: BatchNorm folded into the weights, conv + BN (+ shortcut) + ReLU in one launch, exact three-piece operand split",
-             "fp32_unfolded": "SELAVI_FEATURE_PASS=fp32_unfolded: the model's plain eval forward (rounds 1-5)",
+    notes = {"fp32": "default: the model's own eval forward (bit for bit what model.eval() returns)",
+             "fp32_folded": "SELAVI_FEATURE_PASS=fp32_folded: BatchNorm folded into the weights, conv + BN (+ shortcut) + ReLU in one "
+                            "launch, weight images made once per pass, exact three-piece operand split (features 6e-7 off the default)",
              "fp32x2": "SELAVI_FEATURE_PASS=fp32x2 (opt-in): folded, two bf16 pieces per operand / three partial products: features ~2e-4 "
                        "relative off the exact split, labels not guaranteed identical",
              "bf16": "SELAVI_FEATURE_PASS=bf16 (opt-in): eval forward on bf16 channels-last activations (selavi_amd/infer16.py); features "

@@ -251,7 +251,17 @@ __global__ __launch_bounds__(SK_THREADS) void sk_colsum_kernel(const double* __r
 // fp64 rounding, labels / iteration counts / cost are pinned by the same goldens).  The idea: seven of the eight group sums are
 // formed while other workgroups still stream, only one group sum + the final stage stay exposed.  MEASURED SLOWER than the
 // two extra launches (see sk_fused() below): opt-in, SELAVI_SK_FUSED=1.
-template <int KJ, int ROWS, bool FUSED = false>
+// NT: the loads of P carry the non-temporal hint -- P is read exactly once per iteration; beyond the 256 MB Infinity Cache
+// (one GPU at the VGG-Sound / Kinetics sizes) nothing of it survives to the next iteration anyway, and streaming past the
+// caches' allocation leaves them to beta / the partials.  A row shard that FITS the cache (8-way sharding: 52.8 MB) must stay
+// resident from iteration to iteration: the hint is off there (slv_sk_pass picks by the shard's bytes).  Measured, whole
+// iterations (pass + grid reduce + update), 200 iterations that never terminate, same box, same call
+// (profiles/r06_sk_ab_honest.txt): N = 170 752, K = 309, grid 512: 88.9-89.6 -> 77.6-78.0 us; N = 230 976, K = 400, grid 256:
+// 146.6 -> 129.0 us.  Tried on top and dropped: eight rows per wave in flight instead of four (slower); walking a workgroup's
+// rows back and forth on alternate iterations so that an iteration starts on the rows its predecessor finished with (the
+// Infinity Cache holds 60 % of P): slower, the reversed address stream costs more than the hits return
+// (profiles/r06_sk_alt_ab.txt -- relative figures only: that call averaged over launches behind the solver's fixed point).
+template <int KJ, int ROWS, bool FUSED = false, bool NT = false>
 __global__ __launch_bounds__(SK_THREADS) void sk_pass_kernel(const double* __restrict__ P,
                                                             int64_t N, int K, double c,
                                                             double* __restrict__ beta, SkWs w,
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_pass_kernel(const double* __res
 #pragma unroll
       for (int j = 0; j < KJ; ++j) {
         const int k = lane + 64 * j;
-        p[r][j] = (rv && k < K) ? P[ii * K + k] : 0.0;
+        p[r][j] = (rv && k < K) ? (NT ? __builtin_nontemporal_load(&P[ii * K + k]) : P[ii * K + k]) : 0.0;
       }
     }
 #pragma unroll
@@ -580,6 +590,17 @@ __global__ void sk_sum_splits_kernel(const double* __restrict__ partial, double*
 
 static inline size_t sh_bytes(int KJ) { return sizeof(double) * (SK_WAVES * KJ * 64 + SK_WAVES); }
 
+// SELAVI_SK_NT: "1" / "0" force the non-temporal loads of the pass on / off; default: on when the shard does not fit the
+// Infinity Cache (> 200 MB).
+static inline bool sk_pass_nt(int64_t N_local, int K) {
+  static const int mode = []() {
+    const char* e = getenv("SELAVI_SK_NT");
+    return !e ? -1 : (e[0] == '0' ? 0 : 1);
+  }();
+  if (mode >= 0) return mode == 1;
+  return (double)N_local * K * 8.0 > 200e6;
+}
+
 }  // namespace slv
 
 using namespace slv;
@@ -610,14 +631,20 @@ size_t slv_sk_workspace_bytes(int K, int grid) {
 }
 
 int32_t slv_sk_default_grid(int64_t N, int K) {
-  // 2 workgroups of 8 waves per CU on a 256-CU part; never more blocks than 8-row chunks.  Measured per
-  // iteration at N=170752, K=309 (pass + grid reduce + update): 256: 88.5, 512: 87.9, 1024: 90.9, 2048: 95.9 us
-  // (the reduce over [grid][K] partials grows with the grid).
-  int64_t g = 512;
+  // 2 workgroups of 8 waves per CU on a 256-CU part; never more blocks than 8-row chunks.  Measured per iteration (pass with
+  // non-temporal loads + grid reduce + update, 200 iterations, profiles/r06_sk_ab_honest.txt) at N = 170 752, K = 309:
+  // 256: 78.4-79.0, 512: 77.6-78.0, 768: 79.1-79.8, 1024: 80.8, 1536: 83, 2048: 88.6 us (the reduce over [grid][K] partials grows
+  // with the grid); N = 230 976, K = 400: 256: 129, 512: 136, 768: 132, 1024: 142.  A row shard of an 8-GPU run (21 344 rows,
+  // resident in the Infinity Cache): 256: 17.4, 512: 18.6, 768: 20.9 us -- there the reduce is a third of the iteration.
+  // SELAVI_SK_GRID overrides (A/B).
+  static const int64_t forced = []() {
+    const char* e = getenv("SELAVI_SK_GRID");
+    return e ? (int64_t)atoi(e) : (int64_t)0;
+  }();
+  int64_t g = forced > 0 ? forced : ((double)N * K * 8.0 > 200e6 ? 512 : 256);
   const int64_t maxg = (N + 7) / 8;
   if (g > maxg) g = maxg;
   if (g < 1) g = 1;
-  (void)K;
   return (int)g;
 }
 
@@ -719,8 +746,13 @@ int slv_sk_pass(const double* P, int64_t N_local, int64_t N_global, int K, doubl
   SkWs w = carve(ws, K, grid);
   const int64_t rpb = (N_local + grid - 1) / grid;
   const double c = 1.0 / (double)N_global;  // sk_utils.py:395
-  SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_pass_kernel<KJ, SK_PASS_ROWS>), dim3(grid), dim3(SK_THREADS), sh_bytes(KJ),
-                                        (hipStream_t)stream, P, N_local, K, c, beta, w, rpb));
+  if (sk_pass_nt(N_local, K)) {
+    SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_pass_kernel<KJ, SK_PASS_ROWS, false, true>), dim3(grid), dim3(SK_THREADS), sh_bytes(KJ),
+                                          (hipStream_t)stream, P, N_local, K, c, beta, w, rpb));
+  } else {
+    SK_DISPATCH_KJ(K, hipLaunchKernelGGL((sk_pass_kernel<KJ, SK_PASS_ROWS>), dim3(grid), dim3(SK_THREADS), sh_bytes(KJ),
+                                          (hipStream_t)stream, P, N_local, K, c, beta, w, rpb));
+  }
   SLV_LAUNCH_CHECK();
   return 0;
 }

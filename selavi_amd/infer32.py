@@ -13,9 +13,11 @@ weight images (w * s cut into bf16 pieces) are made ONCE per pass instead of onc
 reference's fp32 N,C,T,H,W tensors.  The two 3 / 1-channel stem convs have no split-operand image: they keep the native
 fp32 kernel followed by slv_bn_act.
 
-``pieces``: 3 = the exact three-piece operand split of the training path (six partial products per fp32 product: the
-arithmetic every parity claim of the fp32 path rests on); 2 = two pieces / three partial products (opt-in,
-SELAVI_FEATURE_PASS=fp32x2): 16-17 significand bits per product at half the matrix-core work -- features move by ~2e-4
+Both forms are OPT-IN for the SK round (SELAVI_FEATURE_PASS / args.feature_pass); its default stays the model's own eval forward.
+``pieces``: 3 ("fp32_folded") = the exact three-piece operand split of the training path (six partial products per fp32
+product: the arithmetic every parity claim of the fp32 path rests on) -- features 6e-7 off the plain forward and, measured,
+no faster (2 131 against 2 120 clips/s at 64 clips: the conv main loops are the time, not the passes folded away); 2 = two
+pieces / three partial products ("fp32x2": 2 800 clips/s): 16-17 significand bits per product at half the matrix-core work -- features move by ~2e-4
 relative (41 convs deep), inside the 1e-3 the north star allows for logits, but pseudo labels are an argmax and are only
 guaranteed identical with pieces = 3 (tests/test_infer32_gpu.py quantifies both).
 
@@ -44,7 +46,7 @@ def _round16_(w):
 
 class _Folded:
     """One conv + BatchNorm pair: scaled weights, bias, and the split-operand image (made at first use)."""
-    __slots__ = ("w", "bias", "ss", "img", "ok")
+    __slots__ = ("w", "bias", "ss", "img", "ok", "cfg")
 
     def __init__(self, conv, bn, pieces):
         _, ss = ops.bn_eval_params(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
@@ -56,6 +58,7 @@ class _Folded:
             _round16_(self.w)
         self.img = None
         self.ok = None
+        self.cfg = {}               # plan -> launch configuration of the eval kernel (benchmark mode: timed at first use)
 
 
 class FoldedEval:
@@ -83,14 +86,39 @@ class FoldedEval:
         y = torch.empty(plan.out_shape, dtype=torch.float32, device=x.device)
         if plan.chunks is None:
             C.slv_conv_fwd_eval(plan.gp, ptr(x), ptr(L.img), ptr(plan.tab_fwd), ptr(L.bias), ptr(res), int(relu), self.pieces,
-                                ptr(y), plan.cfg_fwd, stream())
+                                ptr(y), self._cfg(L, plan, x, y), stream())
             self.launches += 1
             return y
         for b0, b1, sub in plan.chunks:                                         # batch slices at the 32-bit buffer range
             C.slv_conv_fwd_eval(sub.gp, ptr(x[b0:b1]), ptr(L.img), ptr(sub.tab_fwd), ptr(L.bias),
-                                ptr(None if res is None else res[b0:b1]), int(relu), self.pieces, ptr(y[b0:b1]), sub.cfg_fwd, stream())
+                                ptr(None if res is None else res[b0:b1]), int(relu), self.pieces, ptr(y[b0:b1]),
+                                self._cfg(L, sub, x[b0:b1], y[b0:b1]), stream())
             self.launches += 1
         return y
+
+    def _cfg(self, L, plan, x, y):
+        """Launch configuration of the eval kernel for this layer shape.  Benchmark mode (ops.set_benchmark, main.py:187
+        cudnn.benchmark = True): every unsplit tile candidate is timed once on the layer's own tensors -- the training forward's
+        tuned tile was chosen for a kernel with a load prologue, a statistics epilogue and twice the matrix-core work of the
+        two-piece form; otherwise the training forward's configuration."""
+        cfg = L.cfg.get(id(plan))
+        if cfg is not None:
+            return cfg
+        cfg = plan.cfg_fwd if (plan.cfg_fwd >> 16) <= 1 else 0                  # (K is never split here)
+        if ops.benchmark and x.is_cuda:
+            best = None
+            for cand in [cfg] + [c for c in plan.candidates(0) if (c >> 16) <= 1 and ((c >> 12) & 15) == 0 and c != cfg]:
+                try:
+                    t = ops._time_call(lambda: C.slv_conv_fwd_eval(plan.gp, ptr(x), ptr(L.img), ptr(plan.tab_fwd), ptr(L.bias), 0, 1,
+                                                                   self.pieces, ptr(y), cand, stream()))
+                except Exception:
+                    continue
+                if best is None or t < best[0] * 0.97:
+                    best = (t, cand)
+            if best is not None:
+                cfg = best[1]
+        L.cfg[id(plan)] = cfg
+        return cfg
 
 
 def _trunks(model):

@@ -405,20 +405,22 @@ def get_cluster_assignments_gpu(args, dataset, model, logger=None, writer=None, 
                                              pin_memory=dev.type == "cuda", collate_fn=None)
     # opt-in: the feature pass in bf16 on the channels-last MFMA kernels (selavi_amd/infer16.py, ~3x faster; the
     # features are NOT the bit-exact fp32 ones -- the default stays fp32).  args.feature_pass or SELAVI_FEATURE_PASS
-    # default "fp32": the fp32 trunks with BatchNorm folded into the weights for the length of the pass (selavi_amd/infer32.py:
-    # conv + BN (+ shortcut) + ReLU in one launch, weight images made once per pass; the exact three-piece operand split of the
-    # training path); "fp32x2" (opt-in): the same with two pieces per operand (half the matrix-core work, features ~2e-4 off);
-    # "fp32_unfolded": the model's plain eval forward (rounds 1-5)
+    # args.feature_pass / SELAVI_FEATURE_PASS -- "fp32" (default): the model's own eval forward, bit for bit what model.eval()
+    # returns anywhere else; "fp32_folded": the fp32 trunks with BatchNorm folded into the weights for the length of the pass
+    # (selavi_amd/infer32.py: conv + BN (+ shortcut) + ReLU in one launch, weight images made once per pass, the exact
+    # three-piece operand split of the training path -- features 6e-7 off the plain forward, measured no faster: 2 131 against
+    # 2 120 clips/s); "fp32x2" (opt-in): folded with two pieces per operand (half the matrix-core work: 2 800 clips/s; features
+    # ~2e-4 off, labels not guaranteed identical); "bf16" (opt-in): selavi_amd/infer16.py, ~6 400 clips/s, features ~5e-3 off
     engine16 = None
     fp_mode = getattr(args, "feature_pass", None) or os.environ.get("SELAVI_FEATURE_PASS", "fp32")
-    if fp_mode not in ("fp32", "fp32x2", "fp32_unfolded", "bf16"):
-        raise ValueError(f"feature_pass {fp_mode!r}: fp32 | fp32x2 | fp32_unfolded | bf16")
+    if fp_mode not in ("fp32", "fp32_folded", "fp32x2", "bf16"):
+        raise ValueError(f"feature_pass {fp_mode!r}: fp32 | fp32_folded | fp32x2 | bf16")
     if fp_mode == "bf16":
         from . import infer16
         engine16 = infer16.Engine(net)
     import contextlib
     from . import infer32
-    folded = (lambda: infer32.folded_eval(net, pieces=3 if fp_mode == "fp32" else 2)) if fp_mode in ("fp32", "fp32x2") \
+    folded = (lambda: infer32.folded_eval(net, pieces=3 if fp_mode == "fp32_folded" else 2)) if fp_mode in ("fp32_folded", "fp32x2") \
         else contextlib.nullcontext
     for hd_grp_idx in range(args.ind_groups):                                          # :194
         # 1. feature pass over this rank's slice (every head group re-runs it: "decorrelated heads")
