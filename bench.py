@@ -304,7 +304,7 @@ FWD_MB_PER_CLIP_T32_BF16 = 1036.2 / 2 + 3.38           # video bytes halve in bf
 PEAK_BF16_MFMA_TF = 2500.0
 
 
-HOT_X3_KERNEL = "igemm3_kernel<9, 2, 1, 0, 4, 2, true>"     # csrc/igemm3.hpp: MT, NT, PRO, EPI, WAVES, OCC, FUSE of the layer-1 spatial forward
+HOT_X3_KERNEL = "igemm3_kernel<9, 2, 1, 0, 4, 2, true, 3>"     # csrc/igemm3.hpp: MT, NT, PRO, EPI, WAVES, OCC, FUSE, NP of the layer-1 spatial forward
 RIDGE_BF16 = PEAK_BF16_MFMA_TF_DENSE * 1e3 / PEAK_HBM_GBS      # 312.5 FLOP/B: above it a bf16 kernel is MFMA-bound, below HBM-bound
 # The two layer-1 forward kernels of the 16-bit path (68 % of the forward's bytes, 45 % of its FLOPs), one on each side of the ridge:
 #   spatial  Conv3d(64 -> 144, (1,3,3)): 2*144*64*9 FLOP / ((64+144)*2 B) = 399 FLOP/B  -> MFMA-bound

@@ -8,11 +8,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmct_conv_$c -o p -- python tools/conv_bench.py l1.spatial 3 > gpurun_out/pmct_conv_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmct_sk_$c -o p -- python tools/sk_bench.py > gpurun_out/pmct_sk_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmct_c16_$c -o p -- python tools/conv16_bench.py l1.spatial 3 > gpurun_out/pmct_c16_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmct_c16t_$c -o p -- python tools/conv16_bench.py l1.temporal 3 > gpurun_out/pmct_c16t_$c.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections, json
 res = collections.defaultdict(dict)
-for tag in ("conv", "sk", "c16"):
+for tag in ("conv", "sk", "c16", "c16t"):
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for f in glob.glob(f"gpurun_out/pmct_{tag}_{c}/**/*counter_collection.csv", recursive=True):
             acc = collections.defaultdict(list)
@@ -25,7 +26,7 @@ for tag in ("conv", "sk", "c16"):
                 res[name][c + "_KB"] = sum(v) / len(v)
                 res[name]["launches"] = len(v)
 out = {"_how": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes around "
-               "tools/conv_bench.py l1.spatial (B=16 Conv3d 64->144 (1,3,3) fwd/dgrad/wgrad), tools/conv16_bench.py l1.spatial (the same layer on the 16-bit path) and tools/sk_bench.py; KB per "
+               "tools/conv_bench.py l1.spatial (B=16 Conv3d 64->144 (1,3,3) fwd/dgrad/wgrad), tools/conv16_bench.py l1.spatial / l1.temporal (the layer-1 convs on the 16-bit path) and tools/sk_bench.py; KB per "
                "dispatch (mean); hbm_bytes = 2*FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE"}
 for k, d in res.items():
     if "FETCH_SIZE_KB" in d and "WRITE_SIZE_KB" in d:
@@ -43,11 +44,13 @@ for k, d in list(res.items()):          # aliases bench.py looks up
         out["sk_pass"] = dict(d, kernel=k)
     if k.startswith("conv_cl16_sr_kernel<1, 1>") or ((k.startswith("conv_cl16_s3_kernel<9, 1, 1>") or k.startswith("conv_cl16_kernel<9, 1, 1>")) and "hot_conv16_fwd" not in out):
         out["hot_conv16_fwd"] = dict(d, kernel=k)          # layer-1 spatial train forward of the 16-bit path
+    if k.startswith("conv_cl16_tr_kernel<4, 5, 1, 1>"):
+        out["hot_conv16_fwd_temporal"] = dict(d, kernel=k)          # layer-1 temporal train forward of the 16-bit path (HBM-bound)
     if k.startswith("cl16_wgrad_acc_kernel<1>") or ((k.startswith("cl16_wgrad3_kernel<5, 1>") or k.startswith("cl16_wgrad_kernel<5, 3, 1>")) and "hot_conv16_wgrad" not in out):
         out["hot_conv16_wgrad"] = dict(d, kernel=k)          # layer-1 spatial weight gradient (accumulator-resident kernel)
 json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 import shutil
-for tag in ("conv", "sk", "c16"):
+for tag in ("conv", "sk", "c16", "c16t"):
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         shutil.rmtree(f"gpurun_out/pmct_{tag}_{c}", ignore_errors=True)
 print(json.dumps(out, indent=1))
