@@ -182,6 +182,26 @@ def test_preflight_failure_falls_back_to_torch_distributed_on_every_rank(monkeyp
     assert ret_fb[0][1] == ret_gloo[0][1]
 
 
+def _spawn8(fn, make_args):
+    """mp.spawn of an 8-process rig on ONE GPU with a single retry when a worker is KILLED BY SIGABRT (not when it raises: an
+    assertion in a worker fails the test at once).  Round 6 saw one process of eight die with HSA_STATUS_ERROR_ILLEGAL_
+    INSTRUCTION (the runtime aborts: SIGABRT) in one of five runs of the 8-rank bench rig, the other seven healthy, three
+    re-runs green: eight processes time-sliced on one device -- the driver saving and restoring waves of kernels that fill the
+    register file and LDS -- is what these rigs add to the picture, not what one process per GPU does.  make_args(attempt) ->
+    (args tuple, result dict): a fresh rendezvous port and result dict per attempt."""
+    import sys
+    import torch.multiprocessing as mp
+    for attempt in (0, 1):
+        args, ret = make_args(attempt)
+        try:
+            mp.spawn(fn, args=args, nprocs=8, join=True)
+            return ret
+        except mp.ProcessExitedException as e:
+            if attempt == 1 or getattr(e, "signal_name", None) != "SIGABRT":
+                raise
+            sys.stderr.write(f"test_native_comm_gpu: a worker of the oversubscribed 8-process rig was killed by SIGABRT ({e}); retrying once\n")
+
+
 # ---- W = 8 rehearsal on one GPU: the host logic of an 8-rank run (rank-order sums over 8 addends, row assembly of 8 shards,
 # buckets averaged over 8, 8-way SyncBN) before the first 8-GPU node executes it (VERDICT r4 item 8) ------------------------
 def test_eight_rank_sk_iterate_sharded_matches_reference_golden(double_env, golden_dir):
@@ -190,8 +210,10 @@ def test_eight_rank_sk_iterate_sharded_matches_reference_golden(double_env, gold
     reference, identical alpha / cost / iteration count on all 8 ranks."""
     import torch.multiprocessing as mp
     from tests.test_sk_gpu import _digest, _sharded_worker
-    ret = mp.Manager().dict()
-    mp.spawn(_sharded_worker, args=(8, 27900 + os.getpid() % 400, "sk_vggsound_full", golden_dir, ret, True), nprocs=8, join=True)
+    def make_args(attempt):
+        ret = mp.Manager().dict()
+        return (8, 27900 + os.getpid() % 400 + 443 * attempt, "sk_vggsound_full", golden_dir, ret, True), ret
+    ret = _spawn8(_sharded_worker, make_args)
     g = np.load(os.path.join(golden_dir, "sk_vggsound_full.npz"))
     assert all(len(ret[r][1]) == 21344 for r in range(8))
     L = np.concatenate([ret[r][1] for r in range(8)])
@@ -219,12 +241,15 @@ def test_eight_rank_native_step_keeps_the_ranks_in_lock_step_and_equals_one_larg
     from tests.test_cluster_gpu import _ddp_worker
     monkeypatch.setenv("SLV_DBL_TIMEOUT_S", "120")
     monkeypatch.setenv("SELAVI_NATIVE_COMM", "0")
-    ret_gloo = mp.Manager().dict()
-    mp.spawn(_ddp_worker, args=(8, 25900 + os.getpid() % 300, ret_gloo, "native", "fp32"), nprocs=8, join=True)
+    def make_args(base):
+        def f(attempt):
+            ret = mp.Manager().dict()
+            return (8, base + os.getpid() % 300 + 331 * attempt, ret, "native", "fp32"), ret
+        return f
+    ret_gloo = _spawn8(_ddp_worker, make_args(25900))
     monkeypatch.setenv("SELAVI_NATIVE_COMM", "force")
     monkeypatch.setenv("SELAVI_RCCL_LIB", build_double())
-    ret_nat = mp.Manager().dict()
-    mp.spawn(_ddp_worker, args=(8, 26900 + os.getpid() % 300, ret_nat, "native", "fp32"), nprocs=8, join=True)
+    ret_nat = _spawn8(_ddp_worker, make_args(26900))
     assert all(ret_nat[r][3] >= 3 for r in range(8)), "the native run did not create the library's communicators"
     assert all(ret_gloo[r][3] == 0 for r in range(8))
     for ret in (ret_gloo, ret_nat):
