@@ -236,10 +236,10 @@ def _backend(trunk):
 
 
 def _folded_of(trunk, ectx, need_grad):
-    """infer32.FoldedEval attached to this trunk (infer32.folded_eval) -- taken for eval-mode forwards without autograd state
-    on the fp32 backend only."""
+    """infer32.FoldedEval attached to this trunk (infer32.folded_eval) -- taken for eval-mode forwards on the fp32 backend only
+    (an eval-mode node keeps no autograd state either way: its backward raises, folded or not)."""
     f = getattr(trunk, "_folded_eval", None)
-    if f is None or ectx.training or need_grad or torch.is_grad_enabled() or ectx.ops is not ops:
+    if f is None or ectx.training or need_grad or ectx.ops is not ops:
         return None
     return f
 
