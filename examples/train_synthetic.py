@@ -43,7 +43,7 @@ def parse(argv=None):
     ap.add_argument("--seed", type=int, default=31, help="opt.py:152")
     ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
                     help="bf16: the video trunk trains on the 16-bit MFMA path (main.py:151 --use_fp16)")
-    ap.add_argument("--feature-pass", dest="feature_pass", choices=("fp32", "bf16"), default="fp32",
+    ap.add_argument("--feature-pass", dest="feature_pass", choices=("fp32", "fp32_folded", "fp32x2", "bf16"), default="fp32",
                     help="arithmetic of the SK round's eval forward over the dataset (sk_utils.py:137-233)")
     a = ap.parse_args(argv)
     # what sk_utils.optimize_L_sk_gpu / cluster read from `args` (opt.py)
